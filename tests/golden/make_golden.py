@@ -1,0 +1,113 @@
+"""Generates the golden vectors in this directory by running the REAL reference
+(/root/reference, via oracle/run_reference.py) on CPU in the authoring container.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Inputs and weights come from the build-owned counter-based generator (demonet_amd/synth.py), so only
+(model, seeds) need recording; outputs are stored as float32. Nothing from the reference's source is stored.
+The script asserts that each fixture is far from any order/threshold flip (oracle.selection_margins) so that
+torch.topk's unspecified tie order and torchvision-version-dependent NMS ulps never enter a fixture.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from demonet_amd import spec, synth  # noqa: E402
+import run_reference as rr  # noqa: E402
+import ssd_oracle as so  # noqa: E402
+
+CASES = [
+    # name, num_classes, weight seed, per-image seeds (chosen tie-free by tools/find_tiefree_seeds.py), full-logits images
+    ("ssdlite320_mobilenet_v3_large", 91, 0, [1008, 1021], 1),
+    ("ssd_lite_mobilenet_v2", 21, 0, [1003], 1),
+    ("ssd300_vgg16", 91, 0, [1006], 0),
+    ("ssd512_vgg16", 91, 0, [1005], 0),
+]
+MARGIN_SCORE = 2e-6
+MARGIN_IOU = 8e-6
+
+
+def run_case(name, ncls, wseed, iseeds, nfull):
+    nimg = len(iseeds)
+    g = spec.GRAPHS[name](num_classes=ncls)
+    sd = synth.state_dict(g, wseed)
+    W, H = g.size
+    timgs = [torch.from_numpy(synth.images(s, 1, H, W)[0]) for s in iseeds]
+    post = g.post
+    if name == "ssd_lite_mobilenet_v2":
+        # the hub defaults (score_thresh 0.5) leave almost nothing with synthetic weights; goldens use a
+        # low threshold so the select/NMS path is exercised. Recorded in the fixture.
+        post = dict(post, score_thresh=0.02)
+        ref = rr.ReferenceV2Composite(ncls, W, **post)
+        ref.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        ref.eval()
+        with torch.no_grad():
+            il, feats, head, anchors = ref.forward_raw(timgs)
+            dets = ref(timgs)
+    else:
+        ref = rr.build_reference_model(name, ncls, sd)
+        with torch.no_grad():
+            dets = ref(timgs)
+            il, _ = ref.transform(timgs, None)
+            feats = list(ref.backbone(il.tensors).values())
+            head = ref.head(feats)
+            anchors = ref.anchor_generator(il, feats)
+    out = dict(model=name, num_classes=ncls, weight_seed=wseed, image_seeds=np.array(iseeds), n_images=nimg,
+               post=np.array([post["score_thresh"], post["nms_thresh"], post["detections_per_img"],
+                              post["topk_candidates"]], dtype=np.float64))
+    logits = head["cls_logits"].numpy()
+    reg = head["bbox_regression"].numpy()
+    out["anchors"] = anchors[0].numpy()
+    out["bbox_regression"] = reg
+    for i in range(nimg):
+        if i < nfull:
+            out[f"cls_logits_full_{i}"] = logits[i]
+        out[f"cls_logits_rows_{i}"] = logits[i][::7]
+        out[f"cls_logits_sum_{i}"] = np.array([logits[i].astype(np.float64).sum(), np.abs(logits[i]).astype(np.float64).sum()])
+    for lvl, f in enumerate(feats):
+        fn = f.numpy()
+        out[f"feat{lvl}_shape"] = np.array(fn.shape)
+        out[f"feat{lvl}_sample"] = fn.reshape(fn.shape[0], -1)[:, ::max(1, fn[0].size // 4096)]
+        out[f"feat{lvl}_sum"] = np.array([fn.astype(np.float64).sum(), np.abs(fn).astype(np.float64).sum()])
+    # oracle agreement + fixture hygiene
+    o = so.OracleSSD(name, sd, ncls, size=g.size, **post)
+    odets, raw = o(timgs, return_intermediates=True)
+    dl = float(np.abs(raw["cls_logits"].numpy() - logits).max())
+    dr = float(np.abs(raw["bbox_regression"].numpy() - reg).max())
+    da = float(np.abs(raw["anchors"].numpy() - out["anchors"]).max())
+    print(f"{name}: oracle-vs-reference max|d| logits {dl:.3g} regression {dr:.3g} anchors {da:.3g}")
+    assert dl < 1e-4 and dr < 1e-4 and da == 0.0
+    for i in range(nimg):
+        d, od = dets[i], odets[i]
+        n = d["boxes"].shape[0]
+        out[f"det_boxes_{i}"] = d["boxes"].numpy()
+        out[f"det_scores_{i}"] = d["scores"].numpy()
+        out[f"det_labels_{i}"] = d["labels"].numpy()
+        out[f"det_anchor_idx_{i}"] = od["anchor_idx"]
+        assert od["boxes"].shape[0] == n, (od["boxes"].shape, n)
+        assert (od["labels"] == d["labels"].numpy()).all()
+        assert np.abs(od["boxes"] - d["boxes"].numpy()).max() < 1e-3
+        assert np.abs(od["scores"] - d["scores"].numpy()).max() < 1e-6
+        m = so.selection_margins(od["softmax"], od["decoded"], post["score_thresh"], post["nms_thresh"],
+                                 post["topk_candidates"], post["detections_per_img"])
+        print(f"   image {i}: {n} detections; margins " + ", ".join(f"{k}={v:.3g}" for k, v in m.items()))
+        assert m["topk_gap"] > MARGIN_SCORE and m["order_gap"] > MARGIN_SCORE and m["final_gap"] > MARGIN_SCORE, m
+        assert m["thresh_gap"] > MARGIN_SCORE and m["iou_gap"] > MARGIN_IOU, m
+        out[f"margins_{i}"] = np.array([m[k] for k in ("thresh_gap", "topk_gap", "order_gap", "iou_gap", "final_gap")])
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print("   wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    for c in CASES:
+        if not only or c[0] in only:
+            run_case(*c)
