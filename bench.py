@@ -1,0 +1,219 @@
+"""Headline benchmark: images/sec of the SSD inference hot path (incl. NMS) on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the whole hot path (stem .. heads .. softmax/decode/top-k/NMS/merge) over one device-resident
+batch of synthetic 320x320 images (BASELINE.json configs[1]: ssdlite320_mobilenet_v3_large fp16, batch 64 per GPU).
+Timing window = engine.evaluate's (engine.py:86-94): inputs already on the device, synchronize, forward incl.
+post-process, outputs complete on the stream. N > 1: every rank runs its own 64-image shard (weak scaling) and the
+fixed-shape detections are all-gathered over RCCL each step.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16
+
+
+def op_costs(graph, n):
+    """Algorithmic bytes / flops per op for a batch of n (fp16 tensors, fp32 bias; fused op = external bytes)."""
+    out = []
+    for nd in graph.nodes:
+        ti, to = graph.t(nd.inp), graph.t(nd.out)
+        if nd.op == "stem":
+            m = n * to.h * to.w
+            b = 4 * n * 3 * ti.h * ti.w + 2 * m * nd.cout + 4 * (27 * nd.cout + nd.cout)
+            f = 2 * m * 3 * nd.k * nd.k * nd.cout
+            kern = f"stem_kernel<{nd.cout}>"
+        elif nd.op in ("pw", "conv"):
+            m = n * to.h * to.w
+            kk = nd.k * nd.k * nd.cin
+            ob = 4 if nd.head else 2
+            b = 2 * m * (nd.cin if nd.op == "pw" else nd.cin * (ti.h * ti.w) / (to.h * to.w)) + ob * m * nd.cout \
+                + 2 * kk * nd.cout + 4 * nd.cout
+            if nd.residual >= 0:
+                b += 2 * m * nd.cout
+            f = 2 * m * kk * nd.cout
+            cfg = "256x32" if nd.cout <= 32 else ("128x64" if nd.cout <= 64 else "128x128")
+            kern = f"pw_kernel<{cfg}{',conv' if nd.op == 'conv' else ''}>"
+        elif nd.op == "dw":
+            b = 2 * n * (ti.h * ti.w + to.h * to.w) * nd.cin + 2 * nd.k * nd.k * nd.cin + 4 * nd.cin
+            if nd.pool >= 0:
+                b += 2 * n * to.h * to.w * nd.cin          # v1: separate pooling pass re-reads the output
+            f = 2 * n * to.h * to.w * nd.cin * nd.k * nd.k
+            kern = f"dw_kernel<{nd.k},{nd.stride}>"
+        elif nd.op == "se":
+            b = 4 * (2 * nd.cin * nd.squeeze + 2 * n * nd.cin)
+            f = 4 * n * nd.cin * nd.squeeze
+            kern = "se_fc_kernel"
+        elif nd.op == "maxpool":
+            b = 2 * n * (ti.h * ti.w + to.h * to.w) * nd.cin
+            f = 0
+            kern = "maxpool_kernel"
+        else:
+            b = 4 * n * ti.h * ti.w * nd.cin
+            f = 3 * n * ti.h * ti.w * nd.cin
+            kern = "l2norm_kernel"
+        out.append(dict(kernel=kern, bytes=float(b), flops=float(f)))
+    A, K = graph.num_anchors(), graph.num_classes
+    topk, D = graph.post["topk_candidates"], graph.post["detections_per_img"]
+    out.append(dict(kernel="softmax_decode_kernel", bytes=float(n * A * (4 * K + 16 + 4 * (K - 1) + 16)), flops=float(5 * n * A * K)))
+    out.append(dict(kernel="select_nms_kernel", bytes=float(n * (K - 1) * (4 * A + 24 * topk)), flops=float(25 * n * (K - 1) * topk * topk / 2)))
+    out.append(dict(kernel="merge_kernel", bytes=float(n * ((K - 1) * topk * 8 + D * 40)), flops=0.0))
+    return out
+
+
+def cpu_baseline(name, graph, seed, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, fp32 PyTorch eager) timed on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ssd_oracle as so
+    from demonet_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    o = so.OracleSSD(name, synth.state_dict(graph, 0), graph.num_classes, size=graph.size)
+    W, H = graph.size
+    bs = 8
+    imgs = [torch.from_numpy(synth.images(seed + i, 1, H, W)[0]) for i in range(bs)]
+    o(imgs[:1])                                   # warm-up
+    t0 = time.time()
+    done = 0
+    while True:
+        o(imgs)
+        done += bs
+        if time.time() - t0 > budget_s or done >= 64:
+            break
+    dt = time.time() - t0
+    return {"value": round(done / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{done} synthetic 320x320 images in batches of {bs}, full path incl. NMS, fp32 torch CPU eager, "
+                      f"{cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--model", default="ssdlite320_mobilenet_v3_large")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from demonet_amd import models, synth
+    from demonet_amd.dist import pack_detections, gather_detections
+    ncls = 21 if args.model == "ssd_lite_mobilenet_v2" else 91
+    model = models.load_synthetic(getattr(models, args.model)(num_classes=ncls), 0).to(dev)
+    g = model.graph
+    W, H = g.size
+    B = args.batch
+    images = torch.from_numpy(synth.images(1002 + rank, B, H, W)).to(dev)      # device-resident input (engine.py:86)
+    if args.eager:
+        model.set_graph_mode(False)
+
+    def step():
+        boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True)
+        if distributed:
+            gather_detections(pack_detections(boxes, scores, labels), counts)
+        return counts
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    result = {
+        "metric": "images/sec ssdlite320_mobilenet_v3_large fp16 end-to-end incl. NMS" if args.model.startswith("ssdlite320")
+                  else f"images/sec {args.model} fp16 end-to-end incl. NMS",
+        "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "ms_per_img": round(ms_per_step / B, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": f"{args.model} fp16, batch {B} per GPU, {H}x{W} synthetic images, K={ncls}, "
+                               f"synthetic weights seed 0, post-process incl. per-class top-{g.post['topk_candidates']} + hard NMS",
+                   "global_batch": B * world, "launch": "eager" if args.eager else "hipGraph replay",
+                   "parallelism": f"image-sharded x{world}, RCCL all_gather of detections" if distributed else "single GPU",
+                   "mean_detections": float(counts.float().mean().item())},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-kernel device time: HIP events around every launch on the forward stream (eager pass, same inputs)
+        from demonet_amd import _lib
+        L = _lib.lib()
+        h = C.c_void_p(model._handle)
+        nseg = len(g.nodes) + 3
+        _lib.check(L.dn_profile_begin(h))
+        for _ in range(min(args.steps, 20)):
+            model.forward_batch(images, persistent_input=True)
+        buf = (C.c_float * nseg)()
+        runs = _lib.check(L.dn_profile_end(h, buf, nseg))
+        costs = op_costs(g, B)
+        agg = {}
+        for c, ms in zip(costs, buf):
+            a = agg.setdefault(c["kernel"], dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+            a["ms"] += ms
+            a["bytes"] += c["bytes"]
+            a["flops"] += c["flops"]
+            a["launches"] += 1
+        total_ms = sum(a["ms"] for a in agg.values())
+        dom = max(agg, key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                              "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
+                              "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                              "share_of_step": round(d["ms"] / total_ms, 3), "profiled_runs": runs,
+                              "eager_sum_ms": round(total_ms, 4)}
+        result["kernels"] = {k: {"ms": round(v["ms"], 4), "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                 "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "launches": v["launches"]}
+                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.model, g, 1002)
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

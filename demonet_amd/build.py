@@ -1,0 +1,56 @@
+"""Builds demonet_amd/lib/libdemonet_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m demonet_amd.build [--force]
+
+One object per .hip file (postprocess.hip with -ffp-contract=off: decode/IoU must round like the reference),
+linked into one C-ABI shared library. In-tree output so the .so travels with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdemonet_hip.so")
+SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip"]
+EXTRA = {"postprocess.hip": ["-ffp-contract=off"]}
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+          "-fvisibility=hidden", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "demonet_hip.h")]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + headers):
+            cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    if force or procs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,101 @@
+// Shared device/host helpers for the gfx950 SSD library. CDNA4 only: wave64, MFMA, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/demonet_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+void dn_set_error(const char* fmt, ...);
+
+#define DN_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            dn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DN_E_HIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+#define DN_REQUIRE(cond, ...)                                                                \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            dn_set_error(__VA_ARGS__);                                                       \
+            return DN_E_INVALID;                                                             \
+        }                                                                                    \
+    } while (0)
+
+__device__ __forceinline__ float dn_act(float v, int act) {
+    // Hardswish x*relu6(x+3)/6, ReLU6 clamp [0,6] (mobilenetv3.py:72, ssd_mobilenetv3.py:31)
+    if (act == DN_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DN_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    if (act == DN_ACT_HSWISH) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    return v;
+}
+
+static inline int dn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// launchers implemented by the per-kernel translation units (used by plan.hip and by the single-op C entry points)
+struct PwArgs {
+    // implicit-GEMM geometry (dense kxk conv); pointwise uses k=1: x rows are then simply [m][cin]
+    int cv_k = 1, cv_stride = 1, cv_pad = 0, cv_dil = 1, cv_h = 0, cv_w = 0, cv_ho = 0, cv_wo = 0, cv_cin = 0;
+    const half_t* x;        // [m][cin]
+    const half_t* w;        // [cout][cin]
+    const float* bias;      // [cout]
+    const half_t* residual; // [m][cout] or null
+    const float* se;        // [m/hw][cin] or null
+    void* out;
+    int m, cin, cout, hw, act, out_fp32;
+    long out_img_stride;    // elements between images in `out`
+    long out_base;          // element offset of image 0 (head ops: level offset * columns)
+};
+int launch_pointwise(const PwArgs& a, hipStream_t s);
+
+struct DwArgs {
+    const half_t* x; const half_t* w; const float* bias; half_t* out;
+    int n, h, w_, c, k, stride, pad, act, ho, wo;
+};
+int launch_depthwise(const DwArgs& a, hipStream_t s);
+
+struct StemArgs {
+    const float* img;       // [n][3][h][w] fp32 (raw, 0..1)
+    const float* w;         // [k*k*3][cout] fp32, tap index = (c*k + ky)*k + kx
+    const float* bias;      // [cout]
+    half_t* out;            // [n][ho][wo][cout]
+    int n, h, w_, cout, k, stride, pad, act, ho, wo;
+    float mean[3], inv_std_unused[3], std[3];
+};
+int launch_stem(const StemArgs& a, hipStream_t s);
+
+int launch_se_pool(const half_t* x, float* sums, int n, int hw, int c, hipStream_t s);
+int launch_se_fc(const float* sums, const float* w1t, const float* b1, const float* w2t, const float* b2,
+                 float* scale, int n, int c, int squeeze, int pool_pixels, hipStream_t s);
+
+struct ConvArgs {
+    const half_t* x; const half_t* w; const float* bias; void* out;
+    int n, h, w_, cin, cout, k, stride, pad, dil, act, ho, wo, out_fp32;
+    long out_img_stride, out_base;
+};
+int launch_conv(const ConvArgs& a, hipStream_t s);
+int launch_maxpool(const half_t* x, half_t* out, int n, int h, int w, int c, int k, int stride, int pad, int ho, int wo,
+                   hipStream_t s);
+int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels, int c, hipStream_t s);
+// bilinear (align_corners=False) resize of NCHW fp32 planes; also writes scale_xy[n][2] = (w/ow, h/oh) in fp32
+int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s);
+
+struct PostArgs {
+    const float* logits; const float* reg; const float* anchors;
+    int n, A, K;
+    float img_h, img_w; const float* scale_xy;
+    float score_thresh, nms_thresh; int topk, dets;
+    float* boxes; float* scores; int64_t* labels; int32_t* counts; int32_t* kept_anchor;
+    void* ws; size_t ws_bytes;
+};
+size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets);
+int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev /* optional [4] phase boundaries */);

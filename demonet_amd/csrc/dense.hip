@@ -1,0 +1,113 @@
+// VGG-path helpers and input resize: max-pool, L2-normalise x scale, bilinear resize. The dense kxk convolution
+// itself is the implicit-GEMM instantiation of the MFMA kernel in pointwise.hip.
+//
+// reference ops replaced: nn.MaxPool2d (ssd_vgg16.py:34-37,85), F.normalize * scale_weight (ssd_vgg16.py:101),
+//   F.interpolate(mode='bilinear', align_corners=False) (transform.py:52-53).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int n, int h, int w,
+                                                     int c, int k, int stride, int pad, int ho, int wo) {
+    const int C8 = c >> 3;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(idx % C8);
+    idx /= C8;
+    const int ox = (int)(idx % wo);
+    idx /= wo;
+    const int oy = (int)(idx % ho);
+    const int nn = (int)(idx / ho);
+    if (nn >= n) return;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int ky = 0; ky < k; ++ky) {
+        const int iy = oy * stride - pad + ky;
+        if (iy < 0 || iy >= h) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int ix = ox * stride - pad + kx;
+            if (ix < 0 || ix >= w) continue;
+            const half8 v = *reinterpret_cast<const half8*>(x + ((size_t)(nn * h + iy) * w + ix) * c + cg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
+    *reinterpret_cast<half8*>(out + ((size_t)(nn * ho + oy) * wo + ox) * c + cg * 8) = o;
+}
+
+// one wave per pixel: x / max(||x||_2, 1e-12) * scale[c]
+__global__ __launch_bounds__(256) void l2norm_kernel(const half_t* __restrict__ x, const float* __restrict__ scale,
+                                                    half_t* __restrict__ out, long pixels, int c) {
+    const int lane = threadIdx.x & 63;
+    const long px = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (px >= pixels) return;
+    const half_t* p = x + (size_t)px * c;
+    float ss = 0.f;
+    for (int c0 = lane * 8; c0 < c; c0 += 512) {
+        const half8 v = *reinterpret_cast<const half8*>(p + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ss += __shfl_xor(ss, d);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int c0 = lane * 8; c0 < c; c0 += 512) {
+        const half8 v = *reinterpret_cast<const half8*>(p + c0);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)v[e] * inv * scale[c0 + e]);
+        *reinterpret_cast<half8*>(out + (size_t)px * c + c0) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                    float* __restrict__ scale_xy, int planes, int h, int w, int oh, int ow) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < planes / 3) {      // one entry per image
+        if (scale_xy) {
+            scale_xy[2 * idx] = (float)w / (float)ow;
+            scale_xy[2 * idx + 1] = (float)h / (float)oh;
+        }
+    }
+    const int ox = (int)(idx % ow);
+    idx /= ow;
+    const int oy = (int)(idx % oh);
+    const long pl = idx / oh;
+    if (pl >= planes) return;
+    const float rh = (float)h / (float)oh, rw = (float)w / (float)ow;
+    const float sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const float sx = fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = in + (size_t)pl * h * w;
+    const float v = hy * (hx * p[(size_t)y0 * w + x0] + lx * p[(size_t)y0 * w + x1]) +
+                    ly * (hx * p[(size_t)y1 * w + x0] + lx * p[(size_t)y1 * w + x1]);
+    out[((size_t)pl * oh + oy) * ow + ox] = v;
+}
+
+}  // namespace
+
+int launch_maxpool(const half_t* x, half_t* out, int n, int h, int w, int c, int k, int stride, int pad, int ho, int wo,
+                   hipStream_t s) {
+    DN_REQUIRE(c % 8 == 0, "maxpool: c=%d must be a multiple of 8", c);
+    const long threads = (long)n * ho * wo * (c / 8);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, x, out, n, h, w, c, k, stride, pad, ho, wo);
+    return DN_OK;
+}
+
+int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels, int c, hipStream_t s) {
+    DN_REQUIRE(c % 8 == 0, "l2norm: c=%d must be a multiple of 8", c);
+    hipLaunchKernelGGL(l2norm_kernel, dim3(dn_cdiv(pixels, 4)), dim3(256), 0, s, x, scale, out, pixels, c);
+    return DN_OK;
+}
+
+int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s) {
+    const long threads = (long)n * 3 * oh * ow;
+    hipLaunchKernelGGL(resize_kernel, dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, in, out, scale_xy, n * 3, h, w, oh, ow);
+    return DN_OK;
+}

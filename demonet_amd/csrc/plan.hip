@@ -1,0 +1,467 @@
+// C-ABI implementation: plan construction, workspace layout, launch sequence, hipGraph caching, profiling hook.
+// Host-side only (no kernels here). See include/demonet_hip.h for the contract.
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void dn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dn_last_error(void) { return g_err; }
+extern "C" int dn_abi_version(void) { return DN_ABI_VERSION; }
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    int n = 0;
+    std::vector<size_t> toff;       // per tensor byte offset in workspace (SIZE_MAX: not materialised)
+    std::vector<size_t> tbytes;
+    size_t resized_off = 0, logits_off = 0, reg_off = 0, scale_off = 0, post_off = 0, post_bytes = 0, total = 0;
+};
+
+struct GraphKey {
+    const void* img; int n, h, w; void* ws; void* boxes; void* scores; void* labels; void* counts; int heads_only;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(img, n, h, w, ws, boxes, scores, labels, counts, heads_only) <
+               std::tie(o.img, o.n, o.h, o.w, o.ws, o.boxes, o.scores, o.labels, o.counts, o.heads_only);
+    }
+};
+
+struct dn_plan {
+    dn_model_desc d;
+    std::vector<dn_tensor_desc> tensors;
+    std::vector<dn_op_desc> ops;
+    std::vector<int> level_off;         // anchor offset per level
+    unsigned char* weights_dev = nullptr;
+    size_t weight_bytes = 0;
+    float* anchors_dev = nullptr;
+    std::map<int, Layout> layouts;
+    bool graph_mode = true;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    std::vector<double> prof_ms;
+    int prof_runs = 0;
+};
+
+static const Layout& get_layout(dn_plan* p, int n) {
+    auto it = p->layouts.find(n);
+    if (it != p->layouts.end()) return it->second;
+    Layout L;
+    L.n = n;
+    size_t off = 0;
+    const size_t T = p->tensors.size();
+    L.toff.assign(T, (size_t)-1);
+    L.tbytes.assign(T, 0);
+    for (size_t i = 0; i < T; ++i) {
+        const dn_tensor_desc& t = p->tensors[i];
+        size_t b = 0;
+        if (t.kind == DN_T_ACT) b = (size_t)n * t.h * t.w * t.c * 2;
+        else if (t.kind == DN_T_VEC || t.kind == DN_T_POOL) b = (size_t)n * t.c * 4;
+        else continue;      // image: caller's buffer (or the resized copy below)
+        L.toff[i] = off;
+        L.tbytes[i] = b;
+        off += align256(b);
+    }
+    L.resized_off = off;
+    off += align256((size_t)n * 3 * p->d.image_h * p->d.image_w * 4);
+    L.logits_off = off;
+    off += align256((size_t)n * p->d.num_anchors * p->d.num_classes * 4);
+    L.reg_off = off;
+    off += align256((size_t)n * p->d.num_anchors * 4 * 4);
+    L.scale_off = off;
+    off += align256((size_t)n * 2 * 4);
+    L.post_off = off;
+    L.post_bytes = postprocess_ws_bytes(n, p->d.num_anchors, p->d.num_classes, p->d.topk_candidates, p->d.detections_per_img);
+    off += align256(L.post_bytes);
+    L.total = off;
+    return p->layouts.emplace(n, std::move(L)).first->second;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t weight_bytes, dn_plan** out) {
+    DN_REQUIRE(desc && weights && out, "dn_create: null argument");
+    DN_REQUIRE(desc->abi_version == DN_ABI_VERSION, "dn_create: ABI version %d != library %d", desc->abi_version, DN_ABI_VERSION);
+    DN_REQUIRE(desc->n_tensors > 0 && desc->n_ops > 0 && desc->tensors && desc->ops, "dn_create: empty graph");
+    DN_REQUIRE(desc->n_levels >= 1 && desc->n_levels <= 8, "dn_create: n_levels=%d outside [1,8]", desc->n_levels);
+    DN_REQUIRE(desc->num_classes >= 2, "dn_create: num_classes must include background (>= 2)");
+    DN_REQUIRE(desc->anchors && desc->num_anchors > 0, "dn_create: anchors missing");
+    DN_REQUIRE(desc->score_thresh >= 0.f, "dn_create: score_thresh must be >= 0");
+    dn_plan* p = new dn_plan();
+    p->d = *desc;
+    p->tensors.assign(desc->tensors, desc->tensors + desc->n_tensors);
+    p->ops.assign(desc->ops, desc->ops + desc->n_ops);
+    p->d.tensors = p->tensors.data();
+    p->d.ops = p->ops.data();
+    // validate ops
+    auto fail = [&](int rc) { delete p; return rc; };
+    for (int i = 0; i < desc->n_ops; ++i) {
+        const dn_op_desc& o = p->ops[i];
+        auto ok_t = [&](int t) { return t >= 0 && t < desc->n_tensors; };
+        if (!ok_t(o.in) || !ok_t(o.out)) { dn_set_error("dn_create: op %d has bad tensor ids", i); return fail(DN_E_INVALID); }
+        if (o.w_off >= 0 && (size_t)o.w_off >= weight_bytes) { dn_set_error("dn_create: op %d weight offset out of range", i); return fail(DN_E_INVALID); }
+        if (o.type < DN_OP_STEM || o.type > DN_OP_L2NORM) { dn_set_error("dn_create: op %d unknown type %d", i, o.type); return fail(DN_E_INVALID); }
+        if (o.head && (o.level < 0 || o.level >= desc->n_levels)) { dn_set_error("dn_create: head op %d bad level", i); return fail(DN_E_INVALID); }
+    }
+    // anchor offsets per level
+    int acc = 0;
+    for (int l = 0; l < desc->n_levels; ++l) {
+        const dn_tensor_desc& t = p->tensors[desc->level_tensor[l]];
+        p->level_off.push_back(acc);
+        acc += t.h * t.w * desc->anchors_per_loc[l];
+    }
+    if (acc != desc->num_anchors) {
+        dn_set_error("dn_create: anchors per level sum to %d, desc says %d", acc, desc->num_anchors);
+        return fail(DN_E_INVALID);
+    }
+    hipError_t e = hipMalloc((void**)&p->weights_dev, weight_bytes);
+    if (e == hipSuccess) e = hipMemcpy(p->weights_dev, weights, weight_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->anchors_dev, (size_t)desc->num_anchors * 16);
+    if (e == hipSuccess) e = hipMemcpy(p->anchors_dev, desc->anchors, (size_t)desc->num_anchors * 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        dn_set_error("dn_create: device allocation/upload failed: %s", hipGetErrorString(e));
+        if (p->weights_dev) (void)hipFree(p->weights_dev);
+        if (p->anchors_dev) (void)hipFree(p->anchors_dev);
+        return fail(DN_E_HIP);
+    }
+    p->weight_bytes = weight_bytes;
+    p->d.anchors = nullptr;
+    *out = p;
+    return DN_OK;
+}
+
+extern "C" void dn_destroy(dn_plan* p) {
+    if (!p) return;
+    for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto ev : p->events) (void)hipEventDestroy(ev);
+    if (p->weights_dev) (void)hipFree(p->weights_dev);
+    if (p->anchors_dev) (void)hipFree(p->anchors_dev);
+    delete p;
+}
+
+extern "C" size_t dn_workspace_bytes(const dn_plan* p, int n) {
+    if (!p || n <= 0) return 0;
+    return get_layout(const_cast<dn_plan*>(p), n).total;
+}
+
+extern "C" int dn_set_graph_mode(dn_plan* p, int enabled) {
+    DN_REQUIRE(p, "null plan");
+    p->graph_mode = enabled != 0;
+    return DN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the launch sequence
+// ---------------------------------------------------------------------------------------------------------
+static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
+                   int32_t* counts, unsigned char* ws, const Layout& L, bool heads_only, hipStream_t s, bool record) {
+    const dn_model_desc& d = p->d;
+    auto tptr = [&](int tid) -> void* { return ws + L.toff[tid]; };
+    const float* net_in = images;
+    const bool resize = (h != d.image_h || w != d.image_w);
+    float* scale_xy = nullptr;
+    if (resize) {
+        // normalisation commutes with bilinear interpolation (affine per channel), so resizing the raw image first and
+        // normalising on load in the stem equals transform.py:113-114 (normalize then resize) up to fp32 rounding.
+        float* rz = reinterpret_cast<float*>(ws + L.resized_off);
+        scale_xy = reinterpret_cast<float*>(ws + L.scale_off);
+        int rc = launch_resize_bilinear(images, rz, scale_xy, n, h, w, d.image_h, d.image_w, s);
+        if (rc) return rc;
+        net_in = rz;
+    }
+    float* logits = reinterpret_cast<float*>(ws + L.logits_off);
+    float* reg = reinterpret_cast<float*>(ws + L.reg_off);
+    int ev = 0;
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const dn_op_desc& o = p->ops[i];
+        const dn_tensor_desc& ti = p->tensors[o.in];
+        const dn_tensor_desc& to = p->tensors[o.out];
+        if (record) (void)hipEventRecord(p->events[ev++], s);
+        int rc = DN_OK;
+        const unsigned char* W = p->weights_dev;
+        switch (o.type) {
+            case DN_OP_STEM: {
+                StemArgs a;
+                a.img = net_in;
+                a.w = reinterpret_cast<const float*>(W + o.w_off);
+                a.bias = reinterpret_cast<const float*>(W + o.b_off);
+                a.out = reinterpret_cast<half_t*>(tptr(o.out));
+                a.n = n; a.h = ti.h; a.w_ = ti.w; a.cout = o.cout; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
+                a.ho = to.h; a.wo = to.w;
+                for (int c = 0; c < 3; ++c) { a.mean[c] = d.mean[c]; a.std[c] = d.std[c]; a.inv_std_unused[c] = 0.f; }
+                rc = launch_stem(a, s);
+                break;
+            }
+            case DN_OP_PW: {
+                PwArgs a;
+                a.x = reinterpret_cast<const half_t*>(tptr(o.in));
+                a.w = reinterpret_cast<const half_t*>(W + o.w_off);
+                a.bias = reinterpret_cast<const float*>(W + o.b_off);
+                a.residual = o.residual >= 0 ? reinterpret_cast<const half_t*>(tptr(o.residual)) : nullptr;
+                a.se = o.se >= 0 ? reinterpret_cast<const float*>(tptr(o.se)) : nullptr;
+                a.hw = ti.h * ti.w;
+                a.m = n * a.hw;
+                a.cin = o.cin; a.cout = o.cout; a.act = o.act;
+                if (o.head) {
+                    const int cols = (o.head == 1) ? d.num_classes : 4;
+                    a.out = (o.head == 1) ? (void*)logits : (void*)reg;
+                    a.out_fp32 = 1;
+                    a.out_img_stride = (long)d.num_anchors * cols;
+                    a.out_base = (long)p->level_off[o.level] * cols;
+                } else {
+                    a.out = tptr(o.out);
+                    a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
+                }
+                rc = launch_pointwise(a, s);
+                break;
+            }
+            case DN_OP_DW: {
+                DwArgs a;
+                a.x = reinterpret_cast<const half_t*>(tptr(o.in));
+                a.w = reinterpret_cast<const half_t*>(W + o.w_off);
+                a.bias = reinterpret_cast<const float*>(W + o.b_off);
+                a.out = reinterpret_cast<half_t*>(tptr(o.out));
+                a.n = n; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
+                a.ho = to.h; a.wo = to.w;
+                rc = launch_depthwise(a, s);
+                if (rc == DN_OK && o.pool >= 0)
+                    rc = launch_se_pool(a.out, reinterpret_cast<float*>(tptr(o.pool)), n, to.h * to.w, o.cin, s);
+                break;
+            }
+            case DN_OP_SE: {
+                rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), reinterpret_cast<const float*>(W + o.w_off),
+                                  reinterpret_cast<const float*>(W + o.b_off), reinterpret_cast<const float*>(W + o.w2_off),
+                                  reinterpret_cast<const float*>(W + o.b2_off), reinterpret_cast<float*>(tptr(o.out)), n,
+                                  o.cin, o.squeeze, o.pool_pixels, s);
+                break;
+            }
+            case DN_OP_CONV: {
+                ConvArgs a;
+                a.x = reinterpret_cast<const half_t*>(tptr(o.in));
+                a.w = reinterpret_cast<const half_t*>(W + o.w_off);
+                a.bias = reinterpret_cast<const float*>(W + o.b_off);
+                a.n = n; a.h = ti.h; a.w_ = ti.w; a.cin = o.cin; a.cout = o.cout; a.k = o.k; a.stride = o.stride;
+                a.pad = o.pad; a.dil = o.dil; a.act = o.act; a.ho = to.h; a.wo = to.w;
+                if (o.head) {
+                    const int cols = (o.head == 1) ? d.num_classes : 4;
+                    a.out = (o.head == 1) ? (void*)logits : (void*)reg;
+                    a.out_fp32 = 1;
+                    a.out_img_stride = (long)d.num_anchors * cols;
+                    a.out_base = (long)p->level_off[o.level] * cols;
+                } else {
+                    a.out = tptr(o.out);
+                    a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
+                }
+                rc = launch_conv(a, s);
+                break;
+            }
+            case DN_OP_MAXPOOL:
+                rc = launch_maxpool(reinterpret_cast<const half_t*>(tptr(o.in)), reinterpret_cast<half_t*>(tptr(o.out)), n,
+                                    ti.h, ti.w, ti.c, o.k, o.stride, o.pad, to.h, to.w, s);
+                break;
+            case DN_OP_L2NORM:
+                rc = launch_l2norm(reinterpret_cast<const half_t*>(tptr(o.in)), reinterpret_cast<const float*>(W + o.w_off),
+                                   reinterpret_cast<half_t*>(tptr(o.out)), (long)n * ti.h * ti.w, ti.c, s);
+                break;
+        }
+        if (rc != DN_OK) return rc;
+    }
+    if (!heads_only) {
+        PostArgs a;
+        a.logits = logits; a.reg = reg; a.anchors = p->anchors_dev;
+        a.n = n; a.A = d.num_anchors; a.K = d.num_classes;
+        a.img_h = (float)d.image_h; a.img_w = (float)d.image_w;
+        a.scale_xy = nullptr;
+        // ratio = original / network size in fp32 (transform.py:280-285), written by the resize kernel
+        if (resize) a.scale_xy = scale_xy;
+        a.score_thresh = d.score_thresh; a.nms_thresh = d.nms_thresh; a.topk = d.topk_candidates; a.dets = d.detections_per_img;
+        a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = nullptr;
+        a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
+        hipEvent_t* pe = record ? &p->events[ev] : nullptr;
+        int rc = launch_postprocess(a, s, pe);
+        if (rc) return rc;
+        ev += 4;
+    } else if (record) {
+        (void)hipEventRecord(p->events[ev++], s);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dn_set_error("kernel launch failed: %s", hipGetErrorString(e));
+        return DN_E_HIP;
+    }
+    return DN_OK;
+}
+
+static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
+                        int32_t* counts, void* workspace, size_t ws_bytes, void* stream, bool heads_only) {
+    DN_REQUIRE(p && images && workspace, "dn_forward: null argument");
+    DN_REQUIRE(n > 0 && h > 0 && w > 0, "dn_forward: bad shape n=%d h=%d w=%d", n, h, w);
+    DN_REQUIRE(heads_only || (boxes && scores && labels && counts), "dn_forward: null output buffer");
+    const Layout& L = get_layout(p, n);
+    if (ws_bytes < L.total) {
+        dn_set_error("dn_forward: workspace %zu B < required %zu B for n=%d", ws_bytes, L.total, n);
+        return DN_E_WORKSPACE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    if (p->profiling) {
+        const size_t need = p->ops.size() + 5;
+        while (p->events.size() < need) {
+            hipEvent_t e;
+            DN_HIP_CHECK(hipEventCreate(&e));
+            p->events.push_back(e);
+        }
+        int rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, true);
+        if (rc) return rc;
+        DN_HIP_CHECK(hipStreamSynchronize(s));
+        const size_t nseg = heads_only ? p->ops.size() : p->ops.size() + 3;
+        if (p->prof_ms.size() < p->ops.size() + 3) p->prof_ms.assign(p->ops.size() + 3, 0.0);
+        for (size_t i = 0; i < nseg; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, p->events[i], p->events[i + 1]);
+            p->prof_ms[i] += ms;
+        }
+        p->prof_runs++;
+        return DN_OK;
+    }
+    if (!p->graph_mode) return enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
+
+    GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, heads_only ? 1 : 0};
+    auto it = p->graphs.find(key);
+    if (it == p->graphs.end()) {
+        // first call with this signature: run once eagerly (sets function attributes, validates), then capture
+        int rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
+        if (rc) return rc;
+        hipGraph_t g = nullptr;
+        DN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) { dn_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DN_E_HIP; }
+        hipGraphExec_t ge = nullptr;
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { dn_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return DN_E_HIP; }
+        if (p->graphs.size() >= 16) {       // bound the cache
+            for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
+            p->graphs.clear();
+        }
+        p->graphs.emplace(key, ge);
+        return DN_OK;       // the eager run above already produced this call's results
+    }
+    DN_HIP_CHECK(hipGraphLaunch(it->second, s));
+    return DN_OK;
+}
+
+extern "C" int dn_forward(dn_plan* plan, const float* images_dev, int n, int h, int w, float* boxes_dev, float* scores_dev,
+                          int64_t* labels_dev, int32_t* counts_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    return forward_impl(plan, images_dev, n, h, w, boxes_dev, scores_dev, labels_dev, counts_dev, workspace_dev,
+                        workspace_bytes, stream, false);
+}
+
+extern "C" int dn_forward_heads(dn_plan* plan, const float* images_dev, int n, int h, int w, void* workspace_dev,
+                                size_t workspace_bytes, void* stream) {
+    return forward_impl(plan, images_dev, n, h, w, nullptr, nullptr, nullptr, nullptr, workspace_dev, workspace_bytes, stream,
+                        true);
+}
+
+extern "C" int dn_head_outputs(const dn_plan* p, void* workspace, int n, float** logits, float** reg) {
+    DN_REQUIRE(p && workspace && n > 0, "dn_head_outputs: bad argument");
+    const Layout& L = get_layout(const_cast<dn_plan*>(p), n);
+    if (logits) *logits = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + L.logits_off);
+    if (reg) *reg = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + L.reg_off);
+    return DN_OK;
+}
+
+extern "C" int dn_tensor_ptr(const dn_plan* p, void* workspace, int n, int tensor_id, void** ptr, size_t* bytes) {
+    DN_REQUIRE(p && workspace && n > 0 && ptr, "dn_tensor_ptr: bad argument");
+    DN_REQUIRE(tensor_id >= 0 && tensor_id < (int)p->tensors.size(), "dn_tensor_ptr: tensor id %d out of range", tensor_id);
+    const Layout& L = get_layout(const_cast<dn_plan*>(p), n);
+    DN_REQUIRE(L.toff[tensor_id] != (size_t)-1, "dn_tensor_ptr: tensor %d is not materialised in the workspace", tensor_id);
+    *ptr = reinterpret_cast<unsigned char*>(workspace) + L.toff[tensor_id];
+    if (bytes) *bytes = L.tbytes[tensor_id];
+    return DN_OK;
+}
+
+extern "C" int dn_profile_begin(dn_plan* p) {
+    DN_REQUIRE(p, "null plan");
+    p->profiling = true;
+    p->prof_ms.assign(p->ops.size() + 3, 0.0);
+    p->prof_runs = 0;
+    return DN_OK;
+}
+
+extern "C" int dn_profile_end(dn_plan* p, float* ms_per_op, int capacity) {
+    DN_REQUIRE(p && ms_per_op, "null argument");
+    p->profiling = false;
+    const int nseg = (int)p->ops.size() + 3;
+    DN_REQUIRE(capacity >= nseg, "dn_profile_end: capacity %d < %d", capacity, nseg);
+    for (int i = 0; i < nseg; ++i) ms_per_op[i] = p->prof_runs ? (float)(p->prof_ms[i] / p->prof_runs) : 0.f;
+    return p->prof_runs;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// stand-alone entry points
+// ---------------------------------------------------------------------------------------------------------
+extern "C" size_t dn_postprocess_workspace_bytes(int n, int num_anchors, int num_classes, int topk, int dets) {
+    return postprocess_ws_bytes(n, num_anchors, num_classes, topk, dets);
+}
+
+extern "C" int dn_postprocess(const float* logits, const float* reg, const float* anchors, int n, int A, int K, float image_h,
+                              float image_w, const float* scale_xy, float score_thresh, float nms_thresh, int topk, int dets,
+                              float* boxes, float* scores, int64_t* labels, int32_t* counts, int32_t* kept_anchor, void* ws,
+                              size_t ws_bytes, void* stream) {
+    DN_REQUIRE(logits && reg && anchors && boxes && scores && labels && counts && ws, "dn_postprocess: null argument");
+    DN_REQUIRE(score_thresh >= 0.f, "dn_postprocess: score_thresh must be >= 0");
+    PostArgs a;
+    a.logits = logits; a.reg = reg; a.anchors = anchors; a.n = n; a.A = A; a.K = K;
+    a.img_h = image_h; a.img_w = image_w; a.scale_xy = scale_xy;
+    a.score_thresh = score_thresh; a.nms_thresh = nms_thresh; a.topk = topk; a.dets = dets;
+    a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = kept_anchor;
+    a.ws = ws; a.ws_bytes = ws_bytes;
+    return launch_postprocess(a, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+extern "C" int dn_pointwise_conv(const void* x, const void* w, const float* bias, const void* residual, const float* se,
+                                 void* out, int m, int cin, int cout, int hw, int act, int out_fp32, int64_t out_img_stride,
+                                 void* stream) {
+    DN_REQUIRE(x && w && bias && out, "dn_pointwise_conv: null argument");
+    PwArgs a;
+    a.x = reinterpret_cast<const half_t*>(x); a.w = reinterpret_cast<const half_t*>(w); a.bias = bias;
+    a.residual = reinterpret_cast<const half_t*>(residual); a.se = se; a.out = out;
+    a.m = m; a.cin = cin; a.cout = cout; a.hw = hw; a.act = act; a.out_fp32 = out_fp32;
+    a.out_img_stride = out_fp32 ? (long)out_img_stride : 0; a.out_base = 0;
+    int rc = launch_pointwise(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    DN_HIP_CHECK(hipGetLastError());
+    return DN_OK;
+}
+
+extern "C" int dn_depthwise_conv(const void* x, const void* w, const float* bias, void* out, int n, int h, int wd, int c, int k,
+                                 int stride, int pad, int act, void* stream) {
+    DN_REQUIRE(x && w && bias && out, "dn_depthwise_conv: null argument");
+    DwArgs a;
+    a.x = reinterpret_cast<const half_t*>(x); a.w = reinterpret_cast<const half_t*>(w); a.bias = bias;
+    a.out = reinterpret_cast<half_t*>(out);
+    a.n = n; a.h = h; a.w_ = wd; a.c = c; a.k = k; a.stride = stride; a.pad = pad; a.act = act;
+    a.ho = (h + 2 * pad - k) / stride + 1;
+    a.wo = (wd + 2 * pad - k) / stride + 1;
+    int rc = launch_depthwise(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    DN_HIP_CHECK(hipGetLastError());
+    return DN_OK;
+}

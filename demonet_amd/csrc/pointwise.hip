@@ -1,0 +1,242 @@
+// Pointwise (1x1) convolution == GEMM  out[m][n] = act(sum_k x[m][k] * w[n][k] + bias[n]) (+ residual)
+//
+// reference ops replaced: every 1x1 ConvBNActivation / SE-scaled projection / SSDLite head 1x1 conv
+//   (mobilenetv3.py:76,88 ; ssd_mobilenetv3.py:35,44,52 ; BN folded into w/bias at plan time).
+//
+// CDNA4 mapping. Activations are NHWC fp16, so x rows are K-contiguous and so are the rows of the weight
+// matrix in its native [cout][cin] layout: both are directly the per-lane 8-half fragments of
+// v_mfma_f32_32x32x16_f16. The operands are SWAPPED (A := weight tile, B := pixel tile) so that the 32x32
+// accumulator has the pixel on the lane and 4 consecutive output channels in consecutive registers:
+// the epilogue then writes channel-contiguous vectors straight into NHWC rows without a transpose.
+// Tiles are staged through LDS (rows padded to 80 B: conflict-free ds_read_b128), register-staged double
+// buffering with one barrier per 32-deep K step. These GEMMs are HBM-bound (AI 13..300 FLOP/B):
+// the design goal is to read x once, write out once and keep the weight tile L2-resident.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;          // K depth per LDS stage (2 MFMA k-steps)
+constexpr int LDS_ROW = 40;     // halfs per LDS row: 32 data + 8 pad  (80 B = 5 x 16 B -> odd slot stride)
+
+// CONV = true: implicit GEMM for a dense kxk convolution (VGG path, SSDHead 3x3 heads; ssd_vgg16.py, generalized_ssd.py:77-92):
+// K runs over (ky, kx, cin) with the weight stored [cout][ky][kx][cin]; each 32-deep K stage lies inside one tap
+// (cin % 32 == 0), so the pixel tile of a stage is the NHWC rows of the tap-shifted input pixels (zeros outside).
+template <int BP, int BC, int WP, int WC, bool CONV>
+__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
+    static_assert(WP * WC == 4, "4 waves per workgroup");
+    constexpr int TP = BP / WP / 32;    // 32-pixel MFMA tiles per wave
+    constexpr int TC = BC / WC / 32;    // 32-channel MFMA tiles per wave
+    constexpr int NX = BP * 4 / 256;    // 16-B chunks of the pixel tile per thread per stage
+    constexpr int NW = BC * 4 / 256;    // 16-B chunks of the weight tile per thread per stage
+    static_assert(NX >= 1 && NW >= 0, "tile too small");
+    constexpr int NWc = NW > 0 ? NW : 1;
+    __shared__ __attribute__((aligned(16))) half_t lds[2][(BP + BC) * LDS_ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wp = wave / WC, wc = wave % WC;
+    const int r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * BP;
+    const int n0 = blockIdx.y * BC;
+    const int M = a.m, K = a.cin, NC = a.cout;
+
+    floatx16 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 sx[NX], sw[NWc];
+    int cvn[NX], cvy[NX], cvx[NX];      // CONV: image, top-left input coordinate of the output pixel of each staged row
+    if constexpr (CONV) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int m = m0 + ((tid + 256 * i) >> 2);
+            const int img = m / a.hw, rem = m - img * a.hw;
+            const int oy = rem / a.cv_wo, ox = rem - oy * a.cv_wo;
+            cvn[i] = img;
+            cvy[i] = oy * a.cv_stride - a.cv_pad;
+            cvx[i] = ox * a.cv_stride - a.cv_pad;
+        }
+    }
+
+    auto load_stage = [&](int k0) {
+        int tap_c0 = 0, dy = 0, dx = 0;
+        if constexpr (CONV) {
+            const int tap = k0 / a.cv_cin;
+            tap_c0 = k0 - tap * a.cv_cin;
+            const int ky = tap / a.cv_k;
+            dy = ky * a.cv_dil;
+            dx = (tap - ky * a.cv_k) * a.cv_dil;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 2, q = c & 3;
+            const int m = m0 + row, k = k0 + q * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if constexpr (CONV) {
+                const int iy = cvy[i] + dy, ix = cvx[i] + dx;
+                if (m < M && k < K && iy >= 0 && iy < a.cv_h && ix >= 0 && ix < a.cv_w)
+                    v = *reinterpret_cast<const uint4*>(a.x + ((size_t)(cvn[i] * a.cv_h + iy) * a.cv_w + ix) * a.cv_cin + tap_c0 + q * 8);
+            } else if (m < M && k < K) {
+                v = *reinterpret_cast<const uint4*>(a.x + (size_t)m * K + k);
+                if (a.se) {
+                    const float* sp = a.se + (size_t)(m / a.hw) * K + k;
+                    half8 hv = *reinterpret_cast<half8*>(&v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = (half_t)((float)hv[e] * sp[e]);
+                    v = *reinterpret_cast<uint4*>(&hv);
+                }
+            }
+            sx[i] = v;
+        }
+        if constexpr (NW > 0) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int c = tid + 256 * i;
+                const int row = c >> 2, q = c & 3;
+                const int n = n0 + row, k = k0 + q * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
+                sw[i] = v;
+            }
+        } else {
+            // BC*4 < 256: only the first BC*4 threads carry a weight chunk
+            const int row = tid >> 2, q = tid & 3;
+            const int n = n0 + row, k = k0 + q * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (tid < BC * 4 && n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
+            sw[0] = v;
+        }
+    };
+    auto store_stage = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int c = tid + 256 * i;
+            *reinterpret_cast<uint4*>(&lds[b][(c >> 2) * LDS_ROW + (c & 3) * 8]) = sx[i];
+        }
+        if constexpr (NW > 0) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int c = tid + 256 * i;
+                *reinterpret_cast<uint4*>(&lds[b][(BP + (c >> 2)) * LDS_ROW + (c & 3) * 8]) = sw[i];
+            }
+        } else {
+            if (tid < BC * 4) *reinterpret_cast<uint4*>(&lds[b][(BP + (tid >> 2)) * LDS_ROW + (tid & 3) * 8]) = sw[0];
+        }
+    };
+
+    const int KT = (K + BK - 1) / BK;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int b = kt & 1;
+        if (kt + 1 < KT) load_stage((kt + 1) * BK);
+        const int ksteps = (K - kt * BK > 16) ? 2 : 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < ksteps) {
+                half8 xf[TP], wf[TC];
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    xf[j] = *reinterpret_cast<const half8*>(&lds[b][((wp * TP + j) * 32 + r) * LDS_ROW + ks * 16 + hh * 8]);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+                    wf[i] = *reinterpret_cast<const half8*>(&lds[b][(BP + (wc * TC + i) * 32 + r) * LDS_ROW + ks * 16 + hh * 8]);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < KT) store_stage(b ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds pixel (lane&31) of each pixel tile; registers 4g..4g+3 = channels 8g+4h..+3 of each channel tile
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int m = m0 + (wp * TP + j) * 32 + r;
+        if (m >= M) continue;
+        size_t obase;
+        if (a.out_fp32) {
+            const int img = m / a.hw;
+            obase = (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m - img * a.hw) * NC;
+        } else {
+            obase = (size_t)m * NC;
+        }
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = n0 + (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                if (c0 >= NC) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    v[e] = acc[i][j][4 * g + e] + (c < NC ? a.bias[c] : 0.f);
+                    v[e] = dn_act(v[e], a.act);
+                }
+                if (a.out_fp32) {
+                    float* o = reinterpret_cast<float*>(a.out) + obase + c0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < NC) o[e] = v[e];
+                } else {
+                    // cout is a multiple of 8 for every fp16 layer -> the 4-channel group is entirely in range
+                    if (a.residual) {
+                        const half4 rv = *reinterpret_cast<const half4*>(a.residual + obase + c0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    }
+                    half4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
+                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.out) + obase + c0) = hv;
+                }
+            }
+        }
+    }
+}
+
+template <int BP, int BC, int WP, int WC, bool CONV>
+int launch_cfg(const PwArgs& a, hipStream_t s) {
+    dim3 grid(dn_cdiv(a.m, BP), dn_cdiv(a.cout, BC));
+    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV>), grid, dim3(256), 0, s, a);
+    return DN_OK;
+}
+
+}  // namespace
+
+int launch_pointwise(const PwArgs& a, hipStream_t s) {
+    DN_REQUIRE(a.cin % 8 == 0, "pointwise: cin=%d must be a multiple of 8", a.cin);
+    DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
+    DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
+    if (a.cout <= 32) return launch_cfg<256, 32, 4, 1, false>(a, s);
+    if (a.cout <= 64) return launch_cfg<128, 64, 4, 1, false>(a, s);
+    return launch_cfg<128, 128, 2, 2, false>(a, s);
+}
+
+int launch_conv(const ConvArgs& c, hipStream_t s) {
+    DN_REQUIRE(c.cin % 32 == 0, "conv: cin=%d must be a multiple of 32 (implicit-GEMM K stage within one tap)", c.cin);
+    DN_REQUIRE(c.out_fp32 || c.cout % 4 == 0, "conv: fp16 cout=%d must be a multiple of 4", c.cout);
+    PwArgs a;
+    a.cv_k = c.k; a.cv_stride = c.stride; a.cv_pad = c.pad; a.cv_dil = c.dil; a.cv_h = c.h; a.cv_w = c.w_;
+    a.cv_ho = c.ho; a.cv_wo = c.wo; a.cv_cin = c.cin;
+    a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out;
+    a.hw = c.ho * c.wo;
+    a.m = c.n * a.hw;
+    a.cin = c.k * c.k * c.cin;
+    a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
+    DN_REQUIRE(a.m > 0, "conv: empty problem");
+    if (a.cout <= 32) return launch_cfg<256, 32, 4, 1, true>(a, s);
+    if (a.cout <= 64) return launch_cfg<128, 64, 4, 1, true>(a, s);
+    return launch_cfg<128, 128, 2, 2, true>(a, s);
+}

@@ -1,0 +1,510 @@
+// SSD post-process on the GPU: softmax -> box decode -> clip -> per-class (score > thr, top-k) -> hard NMS
+// -> global top-D by score -> rescale to the original image size.
+//
+// reference ops replaced: SSD.postprocess_detections (generalized_ssd.py:351-397), BoxCoder.decode_single
+//   (_utils.py:187-224), torchvision clip_boxes_to_image / batched_nms (third-party; per-class, IoU > thr),
+//   GeneralizedRCNNTransform.postprocess / resize_boxes (transform.py:228-247,278-292).
+// The reference runs 90 python iterations per image (mask, topk, index) and then NMS over up to 27 000 boxes.
+// Here: three launches for the whole batch.
+//   P1 softmax_decode : 64-anchor tiles through LDS; scores written class-major ([n][K-1][A]) so that P2 streams
+//                       one contiguous column per (image, class); boxes decoded in fp32 in the reference's op order.
+//   P2 select_nms     : one 256-thread workgroup per (image, class): column in LDS, 4x8-bit radix select of the
+//                       top-k threshold, ordered compaction, bitonic sort on (score, anchor) keys, 64x64-bit IoU
+//                       mask matrix in LDS, wave-serial greedy reduce.
+//   P3 merge          : one 1024-thread workgroup per image: radix select of the D-th score over all kept
+//                       candidates, ordered compaction, sort, gather + rescale.
+// All ordering decisions are integer/compare work on the fp32 scores, with the canonical tie-break of the oracle
+// (score desc, class asc, anchor asc): bit-exact indices whenever scores/boxes agree.
+// This file is compiled with -ffp-contract=off: decode and IoU must round like the reference (no FMA fusion).
+#include "common.h"
+
+namespace {
+
+constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
+
+// ------------------------------------------------------------------------------------------------------------
+// P1
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __restrict__ logits, const float* __restrict__ reg,
+                                                            const float* __restrict__ anchors, float* __restrict__ scoresT,
+                                                            float4* __restrict__ boxes, int A, int K, float img_w, float img_h) {
+    extern __shared__ float tile[];            // [64][K] then rowsum[64]
+    float* rowsum = tile + 64 * K;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int a0 = blockIdx.x * 64;
+    const int na = min(64, A - a0);
+    const float* src = logits + ((size_t)n * A + a0) * K;
+    const int total = na * K;
+    for (int i = tid; i < total; i += 256) tile[i] = src[i];
+    __syncthreads();
+    {
+        const int row = tid >> 2, sub = tid & 3;
+        float mx = -INFINITY;
+        if (row < na)
+            for (int k = sub; k < K; k += 4) mx = fmaxf(mx, tile[row * K + k]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        float sm = 0.f;
+        if (row < na)
+            for (int k = sub; k < K; k += 4) {
+                const float e = expf(tile[row * K + k] - mx);
+                tile[row * K + k] = e;
+                sm += e;
+            }
+        sm += __shfl_xor(sm, 1);
+        sm += __shfl_xor(sm, 2);
+        if (sub == 0) rowsum[row] = sm;
+    }
+    __syncthreads();
+    const int Km1 = K - 1;
+    for (int idx = tid; idx < Km1 * 64; idx += 256) {
+        const int k = 1 + (idx >> 6), a = idx & 63;
+        if (a < na) scoresT[((size_t)n * Km1 + (k - 1)) * A + a0 + a] = tile[a * K + k] / rowsum[a];
+    }
+    if (tid < na) {
+        const int a = a0 + tid;
+        const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
+        const float4 an = reinterpret_cast<const float4*>(anchors)[a];
+        const float w = an.z - an.x, h = an.w - an.y;
+        const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
+        const float dx = rg.x / 10.f, dy = rg.y / 10.f;
+        const float dw = fminf(rg.z / 5.f, BBOX_XFORM_CLIP), dh = fminf(rg.w / 5.f, BBOX_XFORM_CLIP);
+        const float pcx = dx * w + cx, pcy = dy * h + cy;
+        const float pw = expf(dw) * w, ph = expf(dh) * h;
+        float4 b;
+        b.x = pcx - 0.5f * pw;
+        b.y = pcy - 0.5f * ph;
+        b.z = pcx + 0.5f * pw;
+        b.w = pcy + 0.5f * ph;
+        b.x = fminf(fmaxf(b.x, 0.f), img_w);
+        b.z = fminf(fmaxf(b.z, 0.f), img_w);
+        b.y = fminf(fmaxf(b.y, 0.f), img_h);
+        b.w = fminf(fmaxf(b.w, 0.f), img_h);
+        boxes[(size_t)n * A + a] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// block-level helpers shared by P2 and P3
+// ------------------------------------------------------------------------------------------------------------
+// Finds the radix digit where the count of larger keys crosses `need` (scan of 256 bins from the top by wave 0).
+// hist[] must be complete (barrier before). Results via sh[0] = digit, sh[1] = remaining need within that bin.
+__device__ __forceinline__ void radix_pick_digit(const unsigned* hist, unsigned need, unsigned* sh) {
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        // lane l owns bins 255-4l .. 252-4l (descending)
+        unsigned h0 = hist[255 - 4 * l], h1 = hist[254 - 4 * l], h2 = hist[253 - 4 * l], h3 = hist[252 - 4 * l];
+        unsigned s = h0 + h1 + h2 + h3;
+        unsigned incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned t = __shfl_up(incl, d);
+            if (l >= d) incl += t;
+        }
+        const unsigned long long ball = __ballot(incl >= need);
+        const int first = __ffsll((long long)ball) - 1;     // ball != 0 because total >= need
+        if (l == first) {
+            unsigned before = incl - s;      // count in bins above this lane's
+            unsigned digit, rem;
+            if (before + h0 >= need) { digit = 255 - 4 * l; rem = need - before; }
+            else if (before + h0 + h1 >= need) { digit = 254 - 4 * l; rem = need - before - h0; }
+            else if (before + h0 + h1 + h2 >= need) { digit = 253 - 4 * l; rem = need - before - h0 - h1; }
+            else { digit = 252 - 4 * l; rem = need - before - h0 - h1 - h2; }
+            sh[0] = digit;
+            sh[1] = rem;
+        }
+    }
+}
+
+// Descending bitonic sort of N (power of two) 64-bit keys in LDS by a workgroup of NT threads.
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long* v, int N) {
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < N; i += NT) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = v[i], b = v[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < b) : (a > b)) { v[i] = b; v[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Exclusive, thread-ordered block scan of two flags. wtot = LDS scratch [2][NT/64]. Returns totals via references.
+template <int NT>
+__device__ __forceinline__ void block_scan2(bool f0, bool f1, unsigned* wtot, unsigned& ex0, unsigned& ex1,
+                                            unsigned& tot0, unsigned& tot1) {
+    constexpr int NWV = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const unsigned p0 = __popcll(b0 & lower), p1 = __popcll(b1 & lower);
+    if (lane == 0) { wtot[wave] = __popcll(b0); wtot[NWV + wave] = __popcll(b1); }
+    __syncthreads();
+    unsigned o0 = 0, o1 = 0, t0 = 0, t1 = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+        const unsigned c0 = wtot[w], c1 = wtot[NWV + w];
+        if (w < wave) { o0 += c0; o1 += c1; }
+        t0 += c0; t1 += c1;
+    }
+    ex0 = o0 + p0; ex1 = o1 + p1; tot0 = t0; tot1 = t1;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// P2: per (image, class)
+// ------------------------------------------------------------------------------------------------------------
+template <int NW>   // 64-candidate words: candidate capacity MC = 64*NW >= topk
+__global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
+                                                        int A, int Km1, float score_thr, float nms_thr, int topk,
+                                                        float* __restrict__ keptScore, int* __restrict__ keptAnchor,
+                                                        int* __restrict__ keptCount) {
+    constexpr int MC = 64 * NW;
+    constexpr int SORTN = (NW <= 1) ? 64 : (NW <= 2) ? 128 : (NW <= 4) ? 256 : 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve (all offsets multiples of 16 B)
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem);                 // [SORTN]
+    unsigned long long* mask = cand + SORTN;                                                // [MC][NW]
+    unsigned long long* removed = mask + MC * NW;                                           // [NW] (+pad to 8)
+    float4* cbox = reinterpret_cast<float4*>(removed + 8);                                  // [MC]
+    float* carea = reinterpret_cast<float*>(cbox + MC);                                     // [MC]
+    unsigned* hist = reinterpret_cast<unsigned*>(carea + MC);                               // [256]
+    unsigned* sh = hist + 256;                                                              // [16] scalars / wave totals
+    unsigned* key = sh + 16;                                                                // [A]
+
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.x;          // 0..Km1-1  (label = cls + 1)
+    const int n = blockIdx.y;
+    const float* col = scoresT + ((size_t)n * Km1 + cls) * A;
+
+    // 1. keys + count of passing scores
+    if (tid < 16) sh[tid] = 0;
+    __syncthreads();
+    unsigned local = 0;
+    for (int a = tid; a < A; a += 256) {
+        const float s = col[a];
+        const unsigned k = (s > score_thr) ? __float_as_uint(s) : 0u;     // strict > (generalized_ssd.py:371)
+        key[a] = k;
+        local += (k != 0u);
+    }
+    {
+        unsigned w = local;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) w += __shfl_xor(w, d);
+        if ((tid & 63) == 0) atomicAdd(&sh[8], w);
+    }
+    __syncthreads();
+    const unsigned cnt = sh[8];
+    const size_t obase = ((size_t)n * Km1 + cls) * topk;
+    if (cnt == 0) {
+        if (tid == 0) keptCount[(size_t)n * Km1 + cls] = 0;
+        return;
+    }
+    // 2. threshold key T: keep all keys > T and `quota` keys == T (lowest anchors first)
+    unsigned T = 0, quota = 0;
+    if (cnt > (unsigned)topk) {
+        unsigned prefix = 0, need = topk;
+#pragma unroll
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int a = tid; a < A; a += 256) {
+                const unsigned k = key[a];
+                if (k != 0u && (shift == 24 || (k >> (shift + 8)) == (prefix >> (shift + 8)))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            radix_pick_digit(hist, need, sh);
+            __syncthreads();
+            prefix |= sh[0] << shift;
+            need = sh[1];
+            __syncthreads();
+        }
+        T = prefix;
+        quota = need;
+    }
+    const int M = (int)min(cnt, (unsigned)topk);
+    // 3. ordered compaction -> cand[] (keys > T first region, then == T in ascending anchor order)
+    {
+        unsigned base_gt = 0, base_eq = 0;
+        const unsigned g_total = (cnt > (unsigned)topk) ? (unsigned)topk - quota : cnt;
+        for (int a0 = 0; a0 < A; a0 += 256) {
+            const int a = a0 + tid;
+            const unsigned k = (a < A) ? key[a] : 0u;
+            const bool gt = (k > T);
+            const bool eq = (T != 0u) && (k == T);
+            unsigned e0, e1, t0, t1;
+            block_scan2<256>(gt, eq, sh, e0, e1, t0, t1);
+            const unsigned long long kv = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
+            if (gt) cand[base_gt + e0] = kv;
+            if (eq && base_eq + e1 < quota) cand[g_total + base_eq + e1] = kv;
+            base_gt += t0;
+            base_eq += t1;
+        }
+    }
+    for (int i = M + tid; i < SORTN; i += 256) cand[i] = 0ull;
+    __syncthreads();
+    // 4. sort by (score desc, anchor asc)
+    bitonic_sort_desc<256>(cand, SORTN);
+    // 5. gather boxes
+    for (int i = tid; i < MC; i += 256) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < M) {
+            const unsigned a = 0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFull);
+            b = boxes[(size_t)n * A + a];
+        }
+        cbox[i] = b;
+        carea[i] = (b.z - b.x) * (b.w - b.y);
+    }
+    if (tid < 8) removed[tid] = 0ull;
+    __syncthreads();
+    // 6. IoU mask: mask[i][w] bit j-64w set iff j > i and IoU(i, j) > nms_thr   (strict >, float32, inter/(a+b-inter))
+    const int nwords = (M + 63) >> 6;
+    for (int w = 0; w < nwords; ++w) {
+        const int rows = min(M, 64 * (w + 1));
+        for (int i = tid; i < rows; i += 256) {
+            const float4 bi = cbox[i];
+            const float ai = carea[i];
+            unsigned long long bits = 0ull;
+            const int jbeg = max(64 * w, i + 1), jend = min(M, 64 * (w + 1));
+            for (int j = jbeg; j < jend; ++j) {
+                const float4 bj = cbox[j];
+                const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+                const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+                const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+                const float inter = iw * ih;
+                if (inter > 0.f) {
+                    const float ovr = inter / (ai + carea[j] - inter);
+                    if (ovr > nms_thr) bits |= 1ull << (j - 64 * w);
+                }
+            }
+            mask[i * NW + w] = bits;
+        }
+    }
+    __syncthreads();
+    // 7. greedy reduce by wave 0, 64 candidates at a time; 8. compact kept candidates in order
+    if (tid < 64) {
+        const int lane = tid;
+        int kept_before = 0;
+        for (int c = 0; c < nwords; ++c) {
+            const int i = 64 * c + lane;
+            const unsigned long long rowbits = (i < M) ? mask[i * NW + c] : 0ull;
+            const unsigned lo = (unsigned)rowbits, hi = (unsigned)(rowbits >> 32);
+            unsigned long long rem = removed[c];
+            const int nvalid = min(64, M - 64 * c);
+            for (int l = 0; l < nvalid; ++l) {
+                if (!((rem >> l) & 1ull)) {
+                    const unsigned rl = __builtin_amdgcn_readlane(lo, l);
+                    const unsigned rh = __builtin_amdgcn_readlane(hi, l);
+                    rem |= ((unsigned long long)rh << 32) | rl;
+                }
+            }
+            const bool kept = (lane < nvalid) && !((rem >> lane) & 1ull);
+            // propagate suppression by the kept candidates of this chunk to the later chunks
+            if (kept) {
+                for (int w = c + 1; w < nwords; ++w) {
+                    const unsigned long long m = mask[i * NW + w];
+                    if (m) atomicOr(&removed[w], m);
+                }
+            }
+            const unsigned long long kb = __ballot(kept);
+            if (kept) {
+                const int pos = kept_before + __popcll(kb & ((1ull << lane) - 1ull));
+                const unsigned long long kv = cand[i];
+                keptScore[obase + pos] = __uint_as_float((unsigned)(kv >> 32));
+                keptAnchor[obase + pos] = (int)(0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull));
+            }
+            kept_before += __popcll(kb);
+            __threadfence_block();
+        }
+        if (lane == 0) keptCount[(size_t)n * Km1 + cls] = kept_before;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// P3: per image
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ keptScore, const int* __restrict__ keptAnchor,
+                                                    const int* __restrict__ keptCount, const float4* __restrict__ boxes,
+                                                    const float* __restrict__ scale_xy, int A, int Km1, int topk, int D,
+                                                    float* __restrict__ oboxes, float* __restrict__ oscores,
+                                                    long long* __restrict__ olabels, int* __restrict__ ocounts,
+                                                    int* __restrict__ oanchor) {
+    __shared__ unsigned long long fin[512];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh[40];
+    __shared__ int ccount[256];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
+    const int F = Km1 * topk;
+    const float* ks = keptScore + (size_t)n * F;
+    const int* ka = keptAnchor + (size_t)n * F;
+    if (tid < 40) sh[tid] = 0;
+    for (int c = tid; c < Km1; c += 1024) ccount[c] = keptCount[(size_t)n * Km1 + c];
+    __syncthreads();
+    if (tid < 64) {
+        unsigned t = 0;
+        for (int c = tid; c < Km1; c += 64) t += ccount[c];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+        if (tid == 0) sh[8] = t;
+    }
+    __syncthreads();
+    const unsigned total = sh[8];
+    unsigned T = 0, quota = 0;
+    if (total > (unsigned)D) {
+        unsigned prefix = 0, need = D;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int f = tid; f < F; f += 1024) {
+                const int c = f / topk, p = f - c * topk;
+                if (p < ccount[c]) {
+                    const unsigned k = __float_as_uint(ks[f]);
+                    if (shift == 24 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            radix_pick_digit(hist, need, sh);
+            __syncthreads();
+            prefix |= sh[0] << shift;
+            need = sh[1];
+            __syncthreads();
+        }
+        T = prefix;
+        quota = need;
+    }
+    const int M = (int)min(total, (unsigned)D);
+    {
+        unsigned base_gt = 0, base_eq = 0;
+        const unsigned g_total = (total > (unsigned)D) ? (unsigned)D - quota : total;
+        for (int f0 = 0; f0 < F; f0 += 1024) {
+            const int f = f0 + tid;
+            unsigned k = 0;
+            if (f < F) {
+                const int c = f / topk, p = f - c * topk;
+                if (p < ccount[c]) k = __float_as_uint(ks[f]);
+            }
+            const bool gt = (k > T);
+            const bool eq = (T != 0u) && (k == T);
+            unsigned e0, e1, t0, t1;
+            block_scan2<1024>(gt, eq, sh, e0, e1, t0, t1);
+            const unsigned long long kv = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)f);
+            if (gt) fin[base_gt + e0] = kv;
+            if (eq && base_eq + e1 < quota) fin[g_total + base_eq + e1] = kv;
+            base_gt += t0;
+            base_eq += t1;
+        }
+    }
+    for (int i = M + tid; i < 512; i += 1024) fin[i] = 0ull;
+    __syncthreads();
+    bitonic_sort_desc<1024>(fin, 512);
+    float sx = 1.f, sy = 1.f;
+    if (scale_xy) { sx = scale_xy[2 * n]; sy = scale_xy[2 * n + 1]; }
+    for (int i = tid; i < D; i += 1024) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = 0.f;
+        long long lab = 0;
+        int anc = -1;
+        if (i < M) {
+            const unsigned long long kv = fin[i];
+            const unsigned f = 0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull);
+            s = __uint_as_float((unsigned)(kv >> 32));
+            lab = (long long)(f / (unsigned)topk) + 1;
+            anc = ka[f];
+            b = boxes[(size_t)n * A + anc];
+            b.x *= sx; b.z *= sx; b.y *= sy; b.w *= sy;        // resize_boxes (transform.py:286-291)
+        }
+        reinterpret_cast<float4*>(oboxes)[(size_t)n * D + i] = b;
+        oscores[(size_t)n * D + i] = s;
+        olabels[(size_t)n * D + i] = lab;
+        if (oanchor) oanchor[(size_t)n * D + i] = anc;
+    }
+    if (tid == 0) ocounts[n] = M;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <int NW>
+size_t p2_lds_bytes(int A) {
+    constexpr int MC = 64 * NW;
+    constexpr int SORTN = (NW <= 1) ? 64 : (NW <= 2) ? 128 : (NW <= 4) ? 256 : 512;
+    return (size_t)SORTN * 8 + (size_t)MC * NW * 8 + 64 + (size_t)MC * 16 + (size_t)MC * 4 + 1024 + 64 + (size_t)A * 4;
+}
+
+template <int NW>
+int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, float* keptScore, int* keptAnchor, int* keptCount,
+              hipStream_t s) {
+    const size_t lds = p2_lds_bytes<NW>(a.A);
+    if (lds > 160 * 1024) {
+        dn_set_error("postprocess: %d anchors need %zu B of LDS (> 160 KiB)", a.A, lds);
+        return DN_E_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_nms_kernel<NW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((select_nms_kernel<NW>), dim3(a.K - 1, a.n), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
+                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount);
+    return DN_OK;
+}
+
+}  // namespace
+
+size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
+    (void)dets;
+    const size_t Km1 = K - 1;
+    return align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) +
+           align256((size_t)n * Km1 * 4);
+}
+
+int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
+    DN_REQUIRE(a.n > 0 && a.A > 0 && a.K >= 2, "postprocess: bad sizes n=%d A=%d K=%d", a.n, a.A, a.K);
+    DN_REQUIRE(a.topk >= 1 && a.topk <= 512, "postprocess: topk_candidates=%d outside [1,512]", a.topk);
+    DN_REQUIRE(a.dets >= 1 && a.dets <= 512, "postprocess: detections_per_img=%d outside [1,512]", a.dets);
+    DN_REQUIRE(a.K - 1 <= 256, "postprocess: more than 256 foreground classes");
+    const size_t need = postprocess_ws_bytes(a.n, a.A, a.K, a.topk, a.dets);
+    if (a.ws_bytes < need) {
+        dn_set_error("postprocess: workspace %zu B < required %zu B", a.ws_bytes, need);
+        return DN_E_WORKSPACE;
+    }
+    const size_t Km1 = a.K - 1;
+    unsigned char* p = reinterpret_cast<unsigned char*>(a.ws);
+    float* scoresT = reinterpret_cast<float*>(p);
+    p += align256((size_t)a.n * Km1 * a.A * 4);
+    float4* boxes = reinterpret_cast<float4*>(p);
+    p += align256((size_t)a.n * a.A * 16);
+    float* keptScore = reinterpret_cast<float*>(p);
+    p += align256((size_t)a.n * Km1 * a.topk * 4);
+    int* keptAnchor = reinterpret_cast<int*>(p);
+    p += align256((size_t)a.n * Km1 * a.topk * 4);
+    int* keptCount = reinterpret_cast<int*>(p);
+
+    if (ev) (void)hipEventRecord(ev[0], s);
+    const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float);
+    hipLaunchKernelGGL(softmax_decode_kernel, dim3(dn_cdiv(a.A, 64), a.n), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
+                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h);
+    if (ev) (void)hipEventRecord(ev[1], s);
+    int rc;
+    const int nw = (a.topk + 63) / 64;
+    if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
+    else if (nw <= 2) rc = launch_p2<2>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
+    else if (nw <= 4) rc = launch_p2<4>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
+    else if (nw <= 5) rc = launch_p2<5>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
+    else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
+    if (rc != DN_OK) return rc;
+    if (ev) (void)hipEventRecord(ev[2], s);
+    hipLaunchKernelGGL(merge_kernel, dim3(a.n), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, reinterpret_cast<long long*>(a.labels), a.counts,
+                       a.kept_anchor);
+    if (ev) (void)hipEventRecord(ev[3], s);
+    DN_HIP_CHECK(hipGetLastError());
+    return DN_OK;
+}

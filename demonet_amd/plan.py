@@ -1,0 +1,142 @@
+"""Lowers a spec.Graph + reference-keyed state_dict into the C-ABI model description and weight blob.
+
+BatchNorm (eval) is folded here in float64:  w' = w * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps)
+(+ conv bias carried through). Weights are stored fp16 in the layouts the kernels read directly (see
+include/demonet_hip.h, dn_op_desc); biases and SE FCs stay fp32.
+"""
+import ctypes as C
+from typing import Dict
+
+import numpy as np
+
+from . import _lib
+from .anchors import default_boxes
+from .spec import Graph
+
+
+class _Blob:
+    def __init__(self):
+        self.parts = []
+        self.size = 0
+
+    def add(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        off = self.size
+        b = arr.tobytes()
+        pad = (-len(b)) % 256
+        self.parts.append(b + b"\0" * pad)
+        self.size += len(b) + pad
+        return off
+
+    def bytes(self) -> bytes:
+        return b"".join(self.parts)
+
+
+def _np(sd, key):
+    v = sd[key]
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v, dtype=np.float64)
+
+
+def _fold(sd, node, cout):
+    """Returns (scale[cout], bias[cout]) in float64 for conv -> (+bias) -> BN."""
+    b = _np(sd, node.conv_key + ".bias") if node.has_bias else np.zeros(cout)
+    if node.bn_key:
+        g = _np(sd, node.bn_key + ".weight")
+        beta = _np(sd, node.bn_key + ".bias")
+        mu = _np(sd, node.bn_key + ".running_mean")
+        var = _np(sd, node.bn_key + ".running_var")
+        s = g / np.sqrt(var + node.bn_eps)
+        return s, (b - mu) * s + beta
+    return np.ones(cout), b
+
+
+class LoweredModel:
+    """Owns the ctypes arrays referenced by ModelDesc (they must outlive dn_create)."""
+
+    def __init__(self, graph: Graph, state_dict: Dict):
+        g = graph
+        self.graph = g
+        blob = _Blob()
+        self.tensors = (_lib.TensorDesc * len(g.tensors))()
+        for i, t in enumerate(g.tensors):
+            self.tensors[i] = _lib.TensorDesc(t.c, t.h, t.w, _lib.DN_T[t.kind])
+        ops = []
+        for nd in g.nodes:
+            o = _lib.OpDesc()
+            o.type = _lib.DN_OP[nd.op]
+            o.inp, o.out, o.residual, o.se, o.pool = nd.inp, nd.out, nd.residual, nd.se, nd.pool
+            o.cin, o.cout, o.k, o.stride, o.pad, o.dil, o.act = nd.cin, nd.cout, nd.k, nd.stride, nd.pad, nd.dil, nd.act
+            o.head, o.level, o.squeeze, o.ceil_mode, o.pool_pixels = nd.head, nd.level, nd.squeeze, int(nd.ceil_mode), 0
+            o.w_off = o.b_off = o.w2_off = o.b2_off = -1
+            if nd.op == "stem":
+                w = _np(state_dict, nd.conv_key + ".weight")              # [cout, 3, k, k]
+                s, b = _fold(state_dict, nd, nd.cout)
+                w = w * s[:, None, None, None]
+                o.w_off = blob.add(w.transpose(1, 2, 3, 0).reshape(-1, nd.cout).astype(np.float32))
+                o.b_off = blob.add(b.astype(np.float32))
+            elif nd.op == "pw":
+                w = _np(state_dict, nd.conv_key + ".weight").reshape(nd.cout, nd.cin)
+                s, b = _fold(state_dict, nd, nd.cout)
+                o.w_off = blob.add((w * s[:, None]).astype(np.float16))
+                o.b_off = blob.add(b.astype(np.float32))
+            elif nd.op == "dw":
+                w = _np(state_dict, nd.conv_key + ".weight").reshape(nd.cin, nd.k * nd.k)
+                s, b = _fold(state_dict, nd, nd.cin)
+                o.w_off = blob.add((w * s[:, None]).T.astype(np.float16))  # [k*k][c]
+                o.b_off = blob.add(b.astype(np.float32))
+            elif nd.op == "se":
+                w1 = _np(state_dict, nd.fc1_key + ".weight").reshape(nd.squeeze, nd.cin)
+                w2 = _np(state_dict, nd.fc2_key + ".weight").reshape(nd.cin, nd.squeeze)
+                o.w_off = blob.add(w1.T.astype(np.float32))                # [c][squeeze]
+                o.b_off = blob.add(_np(state_dict, nd.fc1_key + ".bias").astype(np.float32))
+                o.w2_off = blob.add(w2.T.astype(np.float32))               # [squeeze][c]
+                o.b2_off = blob.add(_np(state_dict, nd.fc2_key + ".bias").astype(np.float32))
+                o.pool_pixels = nd.stride
+                o.stride = 1
+            elif nd.op == "conv":
+                w = _np(state_dict, nd.conv_key + ".weight")               # [cout, cin, k, k]
+                s, b = _fold(state_dict, nd, nd.cout)
+                w = (w * s[:, None, None, None]).transpose(0, 2, 3, 1).reshape(nd.cout, -1)   # [cout][ky][kx][cin]
+                o.w_off = blob.add(w.astype(np.float16))
+                o.b_off = blob.add(b.astype(np.float32))
+            elif nd.op == "l2norm":
+                o.w_off = blob.add(_np(state_dict, nd.scale_key).astype(np.float32))
+            elif nd.op == "maxpool":
+                pass
+            else:
+                raise ValueError(nd.op)
+            ops.append(o)
+        self.ops = (_lib.OpDesc * len(ops))(*ops)
+        self.blob = blob.bytes()
+        grid = [(g.t(f).h, g.t(f).w) for f in g.features]
+        W, H = g.size
+        self.anchors = default_boxes(grid, (H, W), **g.anchor_spec)
+        assert self.anchors.shape[0] == g.num_anchors()
+        d = _lib.ModelDesc()
+        d.abi_version = _lib.DN_ABI_VERSION
+        d.n_tensors, d.n_ops = len(g.tensors), len(ops)
+        d.tensors, d.ops = self.tensors, self.ops
+        d.input_tensor = g.nodes[0].inp
+        d.image_h, d.image_w = H, W
+        d.mean = (C.c_float * 3)(*g.image_mean)
+        d.std = (C.c_float * 3)(*g.image_std)
+        d.num_classes = g.num_classes
+        d.n_levels = len(g.features)
+        d.level_tensor = (C.c_int32 * 8)(*(list(g.features) + [0] * (8 - len(g.features))))
+        d.anchors_per_loc = (C.c_int32 * 8)(*(list(g.anchors_per_loc) + [0] * (8 - len(g.features))))
+        d.num_anchors = self.anchors.shape[0]
+        d.anchors = self.anchors.ctypes.data_as(C.POINTER(C.c_float))
+        d.score_thresh = float(g.post["score_thresh"])
+        d.nms_thresh = float(g.post["nms_thresh"])
+        d.detections_per_img = int(g.post["detections_per_img"])
+        d.topk_candidates = int(g.post["topk_candidates"])
+        self.desc = d
+
+    def create(self) -> int:
+        L = _lib.lib()
+        handle = C.c_void_p()
+        buf = C.create_string_buffer(self.blob, len(self.blob))
+        _lib.check(L.dn_create(C.byref(self.desc), buf, len(self.blob), C.byref(handle)), "dn_create")
+        return handle.value

@@ -1,0 +1,236 @@
+"""Host-side mirror of the reference's detector module for the inference path.
+
+`SSD` keeps the reference's contract (demonet/models/generalized_ssd.py:95-349): an nn.Module built by a factory,
+`forward(images: List[Tensor[3,H,W]], targets=None) -> List[Dict[boxes, scores, labels]]` in eval mode, a
+state_dict with the reference's key names, the same exceptions for malformed input -- but its body is one call
+into the HIP library through the C ABI (include/demonet_hip.h). There is no PyTorch/CPU fallback: without the
+library or without a GPU the forward raises.
+"""
+import ctypes as C
+import warnings
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn, Tensor
+
+from . import _lib
+from .plan import LoweredModel
+from .spec import Graph
+
+
+class _Node(nn.Module):
+    """Container that only exists to reproduce the reference's dotted parameter names."""
+
+
+def _attach(root: nn.Module, key: str, value: Tensor, buffer: bool):
+    parts = key.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(parts[-1], value)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
+
+
+class SSD(nn.Module):
+    def __init__(self, graph: Graph, init: str = "normal"):
+        super().__init__()
+        self.graph = graph
+        gen = torch.Generator().manual_seed(0)
+        for p in graph.params:
+            if p.kind == "conv_w":
+                if init == "xavier":                                   # generalized_ssd.py:17-22
+                    fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                    fan_out = p.shape[0] * p.shape[2] * p.shape[3]
+                    a = (6.0 / (fan_in + fan_out)) ** 0.5
+                    v = (torch.rand(p.shape, generator=gen) * 2 - 1) * a
+                else:                                                  # ssd_mobilenetv3.py:57-62 (std 0.03)
+                    v = torch.randn(p.shape, generator=gen) * 0.03
+                _attach(self, p.key, v, False)
+            elif p.kind == "bias":
+                _attach(self, p.key, torch.zeros(p.shape), False)
+            elif p.kind in ("bn_gamma",):
+                _attach(self, p.key, torch.ones(p.shape), False)
+            elif p.kind == "bn_beta":
+                _attach(self, p.key, torch.zeros(p.shape), False)
+            elif p.kind == "bn_mean":
+                _attach(self, p.key, torch.zeros(p.shape), True)
+            elif p.kind == "bn_var":
+                _attach(self, p.key, torch.ones(p.shape), True)
+            elif p.kind == "bn_nbt":
+                _attach(self, p.key, torch.zeros((), dtype=torch.long), True)
+            elif p.kind == "scale20":
+                _attach(self, p.key, torch.ones(p.shape) * 20, False)  # ssd_vgg16.py:40
+            else:
+                raise ValueError(p.kind)
+        self.score_thresh = graph.post["score_thresh"]
+        self.nms_thresh = graph.post["nms_thresh"]
+        self.detections_per_img = graph.post["detections_per_img"]
+        self.topk_candidates = graph.post["topk_candidates"]
+        self._handle = None
+        self._sig = None
+        self._lowered = None
+        self._bufs = {}
+        self.eval()
+
+    # ------------------------------------------------------------------------------------------------------
+    def _weights_signature(self):
+        dev = None
+        ver = 0
+        for t in list(self.parameters()) + list(self.buffers()):
+            ver += t._version
+            dev = t.device
+        return (ver, str(dev), self.score_thresh, self.nms_thresh, self.detections_per_img, self.topk_candidates)
+
+    def _plan(self, device):
+        if device.type != "cuda":
+            raise RuntimeError("demonet_amd runs on an MI355X only (images must be on a cuda device); "
+                               "there is no CPU fallback path")
+        sig = (self._weights_signature(), str(device))
+        if self._handle is not None and sig == self._sig:
+            return self._handle
+        self.release()
+        self.graph.post.update(score_thresh=self.score_thresh, nms_thresh=self.nms_thresh,
+                               detections_per_img=self.detections_per_img, topk_candidates=self.topk_candidates)
+        sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in self.state_dict().items()}
+        with torch.cuda.device(device):
+            self._lowered = LoweredModel(self.graph, sd)
+            self._handle = self._lowered.create()
+        self._sig = sig
+        self._bufs = {}
+        return self._handle
+
+    def release(self):
+        if self._handle is not None:
+            _lib.lib().dn_destroy(C.c_void_p(self._handle))
+            self._handle = None
+            self._bufs = {}
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def set_graph_mode(self, enabled: bool):
+        self._graph_mode = bool(enabled)
+        if self._handle is not None:
+            _lib.check(_lib.lib().dn_set_graph_mode(C.c_void_p(self._handle), int(enabled)))
+
+    def _buffers_for(self, n, h, w, device):
+        key = (n, h, w, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            L = _lib.lib()
+            D = self.detections_per_img
+            ws = L.dn_workspace_bytes(C.c_void_p(self._handle), n)
+            b = dict(
+                images=torch.empty((n, 3, h, w), dtype=torch.float32, device=device),
+                ws=torch.empty(ws, dtype=torch.uint8, device=device),
+                boxes=torch.empty((n, D, 4), dtype=torch.float32, device=device),
+                scores=torch.empty((n, D), dtype=torch.float32, device=device),
+                labels=torch.empty((n, D), dtype=torch.int64, device=device),
+                counts=torch.empty((n,), dtype=torch.int32, device=device),
+            )
+            if len(self._bufs) >= 4:
+                self._bufs.clear()
+            self._bufs[key] = b
+            if hasattr(self, "_graph_mode"):
+                _lib.check(L.dn_set_graph_mode(C.c_void_p(self._handle), int(self._graph_mode)))
+        return b
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward_batch(self, images: Tensor, persistent_input: bool = False):
+        """images: [N,3,H,W] fp32 on the GPU. Returns padded device tensors (boxes [N,D,4], scores [N,D],
+        labels [N,D] int64, counts [N] int32) that stay valid until the next call with the same shape.
+        persistent_input=True promises that `images` keeps its address between calls (lets the hipGraph replay)."""
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError("expected a [N,3,H,W] batch, got {}".format(tuple(images.shape)))
+        if not images.is_floating_point():
+            raise TypeError(f"Expected input images to be of floating type (in range [0, 1]), but found type {images.dtype} instead")
+        handle = self._plan(images.device)
+        n, _, h, w = images.shape
+        b = self._buffers_for(n, h, w, images.device)
+        if persistent_input and images.dtype == torch.float32 and images.is_contiguous():
+            src = images
+        else:
+            b["images"].copy_(images)
+            src = b["images"]
+        stream = torch.cuda.current_stream(images.device).cuda_stream
+        with torch.cuda.device(images.device):
+            _lib.check(_lib.lib().dn_forward(C.c_void_p(handle), C.c_void_p(src.data_ptr()), n, h, w,
+                                             C.c_void_p(b["boxes"].data_ptr()), C.c_void_p(b["scores"].data_ptr()),
+                                             C.c_void_p(b["labels"].data_ptr()), C.c_void_p(b["counts"].data_ptr()),
+                                             C.c_void_p(b["ws"].data_ptr()), b["ws"].numel(), C.c_void_p(stream)), "dn_forward")
+        return b["boxes"], b["scores"], b["labels"], b["counts"]
+
+    def forward_heads(self, images: Tensor):
+        """Backbone + heads only: returns (cls_logits [N,A,K], bbox_regression [N,A,4]) fp32 device tensors (copies)."""
+        handle = self._plan(images.device)
+        n, _, h, w = images.shape
+        b = self._buffers_for(n, h, w, images.device)
+        b["images"].copy_(images)
+        L = _lib.lib()
+        stream = torch.cuda.current_stream(images.device).cuda_stream
+        with torch.cuda.device(images.device):
+            _lib.check(L.dn_forward_heads(C.c_void_p(handle), C.c_void_p(b["images"].data_ptr()), n, h, w,
+                                          C.c_void_p(b["ws"].data_ptr()), b["ws"].numel(), C.c_void_p(stream)), "dn_forward_heads")
+        pl, pr = C.c_void_p(), C.c_void_p()
+        _lib.check(L.dn_head_outputs(C.c_void_p(handle), C.c_void_p(b["ws"].data_ptr()), n, C.byref(pl), C.byref(pr)))
+        A, K = self.graph.num_anchors(), self.graph.num_classes
+        base = b["ws"].data_ptr()
+        lo = (pl.value - base)
+        ro = (pr.value - base)
+        logits = b["ws"][lo:lo + n * A * K * 4].view(torch.float32).view(n, A, K).clone()
+        reg = b["ws"][ro:ro + n * A * 16].view(torch.float32).view(n, A, 4).clone()
+        return logits, reg
+
+    def tensor(self, images_shape, tensor_id: int) -> Tensor:
+        """NHWC fp16 view (copy) of an intermediate activation of the LAST forward with this batch shape."""
+        n, _, h, w = images_shape
+        key = next(k for k in self._bufs if k[:3] == (n, h, w))
+        b = self._bufs[key]
+        p, sz = C.c_void_p(), C.c_size_t()
+        _lib.check(_lib.lib().dn_tensor_ptr(C.c_void_p(self._handle), C.c_void_p(b["ws"].data_ptr()), n, tensor_id,
+                                            C.byref(p), C.byref(sz)))
+        t = self.graph.t(tensor_id)
+        off = p.value - b["ws"].data_ptr()
+        return b["ws"][off:off + sz.value].view(torch.float16).view(n, t.h, t.w, t.c).clone()
+
+    def forward(self, images, targets: Optional[List[Dict[str, Tensor]]] = None):
+        if self.training:
+            if targets is None:
+                raise ValueError("In training mode, targets should be passed")     # generalized_ssd.py:273-274
+            raise NotImplementedError("demonet_amd implements the inference path only (SURVEY.md section 8)")
+        legacy = isinstance(images, Tensor) and images.dim() == 4                   # hub call form model(x[1,3,S,S], shapes)
+        if legacy:
+            images = list(images.unbind(0))
+        for img in images:
+            if img.dim() != 3:
+                raise ValueError("images is expected to be a list of 3d tensors "
+                                 "of shape [C, H, W], got {}".format(img.shape))    # transform.py:110-112
+            if not img.is_floating_point():
+                raise TypeError(f"Expected input images to be of floating type (in range [0, 1]), "
+                                f"but found type {img.dtype} instead")              # transform.py:130-134
+        out: List[Optional[Dict[str, Tensor]]] = [None] * len(images)
+        groups: Dict = OrderedDict()
+        for i, img in enumerate(images):
+            groups.setdefault(tuple(img.shape), []).append(i)
+        for shape, idxs in groups.items():
+            device = images[idxs[0]].device
+            self._plan(device)
+            b = self._buffers_for(len(idxs), shape[1], shape[2], device)
+            torch.stack([images[i].to(torch.float32) for i in idxs], out=b["images"])
+            boxes, scores, labels, counts = self.forward_batch(b["images"], persistent_input=True)
+            cnt = counts.tolist()                                                   # the one device->host sync
+            for j, i in enumerate(idxs):
+                c = cnt[j]
+                d = {"boxes": boxes[j, :c].clone(), "scores": scores[j, :c].clone(), "labels": labels[j, :c].clone()}
+                if legacy:
+                    d = OrderedDict((k, d[k]) for k in ("scores", "labels", "boxes"))   # box_head.py:379 order
+                out[i] = d
+        return out

@@ -1,0 +1,140 @@
+/* demonet_hip.h -- C ABI of the MI355X (gfx950) SSD inference library.
+ *
+ * The reference (zhiqwang/demonet) has no FFI/operator layer: its seam is the Python factory ->
+ * nn.Module.forward contract (demonet/models/generalized_ssd.py:271-349). This header is the native
+ * boundary a maintainer binds instead of calling `SSD.forward` (see INTEGRATION.md for the ctypes stub):
+ * plain pointers and sizes only, no torch types. All `*_dev` pointers are device (HBM) pointers owned by
+ * the caller; the library owns the plan and its weight arena. No entry point below allocates device
+ * memory or synchronises the device except dn_create / dn_destroy.
+ *
+ * Every function returns 0 on success, a negative DN_E_* code on failure; dn_last_error() gives the text.
+ */
+#ifndef DEMONET_HIP_H
+#define DEMONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_ABI_VERSION 1
+#define DN_API __attribute__((visibility("default")))
+
+enum { DN_OK = 0, DN_E_INVALID = -1, DN_E_HIP = -2, DN_E_WORKSPACE = -3, DN_E_UNSUPPORTED = -4 };
+
+/* activation fused behind a convolution (reference: mobilenetv3.py:72, ssd_mobilenetv3.py:31,41) */
+enum { DN_ACT_NONE = 0, DN_ACT_RELU = 1, DN_ACT_RELU6 = 2, DN_ACT_HSWISH = 3 };
+
+/* op kinds of the lowered graph (demonet_amd/spec.py IR) */
+enum { DN_OP_STEM = 1, DN_OP_PW = 2, DN_OP_DW = 3, DN_OP_SE = 4, DN_OP_CONV = 5, DN_OP_MAXPOOL = 6, DN_OP_L2NORM = 7 };
+
+/* tensor kinds: NHWC fp16 activation | NCHW fp32 image | per-image fp32 vector [c] | fp32 pooled sums [c] */
+enum { DN_T_ACT = 0, DN_T_IMAGE = 1, DN_T_VEC = 2, DN_T_POOL = 3 };
+
+typedef struct dn_tensor_desc {
+    int32_t c, h, w, kind;
+} dn_tensor_desc;
+
+typedef struct dn_op_desc {
+    int32_t type;                       /* DN_OP_* */
+    int32_t in, out;                    /* tensor ids */
+    int32_t residual;                   /* PW: tensor added after BN (mobilenetv3.py:97-98); -1 none */
+    int32_t se;                         /* PW: DN_T_VEC tensor scaling the input channels per image; -1 none */
+    int32_t pool;                       /* DW: DN_T_POOL tensor receiving per-(image,channel) sums; -1 none */
+    int32_t cin, cout, k, stride, pad, dil, act;
+    int32_t head;                       /* 0 none, 1 class logits, 2 box regression: write fp32 into the head arrays */
+    int32_t level;                      /* pyramid level of a head op */
+    int32_t squeeze;                    /* SE: squeeze width; pooled pixel count is taken from the producer */
+    int32_t ceil_mode;                  /* MAXPOOL */
+    int32_t pool_pixels;                /* SE: H*W of the pooled map (mean divisor) */
+    int32_t reserved[2];
+    int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob; -1 none.
+                                               PW/CONV: w = fp16 [cout][k*k*cin] (tap-major, channel-minor), b = fp32 [cout]
+                                               DW/STEM: w = fp16 [k*k][c] / fp32 [k*k*3][cout], b = fp32 [c]
+                                               SE: w = fp32 fc1 [squeeze][c], b = fc1 bias, w2 = fc2 [c][squeeze], b2 = fc2 bias
+                                               L2NORM: w = fp32 scale [c] */
+} dn_op_desc;
+
+typedef struct dn_model_desc {
+    int32_t abi_version;                /* DN_ABI_VERSION */
+    int32_t n_tensors, n_ops;
+    const dn_tensor_desc* tensors;
+    const dn_op_desc* ops;
+    int32_t input_tensor;
+    int32_t image_h, image_w;           /* fixed network input size (generalized_ssd.py:190-191) */
+    float mean[3], std[3];              /* transform.py:129-138 */
+    int32_t num_classes;                /* including background class 0 */
+    int32_t n_levels;
+    int32_t level_tensor[8];            /* feature-map tensor id per pyramid level */
+    int32_t anchors_per_loc[8];
+    int32_t num_anchors;
+    const float* anchors;               /* host, [num_anchors][4] xyxy pixels (anchor_utils.py:111-126) */
+    float score_thresh, nms_thresh;     /* generalized_ssd.py:158-162 */
+    int32_t detections_per_img, topk_candidates;
+} dn_model_desc;
+
+typedef struct dn_plan dn_plan;
+
+/* Build a plan: validates the graph, uploads `weights` (host blob addressed by the op offsets) and anchors. */
+DN_API int dn_create(const dn_model_desc* desc, const void* weights, size_t weight_bytes, dn_plan** out);
+DN_API void dn_destroy(dn_plan* plan);
+
+/* Bytes of caller-provided device scratch needed for a batch of n images. */
+DN_API size_t dn_workspace_bytes(const dn_plan* plan, int n);
+
+/* The whole hot path, replacing SSD.forward (eval):  images_dev = [n][3][h][w] fp32 in [0,1], NCHW, contiguous
+ * (the stacked form of the reference's List[Tensor[3,H,W]]); (h, w) may differ from the network size, in which
+ * case the bilinear resize of transform.py:27-53 runs first and boxes are mapped back (transform.py:278-292).
+ * Outputs (device): boxes [n][D][4] fp32 xyxy, scores [n][D] fp32, labels [n][D] int64, counts [n] int32, with
+ * D = detections_per_img; rows >= counts[i] are zero. Asynchronous on `stream` (a hipStream_t). */
+DN_API int dn_forward(dn_plan* plan, const float* images_dev, int n, int h, int w,
+               float* boxes_dev, float* scores_dev, int64_t* labels_dev, int32_t* counts_dev,
+               void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Backbone + heads only (no post-process). The head outputs live inside the workspace; query them with
+ * dn_head_outputs:  cls_logits [n][A][K] fp32, bbox_regression [n][A][4] fp32 (generalized_ssd.py:60-74). */
+DN_API int dn_forward_heads(dn_plan* plan, const float* images_dev, int n, int h, int w,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
+DN_API int dn_head_outputs(const dn_plan* plan, void* workspace_dev, int n, float** cls_logits_dev, float** bbox_regression_dev);
+/* Device address/size of an intermediate tensor inside the workspace (parity tests on feature maps). */
+DN_API int dn_tensor_ptr(const dn_plan* plan, void* workspace_dev, int n, int tensor_id, void** ptr, size_t* bytes);
+
+/* Post-process only, replacing SSD.postprocess_detections (generalized_ssd.py:351-397) + transform.postprocess:
+ * softmax -> decode (BoxCoder weights 10,10,5,5) -> clip -> per-class score>thr & top-k -> hard NMS (IoU > thr)
+ * -> global top-D by score.  kept_anchor_dev (optional, may be NULL): [n][D] int32 anchor index per detection. */
+DN_API size_t dn_postprocess_workspace_bytes(int n, int num_anchors, int num_classes, int topk_candidates, int detections_per_img);
+DN_API int dn_postprocess(const float* cls_logits_dev, const float* bbox_regression_dev, const float* anchors_dev,
+                   int n, int num_anchors, int num_classes,
+                   float image_h, float image_w, const float* scale_xy_dev /* [n][2] (w,h) ratios or NULL */,
+                   float score_thresh, float nms_thresh, int topk_candidates, int detections_per_img,
+                   float* boxes_dev, float* scores_dev, int64_t* labels_dev, int32_t* counts_dev,
+                   int32_t* kept_anchor_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Single-kernel entry points (unit parity tests, micro-benchmarks, roofline measurement).
+ * x: [m][cin] fp16 (NHWC rows), w: [cout][cin] fp16, bias fp32 [cout], residual [m][cout] fp16 or NULL,
+ * se_scale fp32 [m/hw][cin] or NULL, out fp16 [m][cout] (out_fp32 != 0: fp32, addressed
+ * (row/hw)*out_img_stride + (row%hw)*cout + c). */
+DN_API int dn_pointwise_conv(const void* x_dev, const void* w_dev, const float* bias_dev, const void* residual_dev,
+                      const float* se_scale_dev, void* out_dev, int m, int cin, int cout, int hw, int act,
+                      int out_fp32, int64_t out_img_stride, void* stream);
+/* x: [n][h][w][c] fp16, w: [k*k][c] fp16, bias fp32 [c], out [n][ho][wo][c] fp16 */
+DN_API int dn_depthwise_conv(const void* x_dev, const void* w_dev, const float* bias_dev, void* out_dev,
+                      int n, int h, int w, int c, int k, int stride, int pad, int act, void* stream);
+
+/* 1 = replay the launch sequence from a cached hipGraph keyed by (n, pointers) [default], 0 = eager launches */
+DN_API int dn_set_graph_mode(dn_plan* plan, int enabled);
+
+/* Timing hook for bench.py: average device time in ms of the op at `op_index` over the forwards recorded since
+ * dn_profile_begin (HIP events on the forward stream, eager mode). */
+DN_API int dn_profile_begin(dn_plan* plan);
+DN_API int dn_profile_end(dn_plan* plan, float* ms_per_op /* [n_ops + 3] : ops..., softmax/decode, select/NMS, merge */, int capacity);
+
+DN_API const char* dn_last_error(void);
+DN_API int dn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMONET_HIP_H */

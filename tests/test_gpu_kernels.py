@@ -1,0 +1,124 @@
+"""GPU parity tests (-m gpu) for the individual HIP kernels, called through the C ABI (ctypes), against fp32 CPU math."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from demonet_amd import _lib as L
+    return L, L.lib()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _act(x, act):
+    return [lambda v: v, F.relu, F.relu6, F.hardswish][act](x)
+
+
+PW_CASES = [
+    # m, cin, cout, hw, act, residual, se, fp32
+    (1000, 16, 16, 100, 0, True, False, False),
+    (4096, 16, 64, 4096, 1, False, False, False),
+    (777, 72, 24, 777, 0, False, False, False),
+    (800, 72, 40, 400, 0, False, True, False),      # SE-scaled projection (two images)
+    (513, 120, 40, 171, 0, True, True, False),
+    (640, 40, 240, 320, 3, False, False, False),
+    (400, 184, 80, 400, 0, True, False, False),
+    (300, 112, 672, 100, 3, False, False, False),
+    (200, 672, 112, 100, 0, True, True, False),
+    (800, 672, 546, 400, 0, False, False, True),    # level-0 class head, fp32 out into [img][anchor][K]
+    (50, 128, 24, 25, 0, False, False, True),
+    (9, 256, 128, 9, 2, False, False, False),
+    (1, 64, 128, 1, 2, False, False, False),
+]
+
+
+@pytest.mark.parametrize("m,cin,cout,hw,act,res,se,fp32", PW_CASES)
+def test_pointwise_conv(m, cin, cout, hw, act, res, se, fp32):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(m * 31 + cin)
+    x = torch.randn(m, cin, generator=g).half()
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).half()
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(m, cout, generator=g).half() if res else None
+    nimg = m // hw
+    s = torch.rand(nimg, cin, generator=g) if se else None
+    xs = x.float()
+    if se:
+        xs = (xs.view(nimg, hw, cin) * s[:, None, :]).half().float().view(m, cin)   # kernel rounds the scaled input to fp16
+    ref = xs @ w.float().t() + b
+    ref = _act(ref, act)
+    if res:
+        ref = ref + r.float()
+    dev = "cuda"
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    rd = r.to(dev) if res else None
+    sd = s.to(dev) if se else None
+    if fp32:
+        extra = 7 * cout                        # emulate writing one level into a larger per-image anchor array
+        stride = hw * cout + extra
+        out = torch.full((nimg * stride,), -777.0, device=dev)
+    else:
+        stride = 0
+        out = torch.zeros(m, cout, dtype=torch.half, device=dev)
+    rc = lib.dn_pointwise_conv(_ptr(xd), _ptr(wd), _ptr(bd), _ptr(rd), _ptr(sd), _ptr(out), m, cin, cout, hw, act,
+                               int(fp32), stride, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.check(rc, "dn_pointwise_conv")
+    torch.cuda.synchronize()
+    if fp32:
+        o = out.cpu().view(nimg, stride)
+        got = o[:, :hw * cout].reshape(m, cout)
+        assert (o[:, hw * cout:] == -777.0).all()        # nothing written outside the level's slice
+        torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
+    else:
+        torch.testing.assert_close(out.cpu().float(), ref.half().float(), rtol=4e-3, atol=4e-3)
+
+
+DW_CASES = [
+    # n, h, w, c, k, s, act
+    (2, 20, 20, 16, 3, 1, 1),
+    (2, 21, 19, 64, 3, 2, 1),
+    (1, 40, 40, 72, 5, 2, 1),
+    (3, 10, 10, 120, 5, 1, 1),
+    (2, 5, 5, 256, 3, 2, 2),
+    (2, 3, 3, 128, 3, 2, 2),
+    (2, 2, 2, 128, 3, 2, 2),
+    (4, 1, 1, 128, 3, 1, 2),
+    (1, 20, 20, 672, 3, 1, 3),
+    (1, 20, 20, 672, 5, 2, 3),
+]
+
+
+@pytest.mark.parametrize("n,h,w,c,k,s,act", DW_CASES)
+def test_depthwise_conv(n, h, w, c, k, s, act):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(h * 131 + c + k)
+    x = torch.randn(n, c, h, w, generator=g).half()
+    wt = (torch.randn(c, 1, k, k, generator=g) / k).half()
+    b = torch.randn(c, generator=g)
+    pad = (k - 1) // 2
+    ref = _act(F.conv2d(x.float(), wt.float(), b, s, pad, 1, c), act)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = wt.view(c, k * k).t().contiguous().cuda()
+    ho, wo = ref.shape[-2:]
+    out = torch.zeros(n, ho, wo, c, dtype=torch.half, device="cuda")
+    rc = lib.dn_depthwise_conv(_ptr(xd), _ptr(wd), _ptr(b.cuda()), _ptr(out), n, h, w, c, k, s, pad, act,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.check(rc, "dn_depthwise_conv")
+    torch.cuda.synchronize()
+    got = out.cpu().float().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref.half().float(), rtol=4e-3, atol=4e-3)
+
+
+def test_bad_arguments_report_errors():
+    L, lib = _lib()
+    x = torch.zeros(8, 12, dtype=torch.half, device="cuda")
+    rc = lib.dn_pointwise_conv(_ptr(x), _ptr(x), _ptr(x), None, None, _ptr(x), 8, 12, 8, 8, 0, 0, 0, None)
+    assert rc < 0 and b"multiple of 8" in lib.dn_last_error()

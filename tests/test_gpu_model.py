@@ -1,0 +1,228 @@
+"""GPU parity tests (-m gpu): the whole HIP path against the oracle and the golden vectors of the real reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ssd_oracle as so
+from demonet_amd import models, synth
+
+pytestmark = pytest.mark.gpu
+
+# fp16 storage / fp32 accumulate vs the fp32 CPU path: tolerance on the class logits and box regression.
+# north_star: "within 1e-3 on logits" holds for reference-initialised heads (|logit| < 0.3); the synthetic heads used
+# here have |logit| up to ~14, so the bound is stated as atol + rtol*|x| (SURVEY section 7 "fp16 vs 1e-3 on logits").
+LOGIT_ATOL, LOGIT_RTOL = 2e-2, 2e-2
+
+
+def _golden(golden_dir, name):
+    p = os.path.join(golden_dir, name + ".npz")
+    if not os.path.exists(p):
+        pytest.skip("no golden for " + name)
+    return np.load(p)
+
+
+def _model(name, z=None, **kw):
+    ncls = int(z["num_classes"]) if z is not None else kw.pop("num_classes", 91)
+    m = getattr(models, name)(num_classes=ncls, **kw)
+    models.load_synthetic(m, int(z["weight_seed"]) if z is not None else 0)
+    return m.cuda()
+
+
+def _images(g, seeds):
+    W, H = g.size
+    return [torch.from_numpy(synth.images(int(s), 1, H, W)[0]).cuda() for s in seeds]
+
+
+def _postprocess(lib_mod, logits, reg, anchors, hw, st, nt, topk, dets):
+    L = lib_mod.lib()
+    n, A, K = logits.shape
+    ws = torch.empty(L.dn_postprocess_workspace_bytes(n, A, K, topk, dets), dtype=torch.uint8, device="cuda")
+    boxes = torch.empty(n, dets, 4, device="cuda")
+    scores = torch.empty(n, dets, device="cuda")
+    labels = torch.empty(n, dets, dtype=torch.int64, device="cuda")
+    counts = torch.empty(n, dtype=torch.int32, device="cuda")
+    kept = torch.empty(n, dets, dtype=torch.int32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = L.dn_postprocess(p(logits), p(reg), p(anchors), n, A, K, float(hw[0]), float(hw[1]), None, float(st), float(nt),
+                          int(topk), int(dets), p(boxes), p(scores), p(labels), p(counts), p(kept), p(ws), ws.numel(),
+                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    lib_mod.check(rc, "dn_postprocess")
+    torch.cuda.synchronize()
+    return boxes.cpu().numpy(), scores.cpu().numpy(), labels.cpu().numpy(), counts.cpu().numpy(), kept.cpu().numpy()
+
+
+def test_postprocess_on_golden_logits_is_index_exact(golden_dir):
+    """Isolation test: the reference's own logits/regression in -> kept-box indices bit-exact (fixture is tie-free)."""
+    from demonet_amd import _lib
+    z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
+    st, nt, dets, topk = z["post"]
+    logits = torch.from_numpy(z["cls_logits_full_0"])[None].cuda()
+    reg = torch.from_numpy(z["bbox_regression"][0:1]).cuda()
+    anchors = torch.from_numpy(z["anchors"]).cuda()
+    b, s, l, c, k = _postprocess(_lib, logits, reg, anchors, (320, 320), st, nt, int(topk), int(dets))
+    n = int(c[0])
+    assert n == z["det_labels_0"].shape[0]
+    assert np.array_equal(l[0, :n], z["det_labels_0"])
+    assert np.array_equal(k[0, :n], z["det_anchor_idx_0"])
+    np.testing.assert_allclose(s[0, :n], z["det_scores_0"], rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(b[0, :n], z["det_boxes_0"], rtol=1e-5, atol=2e-3)
+    assert (b[0, n:] == 0).all() and (s[0, n:] == 0).all()
+
+
+@pytest.mark.parametrize("n,A,K,topk,dets,st", [
+    (3, 500, 7, 40, 30, 0.05),        # ragged: few candidates per class, counts < dets possible
+    (2, 3234, 21, 400, 100, 0.02),    # V2-like shape, topk > 320
+    (1, 70, 3, 300, 300, 0.0),        # fewer anchors than topk
+    (2, 200, 5, 64, 512, 0.01),       # dets at the cap
+    (1, 128, 4, 100, 50, 0.9999),     # nothing passes the threshold -> empty output
+])
+def test_postprocess_random_vs_oracle(n, A, K, topk, dets, st):
+    """Same scores/boxes semantics as the oracle on random inputs, including exact score ties (duplicated rows):
+    the canonical tie-break (score desc, class asc, anchor asc) must make the index lists identical."""
+    from demonet_amd import _lib
+    rng = np.random.default_rng(A * 7 + K)
+    logits = rng.normal(0, 2.0, (n, A, K)).astype(np.float32)
+    reg = rng.normal(0, 1.0, (n, A, 4)).astype(np.float32)
+    ctr = rng.uniform(20, 300, (A, 2)).astype(np.float32)
+    wh = rng.uniform(10, 120, (A, 2)).astype(np.float32)
+    anchors = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    # exact duplicates -> exact score ties AND identical boxes when anchors are duplicated too
+    dup = rng.integers(0, A, A // 5)
+    src = rng.integers(0, A, A // 5)
+    logits[:, dup] = logits[:, src]
+    reg[:, dup] = reg[:, src]
+    anchors[dup[: len(dup) // 2]] = anchors[src[: len(dup) // 2]]
+    nt = 0.5
+    dets_o = so.postprocess_detections(torch.from_numpy(logits), torch.from_numpy(reg), torch.from_numpy(anchors), (320, 320),
+                                       st, nt, dets, topk, return_intermediates=True)
+    b, s, l, c, k = _postprocess(_lib, torch.from_numpy(logits).cuda(), torch.from_numpy(reg).cuda(),
+                                 torch.from_numpy(anchors).cuda(), (320, 320), st, nt, topk, dets)
+    for i, d in enumerate(dets_o):
+        m = so.selection_margins(d["softmax"], d["decoded"], st, nt, topk, dets)
+        cnt = int(c[i])
+        assert cnt == d["labels"].shape[0]
+        risky = min(m["thresh_gap"], m["iou_gap"]) < 1e-5 or (0 < m["topk_gap"] < 1e-5) or (0 < m["final_gap"] < 1e-5) \
+            or (0 < m["order_gap"] < 1e-5)
+        if not risky:        # exact ties (gap == 0) are fine: canonical order; near-ties could flip with 1-ulp softmax noise
+            assert np.array_equal(l[i, :cnt], d["labels"])
+            assert np.array_equal(k[i, :cnt], d["anchor_idx"])
+        np.testing.assert_allclose(np.sort(s[i, :cnt])[::-1], np.sort(d["scores"])[::-1], rtol=1e-5, atol=1e-7)
+
+
+def test_model_heads_match_golden(golden_dir):
+    z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
+    m = _model("ssdlite320_mobilenet_v3_large", z)
+    imgs = torch.stack(_images(m.graph, z["image_seeds"]))
+    logits, reg = m.forward_heads(imgs)
+    logits, reg = logits.cpu().numpy(), reg.cpu().numpy()
+    ref = z["cls_logits_full_0"]
+    err = np.abs(logits[0] - ref)
+    print("logits max|err| %.4g  mean|err| %.4g  max|ref| %.3g" % (err.max(), err.mean(), np.abs(ref).max()))
+    np.testing.assert_allclose(logits[0], ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(logits[1][::7], z["cls_logits_rows_1"], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    np.testing.assert_allclose(reg, z["bbox_regression"], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    # feature pyramid (NHWC fp16 on the device) against the reference's NCHW fp32 samples
+    for lvl, tid in enumerate(m.graph.features):
+        f = m.tensor(imgs.shape, tid).float().cpu().permute(0, 3, 1, 2).numpy()
+        assert tuple(f.shape) == tuple(z[f"feat{lvl}_shape"])
+        samp = f.reshape(f.shape[0], -1)[:, ::max(1, f[0].size // 4096)]
+        np.testing.assert_allclose(samp, z[f"feat{lvl}_sample"], rtol=2e-2, atol=2e-2)
+
+
+def test_model_heads_small_logits_within_1e3():
+    """north_star tolerance: with reference-scale head weights (logits O(0.3)) the fp16 path is within 1e-3 of the
+    fp32 CPU path on the logits."""
+    name = "ssdlite320_mobilenet_v3_large"
+    m = getattr(models, name)(num_classes=91)
+    g = m.graph
+    sd = synth.state_dict(g, 0)
+    for k in sd:
+        if k.startswith("head.") and k.endswith(".1.weight"):
+            sd[k] = sd[k] * np.float32(0.05)
+        if k.startswith("head.") and k.endswith(".1.bias"):
+            sd[k] = sd[k] * np.float32(0.05)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.cuda()
+    imgs = _images(g, [77])
+    o = so.OracleSSD(name, sd, 91)
+    raw = o.forward_raw([i.cpu() for i in imgs])
+    logits, reg = m.forward_heads(torch.stack(imgs))
+    err = (logits.cpu() - raw["cls_logits"]).abs().max().item()
+    print("small-logit config: max|logit| %.3f max|err| %.2e" % (raw["cls_logits"].abs().max(), err))
+    assert err < 1e-3
+
+
+def test_end_to_end_detections_vs_golden(golden_dir):
+    """fp16 network + GPU post-process vs the reference's detections. fp16 noise (1e-3 relative) reorders near-equal
+    scores, so this is a set comparison: most (label, anchor) pairs must coincide, and the boxes of
+    the coinciding ones must agree."""
+    z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
+    m = _model("ssdlite320_mobilenet_v3_large", z)
+    imgs = _images(m.graph, z["image_seeds"])
+    out = m(imgs)
+    assert len(out) == 2 and set(out[0].keys()) == {"boxes", "scores", "labels"}
+    for i, d in enumerate(out):
+        assert d["labels"].dtype == torch.int64 and d["boxes"].dtype == torch.float32
+        n = d["labels"].shape[0]
+        assert n == z[f"det_labels_{i}"].shape[0]
+        s = d["scores"].cpu().numpy()
+        assert (np.diff(s) <= 0).all()
+        # match by box: every reference detection should have a same-label detection with IoU > 0.9
+        rb, rl = z[f"det_boxes_{i}"], z[f"det_labels_{i}"]
+        gb, gl = d["boxes"].cpu().numpy(), d["labels"].cpu().numpy()
+        iou = so.box_iou_np(rb, gb)
+        same = rl[:, None] == gl[None, :]
+        hit = ((iou > 0.9) & same).any(1)
+        print(f"image {i}: {hit.mean() * 100:.1f}% of reference detections reproduced")
+        assert hit.mean() > 0.85
+        np.testing.assert_allclose(np.sort(s)[::-1][:50], z[f"det_scores_{i}"][:50], rtol=3e-2, atol=1e-3)
+
+
+def test_list_api_batching_and_resize():
+    """Different-size images (the reference docstring's use-case, ssd_mobilenetv3.py:172): resize + box back-mapping."""
+    name = "ssdlite320_mobilenet_v3_large"
+    m = _model(name, num_classes=91)
+    g = m.graph
+    sd = synth.state_dict(g, 0)
+    a = torch.from_numpy(synth.images(5, 1, 320, 320)[0])
+    b = torch.from_numpy(synth.uniform(6, "img_b", 3 * 200 * 260).reshape(3, 200, 260))
+    out = m([a.cuda(), b.cuda(), a.cuda()])
+    assert len(out) == 3
+    assert torch.equal(out[0]["boxes"], out[2]["boxes"]) and torch.equal(out[0]["labels"], out[2]["labels"])
+    o = so.OracleSSD(name, sd, 91)
+    od = o([a, b])
+    bb = out[1]["boxes"].cpu().numpy()
+    assert bb[:, 0::2].max() <= 260 + 1e-3 and bb[:, 1::2].max() <= 200 + 1e-3      # mapped back to the original size
+    iou = so.box_iou_np(od[1]["boxes"], bb)
+    same = od[1]["labels"][:, None] == out[1]["labels"].cpu().numpy()[None, :]
+    assert ((iou > 0.9) & same).any(1).mean() > 0.8
+
+
+def test_graph_replay_equals_eager():
+    m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+    imgs = torch.from_numpy(synth.images(9, 4, 320, 320)).cuda()
+    m.set_graph_mode(False)
+    e = [t.clone() for t in m.forward_batch(imgs, persistent_input=True)]
+    m.set_graph_mode(True)
+    for _ in range(3):          # first call captures, later calls replay
+        r = [t.clone() for t in m.forward_batch(imgs, persistent_input=True)]
+    torch.cuda.synchronize()
+    for a, b in zip(e, r):
+        assert torch.equal(a, b)
+
+
+def test_error_behaviour_matches_reference():
+    m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+    with pytest.raises(ValueError):
+        m([torch.zeros(1, 3, 8, 8, device="cuda")[0:1]])                 # 4-d element: transform.py:110-112
+    with pytest.raises(TypeError):
+        m([torch.zeros(3, 8, 8, dtype=torch.uint8, device="cuda")])      # transform.py:130-134
+    m.train()
+    with pytest.raises(ValueError):
+        m([torch.zeros(3, 8, 8, device="cuda")])                         # generalized_ssd.py:273-274
+    m.eval()
+    with pytest.raises(RuntimeError):
+        m([torch.zeros(3, 320, 320)])                                    # CPU tensors: no fallback path
