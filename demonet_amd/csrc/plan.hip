@@ -51,6 +51,7 @@ struct dn_plan {
     std::map<int, Layout> layouts;
     bool graph_mode = true;
     std::map<GraphKey, hipGraphExec_t> graphs;
+    hipStream_t capture_stream = nullptr;   // capture never happens on the caller's stream (may be the null stream)
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -147,6 +148,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
 extern "C" void dn_destroy(dn_plan* p) {
     if (!p) return;
     for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     for (auto ev : p->events) (void)hipEventDestroy(ev);
     if (p->weights_dev) (void)hipFree(p->weights_dev);
     if (p->anchors_dev) (void)hipFree(p->anchors_dev);
@@ -347,9 +349,11 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
         int rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
         if (rc) return rc;
         hipGraph_t g = nullptr;
-        DN_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
-        hipError_t e = hipStreamEndCapture(s, &g);
+        if (!p->capture_stream) DN_HIP_CHECK(hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking));
+        hipStream_t cs = p->capture_stream;
+        DN_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, cs, false);
+        hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) { dn_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DN_E_HIP; }
         hipGraphExec_t ge = nullptr;
