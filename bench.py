@@ -80,7 +80,7 @@ def cpu_baseline(name, graph, seed, budget_s=20.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ssd_oracle as so
     from demonet_amd import synth
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)          # more threads than this only adds oversubscription on these small convs
     torch.set_num_threads(cores)
     o = so.OracleSSD(name, synth.state_dict(graph, 0), graph.num_classes, size=graph.size)
     W, H = graph.size
@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--per-op", default="", help="write a per-op table (time, GB/s, TFLOP/s) to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +195,13 @@ def main():
             a["bytes"] += c["bytes"]
             a["flops"] += c["flops"]
             a["launches"] += 1
+        if args.per_op:
+            with open(args.per_op, "w") as f:
+                names = [f"{nd.op}:{nd.conv_key or nd.fc1_key or nd.scale_key}" for nd in g.nodes] + ["softmax_decode", "select_nms", "merge"]
+                for i, (c, ms, nm) in enumerate(zip(costs, buf, names)):
+                    nd = g.nodes[i] if i < len(g.nodes) else None
+                    shp = f"{g.t(nd.inp).c}x{g.t(nd.inp).h}x{g.t(nd.inp).w}->{g.t(nd.out).c}x{g.t(nd.out).h}x{g.t(nd.out).w} k{nd.k}s{nd.stride}" if nd else ""
+                    f.write(f"{i:3d} {nm:58s} {shp:34s} {ms * 1e3:8.1f} us {c['bytes'] / 1e6:8.1f} MB {c['bytes'] / max(ms, 1e-9) / 1e6:8.0f} GB/s {c['flops'] / max(ms, 1e-9) / 1e9:7.1f} TF/s  {c['kernel']}\n")
         total_ms = sum(a["ms"] for a in agg.values())
         dom = max(agg, key=lambda k: agg[k]["ms"])
         d = agg[dom]

@@ -60,8 +60,10 @@ int launch_pointwise(const PwArgs& a, hipStream_t s);
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;
     int n, h, w_, c, k, stride, pad, act, ho, wo;
+    float* pool = nullptr;      // optional: [n][blocks][c] fp32 per-workgroup sums of the outputs (SE squeeze)
 };
 int launch_depthwise(const DwArgs& a, hipStream_t s);
+int depthwise_pool_blocks(const DwArgs& a);       // workgroups per image == partial-sum rows per image
 
 struct StemArgs {
     const float* img;       // [n][3][h][w] fp32 (raw, 0..1)
@@ -69,12 +71,11 @@ struct StemArgs {
     const float* bias;      // [cout]
     half_t* out;            // [n][ho][wo][cout]
     int n, h, w_, cout, k, stride, pad, act, ho, wo;
-    float mean[3], inv_std_unused[3], std[3];
+    float mean[3], inv_std[3];
 };
 int launch_stem(const StemArgs& a, hipStream_t s);
 
-int launch_se_pool(const half_t* x, float* sums, int n, int hw, int c, hipStream_t s);
-int launch_se_fc(const float* sums, const float* w1t, const float* b1, const float* w2t, const float* b2,
+int launch_se_fc(const float* partial, int nblk, const float* w1, const float* b1, const float* w2, const float* b2,
                  float* scale, int n, int c, int squeeze, int pool_pixels, hipStream_t s);
 
 struct ConvArgs {

@@ -13,18 +13,21 @@ namespace {
 template <int K, int S, int TW>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
     constexpr int NIN = (TW - 1) * S + K;
+    extern __shared__ float red[];            // [256][8], only when pooling
     const int C8 = a.c >> 3;
     const int XS = (a.wo + TW - 1) / TW;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int cg = (int)(idx % C8);
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    const int cg = idx % C8;
     idx /= C8;
-    const int xs = (int)(idx % XS);
-    idx /= XS;
-    const int oy = (int)(idx % a.ho);
-    const int n = (int)(idx / a.ho);
-    if (n >= a.n) return;
+    const int xs = idx % XS;
+    const int oy = idx / XS;
+    const bool valid = oy < a.ho;
+    if (!valid && !a.pool) return;
     const int ox0 = xs * TW;
     const int c0 = cg * 8;
+    float psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
 
     float acc[TW][8];
     {
@@ -66,105 +69,164 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
         if (ox0 + t >= a.wo) break;
         half8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)dn_act(acc[t][e], a.act);
+        for (int e = 0; e < 8; ++e) {
+            const float v = dn_act(acc[t][e], a.act);
+            psum[e] += v;
+            o[e] = (half_t)v;
+        }
         *reinterpret_cast<half8*>(orow + (size_t)(ox0 + t) * a.c) = o;
+    }
+    }   // valid
+    if (a.pool) {
+        // SE squeeze (mobilenetv3.py:32 adaptive_avg_pool2d) fused as deterministic per-workgroup partial sums:
+        // threads with equal channel group sit C8 apart; thread t < C8 adds them in a fixed order.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = psum[e];
+        __syncthreads();
+        if ((int)threadIdx.x < C8) {
+            const int cgp = (blockIdx.x * 256 + threadIdx.x) % C8;
+            float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int u = threadIdx.x; u < 256; u += C8)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t8[e] += red[u * 8 + e];
+            float* dst = a.pool + ((size_t)n * gridDim.x + blockIdx.x) * a.c + cgp * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = t8[e];
+        }
     }
 }
 
 template <int K, int S, int TW>
 int launch_dw(const DwArgs& a, hipStream_t s) {
-    const long threads = (long)a.n * a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8);
-    hipLaunchKernelGGL((dw_kernel<K, S, TW>), dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, a);
+    const long threads = (long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8);       // per image
+    hipLaunchKernelGGL((dw_kernel<K, S, TW>), dim3(dn_cdiv(threads, 256), a.n), dim3(256), a.pool ? 256 * 8 * 4 : 0, s, a);
     return DN_OK;
 }
 
-// ---- SE: per-(image, channel) sums over the spatial map; deterministic tree order -----------------------
-__global__ __launch_bounds__(256) void se_pool_kernel(const half_t* __restrict__ x, float* __restrict__ sums, int hw, int c) {
-    __shared__ float red[16][16][8];
-    const int C8 = c >> 3;
-    const int cgl = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const int cg = blockIdx.x * 16 + cgl;
-    const int n = blockIdx.y;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (cg < C8) {
-        const half_t* p = x + (size_t)n * hw * c + cg * 8;
-        for (int px = slot; px < hw; px += 16) {
-            const half8 v = *reinterpret_cast<const half8*>(p + (size_t)px * c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[slot][cgl][e] = s[e];
-    __syncthreads();
-    if (slot == 0 && cg < C8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = 0.f;
-            for (int k = 0; k < 16; ++k) t += red[k][cgl][e];
-            sums[(size_t)n * c + cg * 8 + e] = t;
-        }
-    }
-}
+template <int K, int S, int TW>
+int dw_blocks(const DwArgs& a) { return dn_cdiv((long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8), 256); }
 
-// fc1 (+bias) -> ReLU -> fc2 (+bias) -> Hardsigmoid = relu6(x+3)/6      (mobilenetv3.py:31-36)
-// w1t: [c][squeeze], w2t: [squeeze][c] (transposed at plan time so lanes read consecutive addresses)
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ sums, const float* __restrict__ w1t,
-                                                   const float* __restrict__ b1, const float* __restrict__ w2t,
+// ---- SE FCs: (sum of partials)/pixels -> fc1(+b) -> ReLU -> fc2(+b) -> Hardsigmoid   (mobilenetv3.py:31-36) ------------
+// One 512-thread workgroup per image; every dot product is spread over the 64 lanes of a wave (coalesced weight rows,
+// shuffle reduction) instead of one serial loop per thread: the serial form was latency-bound at ~130 us per launch.
+// w1: [squeeze][c] (fc1.weight), w2: [c][squeeze] (fc2.weight), both in the reference's native layout.
+__global__ __launch_bounds__(512) void se_fc_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                    const float* __restrict__ b2, float* __restrict__ scale,
                                                    int c, int sq, float inv_pixels) {
+    // Every phase issues a whole batch of independent loads into registers before the first use: a plain
+    // `for (...) t += w[i] * x[i]` loop waits one full L2 latency per iteration on this chip.
+    constexpr int MAXC64 = 16;         // c <= 1024
+    constexpr int MAXS64 = 4;          // squeeze <= 256
     extern __shared__ float sh[];      // mean[c] then z[sq]
     float* mean = sh;
     float* z = sh + c;
     const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < c; i += 256) mean[i] = sums[(size_t)n * c + i] * inv_pixels;
-    __syncthreads();
-    for (int j = threadIdx.x; j < sq; j += 256) {
-        float t = b1[j];
-        for (int i = 0; i < c; ++i) t += w1t[(size_t)i * sq + j] * mean[i];
-        z[j] = fmaxf(t, 0.f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < c; i += 512) {
+        const float* p = partial + (size_t)n * nblk * c + i;
+        float t = 0.f;
+        for (int b0 = 0; b0 < nblk; b0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (b0 + u < nblk) ? p[(size_t)(b0 + u) * c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += v[u];
+        }
+        mean[i] = t * inv_pixels;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < c; i += 256) {
-        float t = b2[i];
-        for (int j = 0; j < sq; ++j) t += w2t[(size_t)j * c + i] * z[j];
-        scale[(size_t)n * c + i] = fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    // fc1: 4 outputs per wave per batch
+    for (int j0 = wave * 4; j0 < sq; j0 += 32) {
+        float wv[4][MAXC64];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < MAXC64; ++q) {
+                const int i = lane + 64 * q;
+                wv[u][q] = (j0 + u < sq && i < c) ? w1[(size_t)(j0 + u) * c + i] : 0.f;
+            }
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < MAXC64; ++q) {
+            const int i = lane + 64 * q;
+            const float m = (i < c) ? mean[i] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] += wv[u][q] * m;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) t[u] += __shfl_xor(t[u], d);
+            if (lane == 0 && j0 + u < sq) z[j0 + u] = fmaxf(t[u] + b1[j0 + u], 0.f);
+        }
+    }
+    __syncthreads();
+    // fc2: 16 outputs per wave per batch
+    for (int i0 = wave * 16; i0 < c; i0 += 128) {
+        float wv[16][MAXS64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int q = 0; q < MAXS64; ++q) {
+                const int j = lane + 64 * q;
+                wv[u][q] = (i0 + u < c && j < sq) ? w2[(size_t)(i0 + u) * sq + j] : 0.f;
+            }
+        float zz[MAXS64];
+#pragma unroll
+        for (int q = 0; q < MAXS64; ++q) zz[q] = (lane + 64 * q < sq) ? z[lane + 64 * q] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < MAXS64; ++q) t += wv[u][q] * zz[q];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+            if (lane == 0 && i0 + u < c) scale[(size_t)n * c + i0 + u] = fminf(fmaxf(t + b2[i0 + u] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        }
     }
 }
 
 // ---- stem: dense kxk conv on the NCHW fp32 image, normalisation on load, NHWC fp16 out ------------------
+// One thread per output pixel, all COUT channels. The weights are wave-uniform: indexing the kernel-argument pointer
+// with compile-time offsets makes hipcc fetch them with s_load (scalar cache) and feed them as SGPR operands of
+// v_fmac -- no LDS, no 400-register weight image (the first version needed 256 VGPRs and spilled for COUT >= 32).
 template <int COUT, int K>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
-    __shared__ float wsh[K * K * 3 * COUT];
-    __shared__ float bsh[COUT];
-    for (int i = threadIdx.x; i < K * K * 3 * COUT; i += 256) wsh[i] = a.w[i];
-    for (int i = threadIdx.x; i < COUT; i += 256) bsh[i] = a.bias[i];
-    __syncthreads();
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int ox = (int)(idx % a.wo);
-    idx /= a.wo;
-    const int oy = (int)(idx % a.ho);
-    const int n = (int)(idx / a.ho);
-    if (n >= a.n) return;
+    const float* __restrict__ wts = a.w;
+    const float* __restrict__ bias = a.bias;
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    const int ox = idx % a.wo;
+    const int oy = idx / a.wo;
+    if (oy >= a.ho) return;
     float acc[COUT];
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = bsh[o];
-#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
+    // only one (channel, ky) row of taps is unrolled at a time: K*COUT weights live in SGPRs per step. Fully unrolling
+    // makes hipcc hoist all K*K*3*COUT scalar loads and spill SGPRs through thousands of v_readlane.
+#pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         const float* plane = a.img + ((size_t)n * 3 + c) * a.h * a.w_;
-        const float mean = a.mean[c], sd = a.std[c];
-#pragma unroll
+        const float mean = a.mean[c], inv = a.inv_std[c];
+#pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
             const int iy = oy * a.stride - a.pad + ky;
+            const bool yok = iy >= 0 && iy < a.h;
+            const float* prow = plane + (yok ? iy : 0) * a.w_;
+            const float* wp = wts + (c * K + ky) * K * COUT;
+            float v[K];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const int ix = ox * a.stride - a.pad + kx;
-                float v = 0.f;      // zero padding is applied to the NORMALISED image (transform then conv)
-                if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_) v = (plane[(size_t)iy * a.w_ + ix] - mean) / sd;
-                const float* wp = &wsh[((c * K + ky) * K + kx) * COUT];
-#pragma unroll
-                for (int o = 0; o < COUT; ++o) acc[o] += v * wp[o];
+                float t = 0.f;      // zero padding is applied to the NORMALISED image (transform then conv)
+                if (yok && ix >= 0 && ix < a.w_) t = (prow[ix] - mean) * inv;
+                v[kx] = t;
             }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] += v[kx] * wp[kx * COUT + o];
         }
     }
     half_t* op = a.out + ((size_t)(n * a.ho + oy) * a.wo + ox) * COUT;
@@ -179,8 +241,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
 
 template <int COUT, int K>
 int launch_stem_t(const StemArgs& a, hipStream_t s) {
-    const long threads = (long)a.n * a.ho * a.wo;
-    hipLaunchKernelGGL((stem_kernel<COUT, K>), dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((stem_kernel<COUT, K>), dim3(dn_cdiv((long)a.ho * a.wo, 256), a.n), dim3(256), 0, s, a);
     return DN_OK;
 }
 
@@ -188,6 +249,7 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
 
 int launch_depthwise(const DwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.c % 8 == 0, "depthwise: c=%d must be a multiple of 8", a.c);
+    DN_REQUIRE(!a.pool || a.c / 8 <= 256, "depthwise: pooled channel groups %d > 256", a.c / 8);
     if (a.k == 3 && a.stride == 1) return launch_dw<3, 1, 4>(a, s);
     if (a.k == 3 && a.stride == 2) return launch_dw<3, 2, 2>(a, s);
     if (a.k == 5 && a.stride == 1) return launch_dw<5, 1, 4>(a, s);
@@ -196,14 +258,17 @@ int launch_depthwise(const DwArgs& a, hipStream_t s) {
     return DN_E_UNSUPPORTED;
 }
 
-int launch_se_pool(const half_t* x, float* sums, int n, int hw, int c, hipStream_t s) {
-    hipLaunchKernelGGL(se_pool_kernel, dim3(dn_cdiv(c / 8, 16), n), dim3(256), 0, s, x, sums, hw, c);
-    return DN_OK;
+int depthwise_pool_blocks(const DwArgs& a) {
+    if (a.k == 3 && a.stride == 1) return dw_blocks<3, 1, 4>(a);
+    if (a.k == 3 && a.stride == 2) return dw_blocks<3, 2, 2>(a);
+    if (a.k == 5 && a.stride == 1) return dw_blocks<5, 1, 4>(a);
+    return dw_blocks<5, 2, 2>(a);
 }
 
-int launch_se_fc(const float* sums, const float* w1t, const float* b1, const float* w2t, const float* b2, float* scale,
+int launch_se_fc(const float* partial, int nblk, const float* w1, const float* b1, const float* w2, const float* b2, float* scale,
                  int n, int c, int squeeze, int pool_pixels, hipStream_t s) {
-    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(256), (size_t)(c + squeeze) * sizeof(float), s, sums, w1t, b1, w2t, b2,
+    DN_REQUIRE(c <= 1024 && squeeze <= 256, "se: c=%d squeeze=%d exceed the kernel's register tiles", c, squeeze);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(512), (size_t)(c + squeeze) * sizeof(float), s, partial, nblk, w1, b1, w2, b2,
                        scale, c, squeeze, 1.0f / (float)pool_pixels);
     return DN_OK;
 }

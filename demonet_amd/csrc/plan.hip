@@ -45,6 +45,7 @@ struct dn_plan {
     std::vector<dn_tensor_desc> tensors;
     std::vector<dn_op_desc> ops;
     std::vector<int> level_off;         // anchor offset per level
+    std::vector<int> pool_blocks;       // per DN_T_POOL tensor: partial-sum rows per image (= dw workgroups per image)
     unsigned char* weights_dev = nullptr;
     size_t weight_bytes = 0;
     float* anchors_dev = nullptr;
@@ -72,7 +73,8 @@ static const Layout& get_layout(dn_plan* p, int n) {
         const dn_tensor_desc& t = p->tensors[i];
         size_t b = 0;
         if (t.kind == DN_T_ACT) b = (size_t)n * t.h * t.w * t.c * 2;
-        else if (t.kind == DN_T_VEC || t.kind == DN_T_POOL) b = (size_t)n * t.c * 4;
+        else if (t.kind == DN_T_VEC) b = (size_t)n * t.c * 4;
+        else if (t.kind == DN_T_POOL) b = (size_t)n * p->pool_blocks[i] * t.c * 4;
         else continue;      // image: caller's buffer (or the resized copy below)
         L.toff[i] = off;
         L.tbytes[i] = b;
@@ -117,6 +119,18 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (o.w_off >= 0 && (size_t)o.w_off >= weight_bytes) { dn_set_error("dn_create: op %d weight offset out of range", i); return fail(DN_E_INVALID); }
         if (o.type < DN_OP_STEM || o.type > DN_OP_L2NORM) { dn_set_error("dn_create: op %d unknown type %d", i, o.type); return fail(DN_E_INVALID); }
         if (o.head && (o.level < 0 || o.level >= desc->n_levels)) { dn_set_error("dn_create: head op %d bad level", i); return fail(DN_E_INVALID); }
+    }
+    // partial-sum rows of every pooled tensor = workgroups per image of its producing depthwise op
+    p->pool_blocks.assign(desc->n_tensors, 0);
+    for (int i = 0; i < desc->n_ops; ++i) {
+        const dn_op_desc& o = p->ops[i];
+        if (o.type == DN_OP_DW && o.pool >= 0) {
+            const dn_tensor_desc& ti = p->tensors[o.in];
+            const dn_tensor_desc& to = p->tensors[o.out];
+            DwArgs a{};
+            a.n = 1; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.ho = to.h; a.wo = to.w;
+            p->pool_blocks[o.pool] = depthwise_pool_blocks(a);
+        }
     }
     // anchor offsets per level
     int acc = 0;
@@ -204,7 +218,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 a.out = reinterpret_cast<half_t*>(tptr(o.out));
                 a.n = n; a.h = ti.h; a.w_ = ti.w; a.cout = o.cout; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
                 a.ho = to.h; a.wo = to.w;
-                for (int c = 0; c < 3; ++c) { a.mean[c] = d.mean[c]; a.std[c] = d.std[c]; a.inv_std_unused[c] = 0.f; }
+                for (int c = 0; c < 3; ++c) { a.mean[c] = d.mean[c]; a.inv_std[c] = 1.0f / d.std[c]; }
                 rc = launch_stem(a, s);
                 break;
             }
@@ -239,13 +253,12 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 a.out = reinterpret_cast<half_t*>(tptr(o.out));
                 a.n = n; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
                 a.ho = to.h; a.wo = to.w;
+                a.pool = o.pool >= 0 ? reinterpret_cast<float*>(tptr(o.pool)) : nullptr;
                 rc = launch_depthwise(a, s);
-                if (rc == DN_OK && o.pool >= 0)
-                    rc = launch_se_pool(a.out, reinterpret_cast<float*>(tptr(o.pool)), n, to.h * to.w, o.cin, s);
                 break;
             }
             case DN_OP_SE: {
-                rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), reinterpret_cast<const float*>(W + o.w_off),
+                rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), p->pool_blocks[o.in], reinterpret_cast<const float*>(W + o.w_off),
                                   reinterpret_cast<const float*>(W + o.b_off), reinterpret_cast<const float*>(W + o.w2_off),
                                   reinterpret_cast<const float*>(W + o.b2_off), reinterpret_cast<float*>(tptr(o.out)), n,
                                   o.cin, o.squeeze, o.pool_pixels, s);

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     static_assert(NX >= 1 && NW >= 0, "tile too small");
     constexpr int NWc = NW > 0 ? NW : 1;
     __shared__ __attribute__((aligned(16))) half_t lds[2][(BP + BC) * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) float bsh[BC];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -40,6 +41,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     const int m0 = blockIdx.x * BP;
     const int n0 = blockIdx.y * BC;
     const int M = a.m, K = a.cin, NC = a.cout;
+    const int dbg = a.act >> 8;            // probe-only knobs: 1 = skip stores, 2 = skip global loads of x
+    a.act &= 0xff;
 
     floatx16 acc[TC][TP];
 #pragma unroll
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
                 const int iy = cvy[i] + dy, ix = cvx[i] + dx;
                 if (m < M && k < K && iy >= 0 && iy < a.cv_h && ix >= 0 && ix < a.cv_w)
                     v = *reinterpret_cast<const uint4*>(a.x + ((size_t)(cvn[i] * a.cv_h + iy) * a.cv_w + ix) * a.cv_cin + tap_c0 + q * 8);
-            } else if (m < M && k < K) {
+            } else if (m < M && k < K && !(dbg & 2)) {
                 v = *reinterpret_cast<const uint4*>(a.x + (size_t)m * K + k);
                 if (a.se) {
                     const float* sp = a.se + (size_t)(m / a.hw) * K + k;
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     };
 
     const int KT = (K + BK - 1) / BK;
+    if (tid < BC) bsh[tid] = (n0 + tid < NC) ? a.bias[n0 + tid] : 0.f;      // visible after the first barrier below
     load_stage(0);
     store_stage(0);
     __syncthreads();
@@ -159,47 +163,68 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         __syncthreads();
     }
 
-    // epilogue: lane holds pixel (lane&31) of each pixel tile; registers 4g..4g+3 = channels 8g+4h..+3 of each channel tile
+    // epilogue: lane holds pixel (lane&31) of each pixel tile; registers 4g..4g+3 = channels 8g+4h..+3 of each channel tile.
+    // Two phases so that no load sits behind a possibly-aliasing store: (1) all residual loads, (2) math + stores.
+    // Bias comes from LDS (staged before the K loop).
+    size_t obase[TP];
+    bool mvalid[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int m = m0 + (wp * TP + j) * 32 + r;
-        if (m >= M) continue;
-        size_t obase;
+        mvalid[j] = m < M;
         if (a.out_fp32) {
             const int img = m / a.hw;
-            obase = (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m - img * a.hw) * NC;
+            obase[j] = (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m - img * a.hw) * NC;
         } else {
-            obase = (size_t)m * NC;
+            obase[j] = (size_t)m * NC;
         }
+    }
+    half4 resv[TP][TC][4];
+    if (a.residual) {
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = n0 + (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                    half4 rv = {0, 0, 0, 0};
+                    if (mvalid[j] && c0 < NC) rv = *reinterpret_cast<const half4*>(a.residual + obase[j] + c0);
+                    resv[j][i][g] = rv;
+                }
+    }
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        if (!mvalid[j]) continue;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c0 = n0 + (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;      // channel within the block tile
+                const int c0 = n0 + cl;
                 if (c0 >= NC) continue;
-                float v[4];
+                const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
+                float v[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z,
+                              acc[i][j][4 * g + 3] + bv.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = c0 + e;
-                    v[e] = acc[i][j][4 * g + e] + (c < NC ? a.bias[c] : 0.f);
-                    v[e] = dn_act(v[e], a.act);
-                }
-                if (a.out_fp32) {
-                    float* o = reinterpret_cast<float*>(a.out) + obase + c0;
+                for (int e = 0; e < 4; ++e) v[e] = dn_act(v[e], a.act);
+                if (dbg & 1) {
+                    if (v[0] == 123.456f) reinterpret_cast<float*>(a.out)[0] = v[1];
+                } else if (a.out_fp32) {
+                    float* o = reinterpret_cast<float*>(a.out) + obase[j] + c0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (c0 + e < NC) o[e] = v[e];
                 } else {
-                    // cout is a multiple of 8 for every fp16 layer -> the 4-channel group is entirely in range
+                    // cout is a multiple of 4 for every fp16 layer -> the 4-channel group is entirely in range
                     if (a.residual) {
-                        const half4 rv = *reinterpret_cast<const half4*>(a.residual + obase + c0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        for (int e = 0; e < 4; ++e) v[e] += (float)resv[j][i][g][e];
                     }
                     half4 hv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
-                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.out) + obase + c0) = hv;
+                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.out) + obase[j] + c0) = hv;
                 }
             }
         }
@@ -215,13 +240,32 @@ int launch_cfg(const PwArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// Tile choice: these GEMMs are latency/HBM-bound, not MFMA-bound, so what matters is (a) enough workgroups to fill
+// 256 CUs several times over and (b) not re-reading x for many channel tiles. Prefer the largest tile that still
+// gives >= ~1500 workgroups, else fall back to smaller tiles.
+template <bool CONV>
+int launch_select(const PwArgs& a, hipStream_t s) {
+    auto wgs = [&](int bp, int bc) { return (long)dn_cdiv(a.m, bp) * dn_cdiv(a.cout, bc); };
+    if (a.cout <= 32) {
+        if (wgs(256, 32) >= 1500) return launch_cfg<256, 32, 4, 1, CONV>(a, s);
+        return launch_cfg<128, 32, 4, 1, CONV>(a, s);
+    }
+    if (a.cout <= 64) {
+        if (wgs(128, 64) >= 1500) return launch_cfg<128, 64, 4, 1, CONV>(a, s);
+        return launch_cfg<64, 64, 2, 2, CONV>(a, s);
+    }
+    if (wgs(128, 128) >= 1500) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
+    if (wgs(128, 64) >= 1500 || a.cout % 128 > 64 || a.cout % 128 == 0) {
+        if (wgs(64, 128) >= 600) return launch_cfg<64, 128, 2, 2, CONV>(a, s);
+    }
+    return launch_cfg<64, 64, 2, 2, CONV>(a, s);
+}
+
 int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.cin % 8 == 0, "pointwise: cin=%d must be a multiple of 8", a.cin);
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
-    if (a.cout <= 32) return launch_cfg<256, 32, 4, 1, false>(a, s);
-    if (a.cout <= 64) return launch_cfg<128, 64, 4, 1, false>(a, s);
-    return launch_cfg<128, 128, 2, 2, false>(a, s);
+    return launch_select<false>(a, s);
 }
 
 int launch_conv(const ConvArgs& c, hipStream_t s) {
@@ -236,7 +280,5 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     a.cin = c.k * c.k * c.cin;
     a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
     DN_REQUIRE(a.m > 0, "conv: empty problem");
-    if (a.cout <= 32) return launch_cfg<256, 32, 4, 1, true>(a, s);
-    if (a.cout <= 64) return launch_cfg<128, 64, 4, 1, true>(a, s);
-    return launch_cfg<128, 128, 2, 2, true>(a, s);
+    return launch_select<true>(a, s);
 }

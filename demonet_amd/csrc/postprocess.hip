@@ -18,7 +18,12 @@
 // This file is compiled with -ffp-contract=off: decode and IoU must round like the reference (no FMA fusion).
 #include "common.h"
 
+static long long* g_pp_stamps = nullptr;     // dev hook: per-workgroup phase stamps of select_nms (dn_debug_pp_stamps)
+extern "C" __attribute__((visibility("default"))) void dn_debug_pp_stamps(void* dev_ptr) { g_pp_stamps = (long long*)dev_ptr; }
+
 namespace {
+
+#define PP_STAMP(k) do { if (stamps && tid == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
 
@@ -164,7 +169,7 @@ template <int NW>   // 64-candidate words: candidate capacity MC = 64*NW >= topk
 __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
                                                         int A, int Km1, float score_thr, float nms_thr, int topk,
                                                         float* __restrict__ keptScore, int* __restrict__ keptAnchor,
-                                                        int* __restrict__ keptCount) {
+                                                        int* __restrict__ keptCount, long long* stamps) {
     constexpr int MC = 64 * NW;
     constexpr int SORTN = (NW <= 1) ? 64 : (NW <= 2) ? 128 : (NW <= 4) ? 256 : 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     const int n = blockIdx.y;
     const float* col = scoresT + ((size_t)n * Km1 + cls) * A;
 
+    PP_STAMP(0);
     // 1. keys + count of passing scores
     if (tid < 16) sh[tid] = 0;
     __syncthreads();
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
         if (tid == 0) keptCount[(size_t)n * Km1 + cls] = 0;
         return;
     }
+    PP_STAMP(1);
     // 2. threshold key T: keep all keys > T and `quota` keys == T (lowest anchors first)
     unsigned T = 0, quota = 0;
     if (cnt > (unsigned)topk) {
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
         quota = need;
     }
     const int M = (int)min(cnt, (unsigned)topk);
+    PP_STAMP(2);
     // 3. ordered compaction -> cand[] (keys > T first region, then == T in ascending anchor order)
     {
         unsigned base_gt = 0, base_eq = 0;
@@ -249,8 +257,10 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     }
     for (int i = M + tid; i < SORTN; i += 256) cand[i] = 0ull;
     __syncthreads();
+    PP_STAMP(3);
     // 4. sort by (score desc, anchor asc)
     bitonic_sort_desc<256>(cand, SORTN);
+    PP_STAMP(4);
     // 5. gather boxes
     for (int i = tid; i < MC; i += 256) {
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -263,30 +273,43 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     }
     if (tid < 8) removed[tid] = 0ull;
     __syncthreads();
-    // 6. IoU mask: mask[i][w] bit j-64w set iff j > i and IoU(i, j) > nms_thr   (strict >, float32, inter/(a+b-inter))
+    PP_STAMP(5);
+    // 6. IoU mask: mask[i][w] bit j-64w set iff j > i and IoU(i, j) > nms_thr   (strict >, float32, inter/(a_i+a_j-inter)).
+    //    Lane = column j (its box stays in registers), the row box i is an LDS broadcast, one __ballot yields the whole
+    //    64-bit word. Items (word w, 64-row block rb <= w) are dealt round-robin to the 4 waves.
     const int nwords = (M + 63) >> 6;
-    for (int w = 0; w < nwords; ++w) {
-        const int rows = min(M, 64 * (w + 1));
-        for (int i = tid; i < rows; i += 256) {
-            const float4 bi = cbox[i];
-            const float ai = carea[i];
-            unsigned long long bits = 0ull;
-            const int jbeg = max(64 * w, i + 1), jend = min(M, 64 * (w + 1));
-            for (int j = jbeg; j < jend; ++j) {
-                const float4 bj = cbox[j];
-                const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-                const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-                const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
-                const float inter = iw * ih;
-                if (inter > 0.f) {
-                    const float ovr = inter / (ai + carea[j] - inter);
-                    if (ovr > nms_thr) bits |= 1ull << (j - 64 * w);
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        int item = 0;
+        for (int w = 0; w < nwords; ++w) {
+            const int j = 64 * w + lane;
+            const float4 bj = cbox[j];          // j < MC always; rows >= M hold zero boxes
+            const float aj = carea[j];
+            const bool jvalid = j < M;
+            for (int rb = 0; rb <= w; ++rb, ++item) {
+                if ((item & 3) != wave) continue;
+                const int iend = min(M, 64 * (rb + 1));
+#pragma unroll 4
+                for (int i = 64 * rb; i < iend; ++i) {
+                    const float4 bi = cbox[i];
+                    const float ai = carea[i];
+                    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+                    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+                    const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+                    const float inter = iw * ih;
+                    bool sup = false;
+                    if (inter > 0.f) {
+                        const float ovr = inter / (ai + aj - inter);
+                        sup = (ovr > nms_thr) && (j > i) && jvalid;
+                    }
+                    const unsigned long long bits = __ballot(sup);
+                    if (lane == 0) mask[i * NW + w] = bits;
                 }
             }
-            mask[i * NW + w] = bits;
         }
     }
     __syncthreads();
+    PP_STAMP(6);
     // 7. greedy reduce by wave 0, 64 candidates at a time; 8. compact kept candidates in order
     if (tid < 64) {
         const int lane = tid;
@@ -324,6 +347,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
         }
         if (lane == 0) keptCount[(size_t)n * Km1 + cls] = kept_before;
     }
+    PP_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -452,7 +476,7 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
         attr_set = true;
     }
     hipLaunchKernelGGL((select_nms_kernel<NW>), dim3(a.K - 1, a.n), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount);
+                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, g_pp_stamps);
     return DN_OK;
 }
 

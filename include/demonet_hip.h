@@ -30,7 +30,7 @@ enum { DN_ACT_NONE = 0, DN_ACT_RELU = 1, DN_ACT_RELU6 = 2, DN_ACT_HSWISH = 3 };
 /* op kinds of the lowered graph (demonet_amd/spec.py IR) */
 enum { DN_OP_STEM = 1, DN_OP_PW = 2, DN_OP_DW = 3, DN_OP_SE = 4, DN_OP_CONV = 5, DN_OP_MAXPOOL = 6, DN_OP_L2NORM = 7 };
 
-/* tensor kinds: NHWC fp16 activation | NCHW fp32 image | per-image fp32 vector [c] | fp32 pooled sums [c] */
+/* tensor kinds: NHWC fp16 activation | NCHW fp32 image | per-image fp32 vector [c] | fp32 pooled partial sums [blocks][c] */
 enum { DN_T_ACT = 0, DN_T_IMAGE = 1, DN_T_VEC = 2, DN_T_POOL = 3 };
 
 typedef struct dn_tensor_desc {
@@ -53,7 +53,7 @@ typedef struct dn_op_desc {
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob; -1 none.
                                                PW/CONV: w = fp16 [cout][k*k*cin] (tap-major, channel-minor), b = fp32 [cout]
                                                DW/STEM: w = fp16 [k*k][c] / fp32 [k*k*3][cout], b = fp32 [c]
-                                               SE: w = fp32 fc1 [squeeze][c], b = fc1 bias, w2 = fc2 [c][squeeze], b2 = fc2 bias
+                                               SE: w = fp32 fc1 [squeeze][c], b = fc1 bias, w2 = fc2 [c][squeeze], b2 = fc2 bias (native layouts)
                                                L2NORM: w = fp32 scale [c] */
 } dn_op_desc;
 
