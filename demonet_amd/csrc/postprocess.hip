@@ -16,6 +16,8 @@
 // All ordering decisions are integer/compare work on the fp32 scores, with the canonical tie-break of the oracle
 // (score desc, class asc, anchor asc): bit-exact indices whenever scores/boxes agree.
 // This file is compiled with -ffp-contract=off: decode and IoU must round like the reference (no FMA fusion).
+#include <stdlib.h>
+
 #include "common.h"
 
 static long long* g_pp_stamps = nullptr;     // dev hook: per-workgroup phase stamps of select_nms (dn_debug_pp_stamps)
@@ -26,15 +28,20 @@ namespace {
 #define PP_STAMP(k) do { if (stamps && tid == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
+constexpr int HSHIFT = 19;                               // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
+constexpr int HBINS = 4096;
 
 // ------------------------------------------------------------------------------------------------------------
 // P1
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __restrict__ logits, const float* __restrict__ reg,
                                                             const float* __restrict__ anchors, float* __restrict__ scoresT,
-                                                            float4* __restrict__ boxes, int A, int K, float img_w, float img_h) {
-    extern __shared__ float tile[];            // [64][K] then rowsum[64]
+                                                            float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
+                                                            float score_thr, unsigned* __restrict__ ghist) {
+    extern __shared__ float tile[];            // [64][K] then rowsum[64] then hist[HBINS]
     float* rowsum = tile + 64 * K;
+    unsigned* lhist = reinterpret_cast<unsigned*>(rowsum + 64);
+    for (int i = threadIdx.x; i < HBINS; i += 256) lhist[i] = 0u;
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int a0 = blockIdx.x * 64;
@@ -65,7 +72,16 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     const int Km1 = K - 1;
     for (int idx = tid; idx < Km1 * 64; idx += 256) {
         const int k = 1 + (idx >> 6), a = idx & 63;
-        if (a < na) scoresT[((size_t)n * Km1 + (k - 1)) * A + a0 + a] = tile[a * K + k] / rowsum[a];
+        if (a < na) {
+            const float sc = tile[a * K + k] / rowsum[a];
+            scoresT[((size_t)n * Km1 + (k - 1)) * A + a0 + a] = sc;
+            if (sc > score_thr) atomicAdd(&lhist[__float_as_uint(sc) >> HSHIFT], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HBINS; i += 256) {
+        const unsigned v = lhist[i];
+        if (v) atomicAdd(&ghist[(size_t)n * HBINS + i], v);       // integer atomics: order-independent result
     }
     if (tid < na) {
         const int a = a0 + tid;
@@ -140,6 +156,21 @@ __device__ __forceinline__ void bitonic_sort_desc(unsigned long long* v, int N) 
     }
 }
 
+// Descending sort of M unique 64-bit keys by counting ranks (no barriers inside): v -> tmp -> v. M <= capacity of both.
+template <int NT>
+__device__ __forceinline__ void rank_sort_desc(unsigned long long* v, unsigned long long* tmp, int M) {
+    for (int e = threadIdx.x; e < M; e += NT) {
+        const unsigned long long key = v[e];
+        int rank = 0;
+#pragma unroll 8
+        for (int u = 0; u < M; ++u) rank += (v[u] > key) ? 1 : 0;
+        tmp[rank] = key;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < M; e += NT) v[e] = tmp[e];
+    __syncthreads();
+}
+
 // Exclusive, thread-ordered block scan of two flags. wtot = LDS scratch [2][NT/64]. Returns totals via references.
 template <int NT>
 __device__ __forceinline__ void block_scan2(bool f0, bool f1, unsigned* wtot, unsigned& ex0, unsigned& ex1,
@@ -162,6 +193,111 @@ __device__ __forceinline__ void block_scan2(bool f0, bool f1, unsigned* wtot, un
     __syncthreads();
 }
 
+// ---- NMS phases shared by the fast and the full per-class kernels -------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void nms_mask_phase(const float4* cbox, const float* carea, unsigned long long* mask, int M, float nms_thr) {
+    // 6. IoU mask: mask[i][w] bit j-64w set iff j > i and IoU(i, j) > nms_thr  (strict >, float32, inter/(a_i+a_j-inter)).
+    //    Lane = column j (box in registers); two rows per iteration in packed fp32 (v_pk_*); the row boxes are LDS
+    //    broadcasts; one __ballot per row yields the 64-bit word. The division is only executed when some lane is within
+    //    2^-20 (relative) of the threshold: outside that band  inter > thr*union*(1+2^-20)  implies RN(inter/union) > thr
+    //    and  inter < thr*union*(1-2^-20)  implies RN(inter/union) <= thr, so the result is identical to always dividing.
+    const int nwords = (M + 63) >> 6;
+    const int tid = threadIdx.x;
+    {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const int lane = tid & 63, wave = tid >> 6;
+        int item = 0;
+        for (int w = 0; w < nwords; ++w) {
+            const int j = 64 * w + lane;
+            const float4 bj = cbox[j];          // j < MC always; rows >= M hold zero boxes
+            const float aj = carea[j];
+            const bool jvalid = j < M;
+            const f2 jx1 = {bj.x, bj.x}, jy1 = {bj.y, bj.y}, jx2 = {bj.z, bj.z}, jy2 = {bj.w, bj.w}, ja = {aj, aj};
+            const f2 zero = {0.f, 0.f};
+            for (int rb = 0; rb <= w; ++rb, ++item) {
+                if ((item & 3) != wave) continue;
+                const int iend = min(M, 64 * (rb + 1));
+                const bool diag = (rb == w);
+                for (int i = 64 * rb; i < iend; i += 2) {
+                    const float4 b0 = cbox[i], b1 = cbox[i + 1];      // i+1 <= MC-1; a row >= M is a zero box -> inter 0
+                    const f2 ia = {carea[i], carea[i + 1]};
+                    const f2 ix1 = {b0.x, b1.x}, iy1 = {b0.y, b1.y}, ix2 = {b0.z, b1.z}, iy2 = {b0.w, b1.w};
+                    const f2 xx1 = __builtin_elementwise_max(ix1, jx1), yy1 = __builtin_elementwise_max(iy1, jy1);
+                    const f2 xx2 = __builtin_elementwise_min(ix2, jx2), yy2 = __builtin_elementwise_min(iy2, jy2);
+                    const f2 iw = __builtin_elementwise_max(zero, xx2 - xx1), ih = __builtin_elementwise_max(zero, yy2 - yy1);
+                    const f2 inter = iw * ih;
+                    const f2 uni = (ia + ja) - inter;
+                    const f2 t = uni * nms_thr;
+                    const f2 hi = t * 1.00000095367431640625f, lo = t * 0.99999904632568359375f;
+                    bool s0 = inter.x > hi.x, s1 = inter.y > hi.y;
+                    const bool m0 = !s0 && !(inter.x < lo.x), m1 = !s1 && !(inter.y < lo.y);
+                    if (m0 || m1) {                                   // borderline (incl. 0/0): decide exactly
+                        if (m0) s0 = (inter.x / uni.x) > nms_thr;
+                        if (m1) s1 = (inter.y / uni.y) > nms_thr;
+                    }
+                    s0 = s0 && jvalid;
+                    s1 = s1 && jvalid;
+                    if (diag) { s0 = s0 && (j > i); s1 = s1 && (j > i + 1); }
+                    const unsigned long long w0 = __ballot(s0), w1 = __ballot(s1);
+                    if (lane == 0) {
+                        mask[i * NW + w] = w0;
+                        if (i + 1 < iend) mask[(i + 1) * NW + w] = w1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// greedy reduce by ONE wave (threadIdx.x < 64), 64 candidates at a time, then ordered compaction of the survivors
+template <int NW>
+__device__ __forceinline__ void nms_serial_phase(const unsigned long long* cand, const unsigned long long* mask,
+                                                 unsigned long long* removed, int M, float* keptScoreOut, int* keptAnchorOut,
+                                                 int* keptCountOut) {
+    // 7. greedy reduce by wave 0, 64 candidates at a time; 8. compact kept candidates in order
+    {
+        const int lane = threadIdx.x;
+        const int nwords = (M + 63) >> 6;
+        int kept_before = 0;
+        for (int c = 0; c < nwords; ++c) {
+            const int i = 64 * c + lane;
+            const unsigned long long rowbits = (i < M) ? mask[i * NW + c] : 0ull;
+            const unsigned lo = (unsigned)rowbits, hi = (unsigned)(rowbits >> 32);
+            const unsigned long long rem0 = removed[c];
+            // wave-uniform state in SGPRs: the 64-step dependency chain runs on the scalar unit
+            unsigned rem_lo = __builtin_amdgcn_readfirstlane((unsigned)rem0);
+            unsigned rem_hi = __builtin_amdgcn_readfirstlane((unsigned)(rem0 >> 32));
+            const int nvalid = min(64, M - 64 * c);
+            for (int l = 0; l < nvalid; ++l) {
+                const unsigned bit = (l < 32) ? ((rem_lo >> l) & 1u) : ((rem_hi >> (l - 32)) & 1u);
+                if (!bit) {
+                    rem_lo |= __builtin_amdgcn_readlane(lo, l);
+                    rem_hi |= __builtin_amdgcn_readlane(hi, l);
+                }
+            }
+            const unsigned long long rem = ((unsigned long long)rem_hi << 32) | rem_lo;
+            const bool kept = (lane < nvalid) && !((rem >> lane) & 1ull);
+            // propagate suppression by the kept candidates of this chunk to the later chunks
+            if (kept) {
+                for (int w = c + 1; w < nwords; ++w) {
+                    const unsigned long long m = mask[i * NW + w];
+                    if (m) atomicOr(&removed[w], m);
+                }
+            }
+            const unsigned long long kb = __ballot(kept);
+            if (kept) {
+                const int pos = kept_before + __popcll(kb & ((1ull << lane) - 1ull));
+                const unsigned long long kv = cand[i];
+                keptScoreOut[pos] = __uint_as_float((unsigned)(kv >> 32));
+                keptAnchorOut[pos] = (int)(0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull));
+            }
+            kept_before += __popcll(kb);
+            __threadfence_block();
+        }
+        if (lane == 0) *keptCountOut = kept_before;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // P2: per (image, class)
 // ------------------------------------------------------------------------------------------------------------
@@ -169,7 +305,9 @@ template <int NW>   // 64-candidate words: candidate capacity MC = 64*NW >= topk
 __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
                                                         int A, int Km1, float score_thr, float nms_thr, int topk,
                                                         float* __restrict__ keptScore, int* __restrict__ keptAnchor,
-                                                        int* __restrict__ keptCount, long long* stamps) {
+                                                        int* __restrict__ keptCount, const int* __restrict__ needFull,
+                                                        long long* stamps) {
+    if (needFull && !needFull[blockIdx.y]) return;      // the fast path already produced this image's result
     constexpr int MC = 64 * NW;
     constexpr int SORTN = (NW <= 1) ? 64 : (NW <= 2) ? 128 : (NW <= 4) ? 256 : 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -258,8 +396,8 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     for (int i = M + tid; i < SORTN; i += 256) cand[i] = 0ull;
     __syncthreads();
     PP_STAMP(3);
-    // 4. sort by (score desc, anchor asc)
-    bitonic_sort_desc<256>(cand, SORTN);
+    // 4. sort by (score desc, anchor asc): keys are unique (anchor index in the low word) -> rank by counting
+    rank_sort_desc<256>(cand, mask, M);
     PP_STAMP(4);
     // 5. gather boxes
     for (int i = tid; i < MC; i += 256) {
@@ -274,80 +412,105 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     if (tid < 8) removed[tid] = 0ull;
     __syncthreads();
     PP_STAMP(5);
-    // 6. IoU mask: mask[i][w] bit j-64w set iff j > i and IoU(i, j) > nms_thr   (strict >, float32, inter/(a_i+a_j-inter)).
-    //    Lane = column j (its box stays in registers), the row box i is an LDS broadcast, one __ballot yields the whole
-    //    64-bit word. Items (word w, 64-row block rb <= w) are dealt round-robin to the 4 waves.
-    const int nwords = (M + 63) >> 6;
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        int item = 0;
-        for (int w = 0; w < nwords; ++w) {
-            const int j = 64 * w + lane;
-            const float4 bj = cbox[j];          // j < MC always; rows >= M hold zero boxes
-            const float aj = carea[j];
-            const bool jvalid = j < M;
-            for (int rb = 0; rb <= w; ++rb, ++item) {
-                if ((item & 3) != wave) continue;
-                const int iend = min(M, 64 * (rb + 1));
-#pragma unroll 4
-                for (int i = 64 * rb; i < iend; ++i) {
-                    const float4 bi = cbox[i];
-                    const float ai = carea[i];
-                    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-                    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-                    const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
-                    const float inter = iw * ih;
-                    bool sup = false;
-                    if (inter > 0.f) {
-                        const float ovr = inter / (ai + aj - inter);
-                        sup = (ovr > nms_thr) && (j > i) && jvalid;
-                    }
-                    const unsigned long long bits = __ballot(sup);
-                    if (lane == 0) mask[i * NW + w] = bits;
-                }
-            }
+    nms_mask_phase<NW>(cbox, carea, mask, M, nms_thr);
+    __syncthreads();
+    PP_STAMP(6);
+    if (tid < 64) nms_serial_phase<NW>(cand, mask, removed, M, keptScore + obase, keptAnchor + obase, keptCount + (size_t)n * Km1 + cls);
+    PP_STAMP(7);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Cut-off: only candidates that can reach the global top-D matter. tau = lower edge of the highest histogram bin
+// whose suffix count reaches `want` (a multiple of D). Greedy NMS restricted to the score >= tau prefix of each class
+// is exact for that prefix (decisions only depend on higher-scored boxes); if at least D boxes survive, every box
+// with score < tau ranks below them and cannot appear in the output. Otherwise needFull[n] triggers the full path.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ ghist, unsigned want, unsigned* __restrict__ tauKey,
+                                                 int* __restrict__ needFull) {
+    __shared__ unsigned part[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const unsigned* h = ghist + (size_t)n * HBINS;
+    // thread t owns bins [16t, 16t+16); suffix sums from the top
+    unsigned loc[16];
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { loc[i] = h[16 * tid + i]; s += loc[i]; }
+    part[tid] = s;
+    __syncthreads();
+    unsigned above = 0;
+    for (int t = tid + 1; t < 256; ++t) above += part[t];
+    // the unique thread where the suffix count crosses `want`
+    if (above < want && above + s >= want) {
+        unsigned run = above;
+        int bin = 16 * tid;
+        for (int i = 15; i >= 0; --i) {
+            run += loc[i];
+            if (run >= want) { bin = 16 * tid + i; break; }
+        }
+        tauKey[n] = (unsigned)bin << HSHIFT;
+    }
+    if (tid == 0) {
+        unsigned total = 0;
+        for (int t = 0; t < 256; ++t) total += part[t];
+        if (total < want) tauKey[n] = 0u;        // fewer passing scores than wanted: take everything
+        needFull[n] = 0;
+    }
+}
+
+// Fast path of P2: same semantics as select_nms_kernel restricted to keys >= tau. Sets needFull[n] when a class has
+// more than topk scores >= tau (the per-class top-k cap would bite: leave it to the full kernel).
+template <int NW>
+__global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
+                                                             int A, int Km1, float score_thr, float nms_thr, int topk,
+                                                             const unsigned* __restrict__ tauKey, int* __restrict__ needFull,
+                                                             float* __restrict__ keptScore, int* __restrict__ keptAnchor,
+                                                             int* __restrict__ keptCount) {
+    constexpr int MC = 64 * NW;
+    __shared__ unsigned long long cand[MC];
+    __shared__ unsigned long long tmp[MC];
+    __shared__ unsigned long long mask[MC * NW];
+    __shared__ unsigned long long removed[8];
+    __shared__ __attribute__((aligned(16))) float4 cbox[MC];
+    __shared__ float carea[MC];
+    __shared__ unsigned cnt_sh;
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.x, n = blockIdx.y;
+    const float* col = scoresT + ((size_t)n * Km1 + cls) * A;
+    const unsigned tau = tauKey[n];
+    if (tid == 0) cnt_sh = 0;
+    if (tid < 8) removed[tid] = 0ull;
+    __syncthreads();
+    for (int a = tid; a < A; a += 256) {
+        const float sc = col[a];
+        const unsigned k = __float_as_uint(sc);
+        if (sc > score_thr && k >= tau) {
+            const unsigned pos = atomicAdd(&cnt_sh, 1u);
+            if (pos < (unsigned)MC) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
         }
     }
     __syncthreads();
-    PP_STAMP(6);
-    // 7. greedy reduce by wave 0, 64 candidates at a time; 8. compact kept candidates in order
-    if (tid < 64) {
-        const int lane = tid;
-        int kept_before = 0;
-        for (int c = 0; c < nwords; ++c) {
-            const int i = 64 * c + lane;
-            const unsigned long long rowbits = (i < M) ? mask[i * NW + c] : 0ull;
-            const unsigned lo = (unsigned)rowbits, hi = (unsigned)(rowbits >> 32);
-            unsigned long long rem = removed[c];
-            const int nvalid = min(64, M - 64 * c);
-            for (int l = 0; l < nvalid; ++l) {
-                if (!((rem >> l) & 1ull)) {
-                    const unsigned rl = __builtin_amdgcn_readlane(lo, l);
-                    const unsigned rh = __builtin_amdgcn_readlane(hi, l);
-                    rem |= ((unsigned long long)rh << 32) | rl;
-                }
-            }
-            const bool kept = (lane < nvalid) && !((rem >> lane) & 1ull);
-            // propagate suppression by the kept candidates of this chunk to the later chunks
-            if (kept) {
-                for (int w = c + 1; w < nwords; ++w) {
-                    const unsigned long long m = mask[i * NW + w];
-                    if (m) atomicOr(&removed[w], m);
-                }
-            }
-            const unsigned long long kb = __ballot(kept);
-            if (kept) {
-                const int pos = kept_before + __popcll(kb & ((1ull << lane) - 1ull));
-                const unsigned long long kv = cand[i];
-                keptScore[obase + pos] = __uint_as_float((unsigned)(kv >> 32));
-                keptAnchor[obase + pos] = (int)(0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull));
-            }
-            kept_before += __popcll(kb);
-            __threadfence_block();
-        }
-        if (lane == 0) keptCount[(size_t)n * Km1 + cls] = kept_before;
+    const unsigned cnt = cnt_sh;
+    const size_t obase = ((size_t)n * Km1 + cls) * topk;
+    if (cnt > (unsigned)topk) {                 // cap would bite -> whole image goes through the full path
+        if (tid == 0) { needFull[n] = 1; keptCount[(size_t)n * Km1 + cls] = 0; }
+        return;
     }
-    PP_STAMP(7);
+    if (cnt == 0) {
+        if (tid == 0) keptCount[(size_t)n * Km1 + cls] = 0;
+        return;
+    }
+    const int M = (int)cnt;
+    rank_sort_desc<256>(cand, tmp, M);          // unique keys: order is the canonical (score desc, anchor asc)
+    for (int i = tid; i < MC; i += 256) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < M) b = boxes[(size_t)n * A + (0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFull))];
+        cbox[i] = b;
+        carea[i] = (b.z - b.x) * (b.w - b.y);
+    }
+    __syncthreads();
+    nms_mask_phase<NW>(cbox, carea, mask, M, nms_thr);
+    __syncthreads();
+    if (tid < 64) nms_serial_phase<NW>(cand, mask, removed, M, keptScore + obase, keptAnchor + obase, keptCount + (size_t)n * Km1 + cls);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -358,8 +521,14 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
                                                     const float* __restrict__ scale_xy, int A, int Km1, int topk, int D,
                                                     float* __restrict__ oboxes, float* __restrict__ oscores,
                                                     long long* __restrict__ olabels, int* __restrict__ ocounts,
-                                                    int* __restrict__ oanchor) {
+                                                    int* __restrict__ oanchor, int mode, const unsigned* __restrict__ tauKey,
+                                                    int* __restrict__ needFull) {
+    // mode 0: after the fast per-class pass (may raise needFull); mode 1: after the full pass (only flagged images);
+    // mode 2: unconditional (fast path disabled)
+    if (mode == 0 && needFull[blockIdx.x]) return;
+    if (mode == 1 && !needFull[blockIdx.x]) return;
     __shared__ unsigned long long fin[512];
+    __shared__ unsigned long long fin2[512];
     __shared__ unsigned hist[256];
     __shared__ unsigned sh[40];
     __shared__ int ccount[256];
@@ -380,6 +549,11 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
     }
     __syncthreads();
     const unsigned total = sh[8];
+    if (mode == 0 && total < (unsigned)D && tauKey[n] != 0u) {
+        // fewer survivors than outputs while candidates below tau were skipped: redo this image with the full path
+        if (tid == 0) needFull[n] = 1;
+        return;
+    }
     unsigned T = 0, quota = 0;
     if (total > (unsigned)D) {
         unsigned prefix = 0, need = D;
@@ -425,9 +599,8 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
             base_eq += t1;
         }
     }
-    for (int i = M + tid; i < 512; i += 1024) fin[i] = 0ull;
     __syncthreads();
-    bitonic_sort_desc<1024>(fin, 512);
+    rank_sort_desc<1024>(fin, fin2, M);
     float sx = 1.f, sy = 1.f;
     if (scale_xy) { sx = scale_xy[2 * n]; sy = scale_xy[2 * n + 1]; }
     for (int i = tid; i < D; i += 1024) {
@@ -463,7 +636,7 @@ size_t p2_lds_bytes(int A) {
 
 template <int NW>
 int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, float* keptScore, int* keptAnchor, int* keptCount,
-              hipStream_t s) {
+              const int* needFull, hipStream_t s) {
     const size_t lds = p2_lds_bytes<NW>(a.A);
     if (lds > 160 * 1024) {
         dn_set_error("postprocess: %d anchors need %zu B of LDS (> 160 KiB)", a.A, lds);
@@ -476,7 +649,15 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
         attr_set = true;
     }
     hipLaunchKernelGGL((select_nms_kernel<NW>), dim3(a.K - 1, a.n), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, g_pp_stamps);
+                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps);
+    return DN_OK;
+}
+
+template <int NW>
+int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes, const unsigned* tauKey, int* needFull,
+                   float* keptScore, int* keptAnchor, int* keptCount, hipStream_t s) {
+    hipLaunchKernelGGL((select_nms_fast_kernel<NW>), dim3(a.K - 1, a.n), dim3(256), 0, s, scoresT, boxes, a.A, a.K - 1,
+                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount);
     return DN_OK;
 }
 
@@ -486,7 +667,13 @@ size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
     (void)dets;
     const size_t Km1 = K - 1;
     return align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) +
-           align256((size_t)n * Km1 * 4);
+           align256((size_t)n * Km1 * 4) + align256((size_t)n * HBINS * 4 + (size_t)n * 8);
+}
+
+// DN_PP_FAST=0 disables the cut-off fast path (A/B and tests of the full path); DN_PP_WANT overrides the multiple of D.
+static int pp_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
@@ -510,24 +697,43 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     int* keptAnchor = reinterpret_cast<int*>(p);
     p += align256((size_t)a.n * Km1 * a.topk * 4);
     int* keptCount = reinterpret_cast<int*>(p);
+    p += align256((size_t)a.n * Km1 * 4);
+    unsigned* ghist = reinterpret_cast<unsigned*>(p);                      // [n][HBINS], then tauKey[n], needFull[n]
+    unsigned* tauKey = ghist + (size_t)a.n * HBINS;
+    int* needFull = reinterpret_cast<int*>(tauKey + a.n);
+
+    static const int fast = pp_env("DN_PP_FAST", 1);
+    static const int want_mult = pp_env("DN_PP_WANT", 8);
+    long long* labels = reinterpret_cast<long long*>(a.labels);
+    const int nw = (a.topk + 63) / 64;
 
     if (ev) (void)hipEventRecord(ev[0], s);
-    const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float);
+    DN_HIP_CHECK(hipMemsetAsync(ghist, 0, (size_t)a.n * HBINS * 4 + (size_t)a.n * 8, s));
+    const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + HBINS * sizeof(unsigned);
     hipLaunchKernelGGL(softmax_decode_kernel, dim3(dn_cdiv(a.A, 64), a.n), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h);
+                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, ghist);
     if (ev) (void)hipEventRecord(ev[1], s);
-    int rc;
-    const int nw = (a.topk + 63) / 64;
-    if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
-    else if (nw <= 2) rc = launch_p2<2>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
-    else if (nw <= 4) rc = launch_p2<4>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
-    else if (nw <= 5) rc = launch_p2<5>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
-    else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, s);
+    int rc = DN_OK;
+    if (fast) {
+        hipLaunchKernelGGL(tau_kernel, dim3(a.n), dim3(256), 0, s, ghist, (unsigned)(want_mult * a.dets), tauKey, needFull);
+        if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
+        else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
+        else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
+        else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
+        else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
+        hipLaunchKernelGGL(merge_kernel, dim3(a.n), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull);
+    }
+    const int* flag = fast ? needFull : nullptr;
+    if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
+    else if (nw <= 2) rc = launch_p2<2>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
+    else if (nw <= 4) rc = launch_p2<4>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
+    else if (nw <= 5) rc = launch_p2<5>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
+    else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
     if (rc != DN_OK) return rc;
     if (ev) (void)hipEventRecord(ev[2], s);
     hipLaunchKernelGGL(merge_kernel, dim3(a.n), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, reinterpret_cast<long long*>(a.labels), a.counts,
-                       a.kept_anchor);
+                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull);
     if (ev) (void)hipEventRecord(ev[3], s);
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;
