@@ -107,10 +107,10 @@ template <int K, int S, int TW>
 int dw_blocks(const DwArgs& a) { return dn_cdiv((long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8), 256); }
 
 // ---- SE FCs: (sum of partials)/pixels -> fc1(+b) -> ReLU -> fc2(+b) -> Hardsigmoid   (mobilenetv3.py:31-36) ------------
-// One 512-thread workgroup per image; every dot product is spread over the 64 lanes of a wave (coalesced weight rows,
+// One 1024-thread workgroup per image; every dot product is spread over the 64 lanes of a wave (coalesced weight rows,
 // shuffle reduction) instead of one serial loop per thread: the serial form was latency-bound at ~130 us per launch.
 // w1: [squeeze][c] (fc1.weight), w2: [c][squeeze] (fc2.weight), both in the reference's native layout.
-__global__ __launch_bounds__(512) void se_fc_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ w1,
+__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ w1,
                                                    const float* __restrict__ b1, const float* __restrict__ w2,
                                                    const float* __restrict__ b2, float* __restrict__ scale,
                                                    int c, int sq, float inv_pixels) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void se_fc_kernel(const float* __restrict__ pa
     float* z = sh + c;
     const int n = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < c; i += 512) {
+    for (int i = threadIdx.x; i < c; i += 1024) {
         const float* p = partial + (size_t)n * nblk * c + i;
         float t = 0.f;
         for (int b0 = 0; b0 < nblk; b0 += 16) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void se_fc_kernel(const float* __restrict__ pa
     }
     __syncthreads();
     // fc1: 4 outputs per wave per batch
-    for (int j0 = wave * 4; j0 < sq; j0 += 32) {
+    for (int j0 = wave * 4; j0 < sq; j0 += 64) {
         float wv[4][MAXC64];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void se_fc_kernel(const float* __restrict__ pa
     }
     __syncthreads();
     // fc2: 16 outputs per wave per batch
-    for (int i0 = wave * 16; i0 < c; i0 += 128) {
+    for (int i0 = wave * 16; i0 < c; i0 += 256) {
         float wv[16][MAXS64];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
@@ -268,7 +268,7 @@ int depthwise_pool_blocks(const DwArgs& a) {
 int launch_se_fc(const float* partial, int nblk, const float* w1, const float* b1, const float* w2, const float* b2, float* scale,
                  int n, int c, int squeeze, int pool_pixels, hipStream_t s) {
     DN_REQUIRE(c <= 1024 && squeeze <= 256, "se: c=%d squeeze=%d exceed the kernel's register tiles", c, squeeze);
-    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(512), (size_t)(c + squeeze) * sizeof(float), s, partial, nblk, w1, b1, w2, b2,
+    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(1024), (size_t)(c + squeeze) * sizeof(float), s, partial, nblk, w1, b1, w2, b2,
                        scale, c, squeeze, 1.0f / (float)pool_pixels);
     return DN_OK;
 }

@@ -1,6 +1,7 @@
 // C-ABI implementation: plan construction, workspace layout, launch sequence, hipGraph caching, profiling hook.
 // Host-side only (no kernels here). See include/demonet_hip.h for the contract.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -53,6 +54,14 @@ struct dn_plan {
     bool graph_mode = true;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t capture_stream = nullptr;   // capture never happens on the caller's stream (may be the null stream)
+    // head chains (dw -> 1x1 per level, class and box) are independent of the rest of the backbone: they run on two side
+    // streams forked at the event of their feature map and joined before the post-process (parallel graph branches)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_feat[8] = {}, ev_join[2] = {};
+    std::vector<int> op_stream;             // 0 main, 1 class-head chain, 2 box-head chain
+    std::vector<int> op_wait_level;         // head-chain op reading a feature map: its level, else -1
+    std::vector<int> op_feat_level;         // main op producing a feature map: its level, else -1
+    bool multi_stream = true;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -132,6 +141,24 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             p->pool_blocks[o.pool] = depthwise_pool_blocks(a);
         }
     }
+    // stream assignment
+    p->op_stream.assign(desc->n_ops, 0);
+    p->op_wait_level.assign(desc->n_ops, -1);
+    p->op_feat_level.assign(desc->n_ops, -1);
+    auto level_of = [&](int tensor) { for (int l = 0; l < desc->n_levels; ++l) if (desc->level_tensor[l] == tensor) return l; return -1; };
+    for (int i = 0; i < desc->n_ops; ++i) {
+        const dn_op_desc& o = p->ops[i];
+        if (o.head) p->op_stream[i] = o.head;
+        else
+            for (int j = 0; j < desc->n_ops; ++j)
+                if (p->ops[j].head && p->ops[j].in == o.out && level_of(o.out) < 0) p->op_stream[i] = p->ops[j].head;
+    }
+    for (int i = 0; i < desc->n_ops; ++i) {
+        const dn_op_desc& o = p->ops[i];
+        if (p->op_stream[i]) p->op_wait_level[i] = level_of(o.in);
+        else p->op_feat_level[i] = level_of(o.out);
+    }
+    p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : true;
     // anchor offsets per level
     int acc = 0;
     for (int l = 0; l < desc->n_levels; ++l) {
@@ -153,6 +180,13 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (p->anchors_dev) (void)hipFree(p->anchors_dev);
         return fail(DN_E_HIP);
     }
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking);
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_feat[i], hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        dn_set_error("dn_create: stream/event creation failed: %s", hipGetErrorString(e));
+        return fail(DN_E_HIP);
+    }
     p->weight_bytes = weight_bytes;
     p->d.anchors = nullptr;
     *out = p;
@@ -163,6 +197,9 @@ extern "C" void dn_destroy(dn_plan* p) {
     if (!p) return;
     for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
+    for (int i = 0; i < 2; ++i) if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
+    for (int i = 0; i < 8; ++i) if (p->ev_feat[i]) (void)hipEventDestroy(p->ev_feat[i]);
+    for (int i = 0; i < 2; ++i) if (p->ev_join[i]) (void)hipEventDestroy(p->ev_join[i]);
     for (auto ev : p->events) (void)hipEventDestroy(ev);
     if (p->weights_dev) (void)hipFree(p->weights_dev);
     if (p->anchors_dev) (void)hipFree(p->anchors_dev);
@@ -202,10 +239,20 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     float* logits = reinterpret_cast<float*>(ws + L.logits_off);
     float* reg = reinterpret_cast<float*>(ws + L.reg_off);
     int ev = 0;
+    hipStream_t const main_stream = s;
+    const bool ms = p->multi_stream && !record;
+    bool side_used[2] = {false, false};
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const dn_op_desc& o = p->ops[i];
         const dn_tensor_desc& ti = p->tensors[o.in];
         const dn_tensor_desc& to = p->tensors[o.out];
+        s = main_stream;
+        if (ms && p->op_stream[i]) {
+            const int sid = p->op_stream[i] - 1;
+            s = p->side[sid];
+            side_used[sid] = true;
+            if (p->op_wait_level[i] >= 0) DN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_feat[p->op_wait_level[i]], 0));
+        }
         if (record) (void)hipEventRecord(p->events[ev++], s);
         int rc = DN_OK;
         const unsigned char* W = p->weights_dev;
@@ -294,7 +341,14 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 break;
         }
         if (rc != DN_OK) return rc;
+        if (ms && p->op_feat_level[i] >= 0) DN_HIP_CHECK(hipEventRecord(p->ev_feat[p->op_feat_level[i]], main_stream));
     }
+    s = main_stream;
+    for (int k = 0; k < 2; ++k)
+        if (side_used[k]) {
+            DN_HIP_CHECK(hipEventRecord(p->ev_join[k], p->side[k]));
+            DN_HIP_CHECK(hipStreamWaitEvent(main_stream, p->ev_join[k], 0));
+        }
     if (!heads_only) {
         PostArgs a;
         a.logits = logits; a.reg = reg; a.anchors = p->anchors_dev;

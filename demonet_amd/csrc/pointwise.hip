@@ -11,27 +11,31 @@
 // Tiles are staged through LDS (rows padded to 80 B: conflict-free ds_read_b128), register-staged double
 // buffering with one barrier per 32-deep K step. These GEMMs are HBM-bound (AI 13..300 FLOP/B):
 // the design goal is to read x once, write out once and keep the weight tile L2-resident.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 32;          // K depth per LDS stage (2 MFMA k-steps)
-constexpr int LDS_ROW = 40;     // halfs per LDS row: 32 data + 8 pad  (80 B = 5 x 16 B -> odd slot stride)
 
 // CONV = true: implicit GEMM for a dense kxk convolution (VGG path, SSDHead 3x3 heads; ssd_vgg16.py, generalized_ssd.py:77-92):
 // K runs over (ky, kx, cin) with the weight stored [cout][ky][kx][cin]; each 32-deep K stage lies inside one tap
 // (cin % 32 == 0), so the pixel tile of a stage is the NHWC rows of the tap-shifted input pixels (zeros outside).
-template <int BP, int BC, int WP, int WC, bool CONV>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
+    constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
+    constexpr int CPR = BK / 8;         // 16-B chunks per row per stage
+    constexpr int CSH = (BK == 32) ? 2 : 3;
     constexpr int TP = BP / WP / 32;    // 32-pixel MFMA tiles per wave
     constexpr int TC = BC / WC / 32;    // 32-channel MFMA tiles per wave
-    constexpr int NX = BP * 4 / 256;    // 16-B chunks of the pixel tile per thread per stage
-    constexpr int NW = BC * 4 / 256;    // 16-B chunks of the weight tile per thread per stage
+    constexpr int NX = BP * CPR / 256;  // 16-B chunks of the pixel tile per thread per stage
+    constexpr int NW = BC * CPR / 256;  // 16-B chunks of the weight tile per thread per stage
     static_assert(NX >= 1 && NW >= 0, "tile too small");
     constexpr int NWc = NW > 0 ? NW : 1;
-    __shared__ __attribute__((aligned(16))) half_t lds[2][(BP + BC) * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) float bsh[BC];
+    extern __shared__ __attribute__((aligned(16))) half_t lds_dyn[];      // [2][(BP + BC) * LDS_ROW] halfs, then bias[BC] floats
+    half_t (*lds)[(BP + BC) * LDS_ROW] = reinterpret_cast<half_t (*)[(BP + BC) * LDS_ROW]>(lds_dyn);
+    float* bsh = reinterpret_cast<float*>(lds_dyn + 2 * (BP + BC) * LDS_ROW);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     if constexpr (CONV) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int m = m0 + ((tid + 256 * i) >> 2);
+            const int m = m0 + ((tid + 256 * i) >> CSH);
             const int img = m / a.hw, rem = m - img * a.hw;
             const int oy = rem / a.cv_wo, ox = rem - oy * a.cv_wo;
             cvn[i] = img;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + 256 * i;
-            const int row = c >> 2, q = c & 3;
+            const int row = c >> CSH, q = c & (CPR - 1);
             const int m = m0 + row, k = k0 + q * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
             if constexpr (CONV) {
@@ -101,18 +105,18 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int c = tid + 256 * i;
-                const int row = c >> 2, q = c & 3;
+                const int row = c >> CSH, q = c & (CPR - 1);
                 const int n = n0 + row, k = k0 + q * 8;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
                 sw[i] = v;
             }
         } else {
-            // BC*4 < 256: only the first BC*4 threads carry a weight chunk
-            const int row = tid >> 2, q = tid & 3;
+            // BC*CPR < 256: only the first BC*CPR threads carry a weight chunk
+            const int row = tid >> CSH, q = tid & (CPR - 1);
             const int n = n0 + row, k = k0 + q * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (tid < BC * 4 && n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
+            if (tid < BC * CPR && n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
             sw[0] = v;
         }
     };
@@ -120,16 +124,16 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + 256 * i;
-            *reinterpret_cast<uint4*>(&lds[b][(c >> 2) * LDS_ROW + (c & 3) * 8]) = sx[i];
+            *reinterpret_cast<uint4*>(&lds[b][(c >> CSH) * LDS_ROW + (c & (CPR - 1)) * 8]) = sx[i];
         }
         if constexpr (NW > 0) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int c = tid + 256 * i;
-                *reinterpret_cast<uint4*>(&lds[b][(BP + (c >> 2)) * LDS_ROW + (c & 3) * 8]) = sw[i];
+                *reinterpret_cast<uint4*>(&lds[b][(BP + (c >> CSH)) * LDS_ROW + (c & (CPR - 1)) * 8]) = sw[i];
             }
         } else {
-            if (tid < BC * 4) *reinterpret_cast<uint4*>(&lds[b][(BP + (tid >> 2)) * LDS_ROW + (tid & 3) * 8]) = sw[0];
+            if (tid < BC * CPR) *reinterpret_cast<uint4*>(&lds[b][(BP + (tid >> CSH)) * LDS_ROW + (tid & (CPR - 1)) * 8]) = sw[0];
         }
     };
 
@@ -141,9 +145,9 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     for (int kt = 0; kt < KT; ++kt) {
         const int b = kt & 1;
         if (kt + 1 < KT) load_stage((kt + 1) * BK);
-        const int ksteps = (K - kt * BK > 16) ? 2 : 1;
+        const int ksteps = min(BK / 16, (K - kt * BK + 15) >> 4);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             if (ks < ksteps) {
                 half8 xf[TP], wf[TC];
 #pragma unroll
@@ -231,10 +235,218 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// X-stationary variant for the mid/small layers (M <= ~130k rows, any K <= 1024, any N).
+// The tiled kernel above pays one exposed memory latency per 32-deep K stage; with K up to 672 and few workgroups that
+// is 20+ us of pure latency. Here a workgroup stages its whole [BP][K] pixel strip in LDS once (every load in flight
+// together), then each wave walks its own 32-channel tiles streaming the weight rows straight from L2 into MFMA
+// A-fragments (16 B per lane, 256 contiguous bytes per weight row per 8 k-steps), double-buffered so the next chunk's
+// loads fly under the current chunk's MFMAs. No barrier after the staging one.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BP>
+__global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a) {
+    constexpr int TP = BP / 32;
+    constexpr int KC = 8;                       // k-steps (of 16) per weight chunk
+    extern __shared__ __attribute__((aligned(16))) half_t xs[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int M = a.m, K = a.cin, NC = a.cout;
+    const int KS = (K + 15) >> 4;
+    const int KP = KS * 16 + 8;                 // row stride (halfs): odd number of 16-B slots -> conflict-free b128 reads
+    const int m0 = blockIdx.x * BP;
+
+    // ---- stage the pixel strip (zero-filled beyond M / K), 8 independent 16-B loads per thread per batch
+    const int CPR = KS * 2;                     // 16-B chunks per row (incl. zero padding up to KS*16)
+    const int total = BP * CPR;
+    for (int c0 = 0; c0 < total; c0 += 256 * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 256 + tid;
+            const int row = c / CPR, q = c - row * CPR;
+            const int m = m0 + row, k = q * 8;
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (c < total && m < M && k < K) t = *reinterpret_cast<const uint4*>(a.x + (size_t)m * K + k);
+            v[u] = t;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 256 + tid;
+            if (c < total) {
+                const int row = c / CPR, q = c - row * CPR;
+                uint4 t = v[u];
+                if (a.se) {
+                    const int m = m0 + row, k = q * 8;
+                    if (m < M && k < K) {
+                        const float* sp = a.se + (size_t)(m / a.hw) * K + k;
+                        half8 hv = *reinterpret_cast<half8*>(&t);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) hv[e] = (half_t)((float)hv[e] * sp[e]);
+                        t = *reinterpret_cast<uint4*>(&hv);
+                    }
+                }
+                *reinterpret_cast<uint4*>(&xs[row * KP + q * 8]) = t;
+            }
+        }
+    }
+    __syncthreads();
+
+    size_t obase[TP];
+    bool mvalid[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int m = m0 + j * 32 + r;
+        mvalid[j] = m < M;
+        if (a.out_fp32) {
+            const int img = m / a.hw;
+            obase[j] = (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m - img * a.hw) * NC;
+        } else {
+            obase[j] = (size_t)m * NC;
+        }
+    }
+
+    auto load_w = [&](half8 (&wf)[KC], int nt, int ks0) {
+        const int n = nt * 32 + r;
+        const half_t* wr = a.w + (size_t)n * K + hh * 8;
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            const int k = (ks0 + u) * 16 + hh * 8;
+            half8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (n < NC && k < K) t = *reinterpret_cast<const half8*>(wr + (ks0 + u) * 16);
+            wf[u] = t;
+        }
+    };
+
+    const int NT = (NC + 31) >> 5;
+    half8 wa[KC], wb[KC];
+    if (wave < NT) load_w(wa, wave, 0);
+    for (int nt = wave; nt < NT; nt += 4) {
+        // bias / residual of this channel tile: issued now, consumed after the K loop
+        float4 bv[4];
+        half4 resv[TP][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = nt * 32 + 8 * g + 4 * hh;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + 3 < NC) t = *reinterpret_cast<const float4*>(a.bias + c0);
+            else {
+                if (c0 < NC) t.x = a.bias[c0];
+                if (c0 + 1 < NC) t.y = a.bias[c0 + 1];
+                if (c0 + 2 < NC) t.z = a.bias[c0 + 2];
+            }
+            bv[g] = t;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                half4 rv = {0, 0, 0, 0};
+                if (a.residual && mvalid[j] && c0 < NC) rv = *reinterpret_cast<const half4*>(a.residual + obase[j] + c0);
+                resv[j][g] = rv;
+            }
+        }
+        floatx16 acc[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+        for (int ks0 = 0; ks0 < KS; ks0 += 2 * KC) {
+            // chunk A is loaded; prefetch chunk B (next KC k-steps, or the next tile's first chunk)
+            const bool moreB = ks0 + KC < KS;
+            if (moreB) load_w(wb, nt, ks0 + KC);
+            else if (nt + 4 < NT) load_w(wb, nt + 4, 0);
+#pragma unroll
+            for (int u = 0; u < KC; ++u) {
+                if (ks0 + u < KS) {
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        const half8 xf = *reinterpret_cast<const half8*>(&xs[(j * 32 + r) * KP + (ks0 + u) * 16 + hh * 8]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[u], xf, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            if (moreB) {
+                const bool moreA = ks0 + 2 * KC < KS;
+                if (moreA) load_w(wa, nt, ks0 + 2 * KC);
+                else if (nt + 4 < NT) load_w(wa, nt + 4, 0);
+#pragma unroll
+                for (int u = 0; u < KC; ++u) {
+                    if (ks0 + KC + u < KS) {
+#pragma unroll
+                        for (int j = 0; j < TP; ++j) {
+                            const half8 xf = *reinterpret_cast<const half8*>(&xs[(j * 32 + r) * KP + (ks0 + KC + u) * 16 + hh * 8]);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u], xf, acc[j], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                // the prefetched chunk (next tile's first) sits in wb: make it the A buffer of the next tile
+#pragma unroll
+                for (int u = 0; u < KC; ++u) wa[u] = wb[u];
+            }
+        }
+        // epilogue
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            if (!mvalid[j]) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = nt * 32 + 8 * g + 4 * hh;
+                if (c0 >= NC) continue;
+                float v[4] = {acc[j][4 * g + 0] + bv[g].x, acc[j][4 * g + 1] + bv[g].y, acc[j][4 * g + 2] + bv[g].z,
+                              acc[j][4 * g + 3] + bv[g].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = dn_act(v[e], a.act);
+                if (a.out_fp32) {
+                    float* o = reinterpret_cast<float*>(a.out) + obase[j] + c0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < NC) o[e] = v[e];
+                } else {
+                    if (a.residual) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)resv[j][g][e];
+                    }
+                    half4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
+                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(a.out) + obase[j] + c0) = hv;
+                }
+            }
+        }
+    }
+}
+
+template <int BP>
+int launch_xs(const PwArgs& a, hipStream_t s) {
+    const int KS = (a.cin + 15) / 16;
+    const size_t lds = (size_t)BP * (KS * 16 + 8) * sizeof(half_t);
+    static bool attr = false;
+    if (!attr) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_xs_kernel<BP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((pw_xs_kernel<BP>), dim3(dn_cdiv(a.m, BP)), dim3(256), lds, s, a);
+    return DN_OK;
+}
+
 template <int BP, int BC, int WP, int WC, bool CONV>
 int launch_cfg(const PwArgs& a, hipStream_t s) {
     dim3 grid(dn_cdiv(a.m, BP), dn_cdiv(a.cout, BC));
-    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV>), grid, dim3(256), 0, s, a);
+    static const int bk64 = getenv("DN_PW_BK64") ? atoi(getenv("DN_PW_BK64")) : 0;
+    // BK=64 halves the number of K stages but doubles LDS per workgroup; measured: no net win (occupancy), off by default
+    if (bk64 && a.cin >= 64 && (!CONV || a.cv_cin % 64 == 0)) {
+        constexpr size_t lds = (size_t)2 * (BP + BC) * 72 * sizeof(half_t) + BC * sizeof(float);
+        static bool attr = false;
+        if (!attr && lds > 64 * 1024) {
+            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, 64>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        attr = true;
+        hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, 64>), grid, dim3(256), lds, s, a);
+        return DN_OK;
+    }
+    constexpr size_t lds32 = (size_t)2 * (BP + BC) * 40 * sizeof(half_t) + BC * sizeof(float);
+    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, 32>), grid, dim3(256), lds32, s, a);
     return DN_OK;
 }
 
@@ -265,6 +477,11 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.cin % 8 == 0, "pointwise: cin=%d must be a multiple of 8", a.cin);
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
+    static const int xs_mode = getenv("DN_PW_XS") ? atoi(getenv("DN_PW_XS")) : 1;
+    if (xs_mode && a.cin <= 1024 && a.cin >= 64 && a.cout <= 160 && a.m <= 8192 && !(a.act >> 8)) {
+        // measured: the strip kernel wins only where the tiled kernel cannot fill the chip (M <= ~8k rows)
+        return launch_xs<32>(a, s);
+    }
     return launch_select<false>(a, s);
 }
 

@@ -1,0 +1,114 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads, exports every symbol include/demonet_hip.h declares, the ctypes
+mirrors match the C structs, and the host-side lowering (BN fold, weight packing, graph IR) is self-consistent.
+No compute calls: there is no GPU here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from demonet_amd import _lib, models, spec, synth
+from demonet_amd.plan import LoweredModel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "demonet_hip.h")
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"DN_API\s+[\w\s\*]+?\b(dn_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from demonet_amd import build
+        build.build(verbose=False)
+    L = C.CDLL(_lib.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in demonet_hip.h but not exported"
+    assert set(syms) == set(_lib.EXPORTS), "ctypes binding and header disagree"
+    L.dn_abi_version.restype = C.c_int
+    assert L.dn_abi_version() == _lib.DN_ABI_VERSION
+
+
+def test_struct_layout_matches_c(tmp_path):
+    """sizeof/offsetof of the ctypes mirrors against the real header (compiled with gcc)."""
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "demonet_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dn_tensor_desc), sizeof(dn_op_desc), '
+                   'sizeof(dn_model_desc), offsetof(dn_op_desc, w_off), offsetof(dn_model_desc, anchors), '
+                   'offsetof(dn_model_desc, score_thresh));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    a = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert a[0] == C.sizeof(_lib.TensorDesc)
+    assert a[1] == C.sizeof(_lib.OpDesc)
+    assert a[2] == C.sizeof(_lib.ModelDesc)
+    assert a[3] == _lib.OpDesc.w_off.offset
+    assert a[4] == _lib.ModelDesc.anchors.offset
+    assert a[5] == _lib.ModelDesc.score_thresh.offset
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdemonet_hip.so")
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.lib()
+
+
+@pytest.mark.parametrize("name,ncls,nparams", [("ssdlite320_mobilenet_v3_large", 91, 476)])
+def test_state_dict_keys_and_lowering(name, ncls, nparams):
+    m = getattr(models, name)(num_classes=ncls)
+    sd = m.state_dict()
+    assert len(sd) == nparams                                   # 476 entries for SSDLite-V3
+    assert "backbone.features.0.0.0.weight" in sd and "head.classification_head.module_list.0.1.bias" in sd
+    models.load_synthetic(m, 0)
+    lm = LoweredModel(m.graph, m.state_dict())
+    assert lm.desc.num_anchors == 3234 and lm.desc.n_ops == len(m.graph.nodes)
+    # BN fold check on the first pointwise op against an explicit fp64 computation
+    nd = next(n for n in m.graph.nodes if n.op == "pw")
+    o = next(o for o, n in zip(lm.ops, m.graph.nodes) if n is nd)
+    w = np.frombuffer(lm.blob, dtype=np.float16, count=nd.cout * nd.cin, offset=o.w_off).reshape(nd.cout, nd.cin)
+    s = synth.state_dict(m.graph, 0)
+    g, b = s[nd.bn_key + ".weight"].astype(np.float64), s[nd.bn_key + ".bias"].astype(np.float64)
+    mu, var = s[nd.bn_key + ".running_mean"].astype(np.float64), s[nd.bn_key + ".running_var"].astype(np.float64)
+    sc = g / np.sqrt(var + nd.bn_eps)
+    ref = s[nd.conv_key + ".weight"].reshape(nd.cout, nd.cin).astype(np.float64) * sc[:, None]
+    np.testing.assert_allclose(w.astype(np.float64), ref, rtol=1e-3, atol=1e-4)
+    bias = np.frombuffer(lm.blob, dtype=np.float32, count=nd.cout, offset=o.b_off)
+    np.testing.assert_allclose(bias, b - mu * sc, rtol=1e-6, atol=1e-6)
+
+
+def test_factory_api_mirrors_reference():
+    with pytest.warns(UserWarning):
+        m = models.ssdlite320_mobilenet_v3_large(num_classes=5, size=(300, 300), score_thresh=0.3)     # ssd_mobilenetv3.py:183-184
+    assert m.score_thresh == 0.3 and m.nms_thresh == 0.55 and m.detections_per_img == 300 and m.topk_candidates == 300
+    assert m.graph.num_classes == 5 and not m.training
+    with pytest.raises(RuntimeError):
+        models.ssdlite320_mobilenet_v3_large(pretrained=True)
+    v = models.ssd300_vgg16(num_classes=91)
+    assert v.graph.num_anchors() == 8732 and v.score_thresh == 0.01 and v.topk_candidates == 400
+    h = models.ssd_lite_mobilenet_v2(num_classes=21)
+    assert h.score_thresh == 0.5 and h.graph.num_anchors() == 3234
+    assert models.__dict__["ssdlite320_mobilenet_v3_large"] is models.ssdlite320_mobilenet_v3_large   # train.py:154 lookup
+    m.train()
+    with pytest.raises(ValueError):
+        m([torch.zeros(3, 8, 8)])
+    m.eval()
+    with pytest.raises(RuntimeError):
+        m([torch.zeros(3, 320, 320)])          # CPU input: the product path has no fallback
+
+
+def test_graph_geometry_matches_survey():
+    g = spec.ssdlite320_mobilenet_v3_large_graph(91)
+    assert [(g.t(f).c, g.t(f).h) for f in g.features] == [(672, 20), (480, 10), (512, 5), (256, 3), (256, 2), (128, 1)]
+    macs = sum(g.t(n.out).h * g.t(n.out).w * n.cout * (n.cin if n.op == "pw" else n.k * n.k * (3 if n.op == "stem" else 1))
+               for n in g.nodes if n.op in ("pw", "dw", "stem"))
+    assert abs(macs / 1e6 - 583.17) < 1.0                       # 583.17 MMAC / image
+    v = spec.ssd512_vgg16_graph(91)
+    assert v.num_anchors() == 24732 and [g_.h for g_ in (v.t(f) for f in v.features)] == [64, 32, 16, 8, 6, 4, 1]

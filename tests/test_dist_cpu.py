@@ -1,0 +1,46 @@
+"""CPU test of the N>1 path (gloo, world_size 2): image sharding + fixed-shape gather of detections."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from demonet_amd.dist import gather_detections, pack_detections, shard_range, unpack_detections
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, D = 3, 5
+    g = torch.Generator().manual_seed(100 + rank)
+    boxes = torch.rand(B, D, 4, generator=g)
+    scores = torch.rand(B, D, generator=g)
+    labels = torch.randint(1, 91, (B, D), generator=g)
+    counts = torch.tensor([D, 2, 0], dtype=torch.int32) if rank == 0 else torch.tensor([1, D, 3], dtype=torch.int32)
+    gp, gc = gather_detections(pack_detections(boxes, scores, labels), counts)
+    assert gp.shape == (world * B, D, 6) and gc.tolist() == [D, 2, 0, 1, D, 3]
+    mine = unpack_detections(gp[rank * B:(rank + 1) * B], gc[rank * B:(rank + 1) * B])
+    for i in range(B):
+        c = int(counts[i])
+        assert torch.equal(mine[i]["boxes"], boxes[i, :c]) and torch.equal(mine[i]["labels"], labels[i, :c])
+        assert torch.equal(mine[i]["scores"], scores[i, :c])
+    ret[rank] = float(gp.sum())
+    dist.destroy_process_group()
+
+
+def test_gather_detections_gloo_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2 and abs(ret[0] - ret[1]) < 1e-6          # both ranks hold the same global batch
+
+
+def test_shard_range():
+    assert [shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]       # 32 images per GPU
+    assert shard_range(10, 3, 4) == (9, 10) and shard_range(2, 3, 4) == (2, 2)     # ragged / empty shards

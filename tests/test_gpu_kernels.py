@@ -37,6 +37,11 @@ PW_CASES = [
     (50, 128, 24, 25, 0, False, False, True),
     (9, 256, 128, 9, 2, False, False, False),
     (1, 64, 128, 1, 2, False, False, False),
+    (16640, 200, 80, 16640, 0, True, False, False),   # BP=64 strip kernel, K not a multiple of 16
+    (25600, 112, 672, 400, 3, False, False, False),
+    (19200, 480, 112, 400, 0, False, True, False),    # SE scale, 48 images
+    (200000, 24, 72, 200000, 1, False, False, False), # big-M tiled kernel
+    (150000, 72, 24, 150000, 0, True, False, False),
 ]
 
 
