@@ -188,6 +188,11 @@ def main():
         buf = (C.c_float * nseg)()
         runs = _lib.check(L.dn_profile_end(h, buf, nseg))
         costs = op_costs(g, B)
+        grp = (C.c_int32 * len(g.nodes))()
+        _lib.check(L.dn_op_groups(h, grp, len(g.nodes)))
+        for i in range(len(g.nodes)):
+            if grp[i] >= 0:
+                costs[i]["kernel"] = "mega_kernel (per-image tail runs)"
         agg = {}
         for c, ms in zip(costs, buf):
             a = agg.setdefault(c["kernel"], dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))

@@ -54,6 +54,7 @@ struct PwArgs {
     int m, cin, cout, hw, act, out_fp32;
     long out_img_stride;    // elements between images in `out`
     long out_base;          // element offset of image 0 (head ops: level offset * columns)
+    long long* stamps = nullptr;   // dev-only phase stamps
 };
 int launch_pointwise(const PwArgs& a, hipStream_t s);
 
@@ -89,6 +90,30 @@ int launch_maxpool(const half_t* x, half_t* out, int n, int h, int w, int c, int
 int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels, int c, hipStream_t s);
 // bilinear (align_corners=False) resize of NCHW fp32 planes; also writes scale_xy[n][2] = (w/ow, h/oh) in fp32
 int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s);
+
+// fused inverted-residual block (fused.hip): [expand 1x1] -> depthwise -> [project 1x1 (+residual)]
+struct FusedArgs {
+    const half_t* x; half_t* out; float* pool;
+    const half_t* w1; const float* b1;     // expand [cexp][cin] (null: none)
+    const half_t* wd; const float* bd;     // depthwise [k*k][cexp]
+    const half_t* w3; const float* b3;     // project [cout][cexp] (null: stop after the depthwise stage)
+    int n, H, W, Ho, Wo, cin, cexp, cout, k, stride, pad, act1, act2, act3, has_res;
+    int ch, xw;                            // filled by the launcher
+    long long* stamps = nullptr;           // dev-only
+};
+int launch_fused(const FusedArgs& a, hipStream_t s);
+int fused_tiles_per_image(int Ho, int Wo);
+void fused_tile(int Ho, int Wo, int* th, int* tw);
+
+// one op of a per-image "tail" kernel run (mega.hip); offsets are bytes from the workspace / weight-blob base
+struct MegaOp {
+    int type, cin, cout, k, stride, pad, act;
+    int hin, win, hout, wout;
+    int out_fp32, pool, pool_rows, pool_pixels, squeeze, pad0;
+    long x_off, x_stride, out_off, out_stride, res_off, res_stride, se_off, se_stride, pool_off, pool_stride;
+    long w_off, b_off, w2_off, b2_off;
+};
+int launch_mega(const MegaOp* ops_dev, int first, int count, int n, unsigned char* ws, const unsigned char* wts, hipStream_t s);
 
 struct PostArgs {
     const float* logits; const float* reg; const float* anchors;

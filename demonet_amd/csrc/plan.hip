@@ -31,6 +31,8 @@ struct Layout {
     std::vector<size_t> toff;       // per tensor byte offset in workspace (SIZE_MAX: not materialised)
     std::vector<size_t> tbytes;
     size_t resized_off = 0, logits_off = 0, reg_off = 0, scale_off = 0, post_off = 0, post_bytes = 0, total = 0;
+    MegaOp* mega_dev = nullptr;     // device copy of the tail-kernel op table for this batch size
+    std::vector<int> mega_index;    // op -> index in the table (-1: not in a group)
 };
 
 struct GraphKey {
@@ -61,7 +63,15 @@ struct dn_plan {
     std::vector<int> op_stream;             // 0 main, 1 class-head chain, 2 box-head chain
     std::vector<int> op_wait_level;         // head-chain op reading a feature map: its level, else -1
     std::vector<int> op_feat_level;         // main op producing a feature map: its level, else -1
-    bool multi_stream = true;
+    bool multi_stream = false;
+    // runs of consecutive small ops executed by one per-image workgroup (mega.hip)
+    std::vector<int> op_group;              // group id per op or -1
+    std::vector<int> group_first, group_count;
+    std::vector<int> se_inplace_pw;         // SE op -> index of the in-group projection whose input it rescales in place, else -1
+    bool mega_enabled = true;
+    // fused inverted-residual groups (fused.hip): at the first op of a group fused_len = 2 or 3, fused_kind bit0 = has
+    // expand, bit1 = has project
+    std::vector<int> fused_len, fused_kind;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -101,6 +111,51 @@ static const Layout& get_layout(dn_plan* p, int n) {
     L.post_bytes = postprocess_ws_bytes(n, p->d.num_anchors, p->d.num_classes, p->d.topk_candidates, p->d.detections_per_img);
     off += align256(L.post_bytes);
     L.total = off;
+    L.mega_index.assign(p->ops.size(), -1);
+    if (!p->group_first.empty()) {
+        std::vector<MegaOp> tab;
+        std::vector<char> pw_se_applied(p->ops.size(), 0);
+        for (size_t i = 0; i < p->ops.size(); ++i)
+            if (p->se_inplace_pw[i] >= 0) pw_se_applied[p->se_inplace_pw[i]] = 1;
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            if (p->op_group[i] < 0) continue;
+            const dn_op_desc& o = p->ops[i];
+            const dn_tensor_desc& ti = p->tensors[o.in];
+            const dn_tensor_desc& to = p->tensors[o.out];
+            MegaOp m{};
+            m.type = o.type; m.cin = o.cin; m.cout = o.cout; m.k = o.k; m.stride = o.stride; m.pad = o.pad; m.act = o.act;
+            m.hin = ti.h; m.win = ti.w; m.hout = to.h; m.wout = to.w;
+            m.squeeze = o.squeeze; m.pool_pixels = o.pool_pixels; m.pool = -1; m.pool_rows = 0;
+            m.res_off = m.se_off = m.pool_off = -1;
+            m.w_off = o.w_off; m.b_off = o.b_off; m.w2_off = o.w2_off; m.b2_off = o.b2_off;
+            auto per_img = [&](int t) { return (long)(L.tbytes[t] / n); };
+            m.x_off = (long)L.toff[o.in]; m.x_stride = per_img(o.in);
+            if (o.type == DN_OP_PW && o.head) {
+                const int cols = (o.head == 1) ? p->d.num_classes : 4;
+                m.out_fp32 = 1;
+                m.out_off = (long)((o.head == 1) ? L.logits_off : L.reg_off) + (long)p->level_off[o.level] * cols * 4;
+                m.out_stride = (long)p->d.num_anchors * cols * 4;
+            } else {
+                m.out_off = (long)L.toff[o.out]; m.out_stride = per_img(o.out);
+            }
+            if (o.type == DN_OP_PW) {
+                if (o.residual >= 0) { m.res_off = (long)L.toff[o.residual]; m.res_stride = per_img(o.residual); }
+                if (o.se >= 0 && !pw_se_applied[i]) { m.se_off = (long)L.toff[o.se]; m.se_stride = per_img(o.se); }
+            } else if (o.type == DN_OP_DW) {
+                if (o.pool >= 0) { m.pool = 1; m.pool_off = (long)L.toff[o.pool]; m.pool_stride = per_img(o.pool); m.pool_rows = p->pool_blocks[o.pool]; }
+            } else if (o.type == DN_OP_SE) {
+                m.pool_rows = p->pool_blocks[o.in];
+                if (p->se_inplace_pw[i] >= 0) {
+                    const int xt = p->ops[p->se_inplace_pw[i]].in;      // the depthwise output the projection reads
+                    m.res_off = (long)L.toff[xt]; m.res_stride = per_img(xt);
+                }
+            }
+            L.mega_index[i] = (int)tab.size();
+            tab.push_back(m);
+        }
+        if (hipMalloc((void**)&L.mega_dev, tab.size() * sizeof(MegaOp)) == hipSuccess)
+            (void)hipMemcpy(L.mega_dev, tab.data(), tab.size() * sizeof(MegaOp), hipMemcpyHostToDevice);
+    }
     return p->layouts.emplace(n, std::move(L)).first->second;
 }
 
@@ -129,10 +184,63 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (o.type < DN_OP_STEM || o.type > DN_OP_L2NORM) { dn_set_error("dn_create: op %d unknown type %d", i, o.type); return fail(DN_E_INVALID); }
         if (o.head && (o.level < 0 || o.level >= desc->n_levels)) { dn_set_error("dn_create: head op %d bad level", i); return fail(DN_E_INVALID); }
     }
+    // ---- fused inverted-residual groups
+    p->fused_len.assign(desc->n_ops, 0);
+    p->fused_kind.assign(desc->n_ops, 0);
+    {
+        const bool enabled = getenv("DN_FUSED") ? atoi(getenv("DN_FUSED")) != 0 : false;   // measured: instruction-bound, opt-in
+        const int min_hw = getenv("DN_FUSED_MINHW") ? atoi(getenv("DN_FUSED_MINHW")) : 1;
+        std::vector<int> uses(desc->n_tensors, 0);
+        for (int i = 0; i < desc->n_ops; ++i) {
+            const dn_op_desc& o = p->ops[i];
+            uses[o.in]++;
+            if (o.residual >= 0) uses[o.residual]++;
+            if (o.se >= 0) uses[o.se]++;
+        }
+        for (int l = 0; l < desc->n_levels; ++l) uses[desc->level_tensor[l]] += 100;    // features must be materialised
+        auto plain_pw = [&](const dn_op_desc& o) { return o.type == DN_OP_PW && !o.head && o.se < 0 && o.cin % 8 == 0 && o.cout % 8 == 0; };
+        auto proj_pw = [&](const dn_op_desc& o) { return plain_pw(o) && o.cout <= 96; };
+        auto dw_ok = [&](const dn_op_desc& o) { return o.type == DN_OP_DW && (o.k == 3 || o.k == 5) && o.dil == 1 && o.cin % 8 == 0; };
+        auto proj_fits = [&](const dn_op_desc& pw) {
+            const dn_tensor_desc& to = p->tensors[pw.out];
+            int th, tw;
+            fused_tile(to.h, to.w, &th, &tw);
+            return ((th * tw + 31) / 32) * ((pw.cout + 31) / 32) <= 16;
+        };
+        int i = 0;
+        while (enabled && i < desc->n_ops) {
+            const dn_op_desc& a = p->ops[i];
+            const bool has_b = i + 1 < desc->n_ops, has_c = i + 2 < desc->n_ops;
+            // expand -> dw [-> project]
+            if (plain_pw(a) && a.residual < 0 && a.cin <= 120 && uses[a.out] == 1 && has_b && dw_ok(p->ops[i + 1]) &&
+                p->ops[i + 1].in == a.out && p->tensors[p->ops[i + 1].out].h >= min_hw) {
+                const dn_op_desc& d = p->ops[i + 1];
+                if (d.pool < 0 && has_c && proj_pw(p->ops[i + 2]) && p->ops[i + 2].in == d.out && uses[d.out] == 1 &&
+                    (p->ops[i + 2].residual < 0 || (p->ops[i + 2].residual == a.in && d.stride == 1 && a.cin == p->ops[i + 2].cout)) &&
+                    proj_fits(p->ops[i + 2])) {
+                    p->fused_len[i] = 3; p->fused_kind[i] = 3; i += 3; continue;
+                }
+                p->fused_len[i] = 2; p->fused_kind[i] = 1; i += 2; continue;
+            }
+            // dw -> project (no expand)
+            if (dw_ok(a) && a.pool < 0 && uses[a.out] == 1 && has_b && proj_pw(p->ops[i + 1]) && p->ops[i + 1].in == a.out &&
+                p->tensors[a.out].h >= min_hw && p->tensors[a.in].kind == DN_T_ACT &&
+                (p->ops[i + 1].residual < 0 || (p->ops[i + 1].residual == a.in && a.stride == 1 && a.cin == p->ops[i + 1].cout)) &&
+                proj_fits(p->ops[i + 1])) {
+                p->fused_len[i] = 2; p->fused_kind[i] = 2; i += 2; continue;
+            }
+            ++i;
+        }
+    }
     // partial-sum rows of every pooled tensor = workgroups per image of its producing depthwise op
     p->pool_blocks.assign(desc->n_tensors, 0);
     for (int i = 0; i < desc->n_ops; ++i) {
         const dn_op_desc& o = p->ops[i];
+        if (o.type == DN_OP_DW && o.pool >= 0 && i > 0 && p->fused_len[i - 1] == 2 && (p->fused_kind[i - 1] & 1)) {
+            const dn_tensor_desc& to = p->tensors[o.out];
+            p->pool_blocks[o.pool] = fused_tiles_per_image(to.h, to.w);
+            continue;
+        }
         if (o.type == DN_OP_DW && o.pool >= 0) {
             const dn_tensor_desc& ti = p->tensors[o.in];
             const dn_tensor_desc& to = p->tensors[o.out];
@@ -158,7 +266,46 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (p->op_stream[i]) p->op_wait_level[i] = level_of(o.in);
         else p->op_feat_level[i] = level_of(o.out);
     }
-    p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : true;
+    p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
+    p->mega_enabled = getenv("DN_MEGA") ? atoi(getenv("DN_MEGA")) != 0 : false;   // measured slower than launches: opt-in
+    p->op_group.assign(desc->n_ops, -1);
+    p->se_inplace_pw.assign(desc->n_ops, -1);
+    if (p->mega_enabled) {
+        const long mac_limit = getenv("DN_MEGA_MACS") ? atol(getenv("DN_MEGA_MACS")) : 12000000L;
+        const int hw_limit = getenv("DN_MEGA_HW") ? atoi(getenv("DN_MEGA_HW")) : 25;
+        auto eligible = [&](int i) {
+            const dn_op_desc& o = p->ops[i];
+            const dn_tensor_desc& ti = p->tensors[o.in];
+            const dn_tensor_desc& to = p->tensors[o.out];
+            if (o.type == DN_OP_PW)
+                return ti.kind == DN_T_ACT && to.h * to.w <= hw_limit && (long)to.h * to.w * o.cin * o.cout <= mac_limit && o.cin % 8 == 0 &&
+                       (o.head || o.cout % 4 == 0);
+            if (o.type == DN_OP_DW)
+                return ti.h * ti.w <= hw_limit && (o.k == 3 || o.k == 5) && o.cin % 8 == 0 && o.cin / 8 <= 512 && o.dil == 1;
+            if (o.type == DN_OP_SE) return o.cin <= 1024 && o.squeeze <= 256 && o.pool_pixels <= hw_limit;
+            return false;
+        };
+        int i = 0;
+        while (i < desc->n_ops) {
+            if (!eligible(i)) { ++i; continue; }
+            int j = i;
+            while (j < desc->n_ops && eligible(j)) ++j;
+            if (j - i >= 2) {
+                const int g = (int)p->group_first.size();
+                p->group_first.push_back(i);
+                p->group_count.push_back(j - i);
+                for (int q = i; q < j; ++q) p->op_group[q] = g;
+            }
+            i = j;
+        }
+        // SE ops whose consumer projection sits in the same group rescale the depthwise output in place
+        for (int i2 = 0; i2 < desc->n_ops; ++i2) {
+            const dn_op_desc& o = p->ops[i2];
+            if (o.type != DN_OP_SE || p->op_group[i2] < 0) continue;
+            for (int j = i2 + 1; j < desc->n_ops && p->op_group[j] == p->op_group[i2]; ++j)
+                if (p->ops[j].type == DN_OP_PW && p->ops[j].se == o.out) { p->se_inplace_pw[i2] = j; break; }
+        }
+    }
     // anchor offsets per level
     int acc = 0;
     for (int l = 0; l < desc->n_levels; ++l) {
@@ -196,6 +343,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
 extern "C" void dn_destroy(dn_plan* p) {
     if (!p) return;
     for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : p->layouts) if (kv.second.mega_dev) (void)hipFree(kv.second.mega_dev);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     for (int i = 0; i < 2; ++i) if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
     for (int i = 0; i < 8; ++i) if (p->ev_feat[i]) (void)hipEventDestroy(p->ev_feat[i]);
@@ -256,6 +404,41 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         if (record) (void)hipEventRecord(p->events[ev++], s);
         int rc = DN_OK;
         const unsigned char* W = p->weights_dev;
+        if (p->fused_len[i] > 0) {
+            const int kind = p->fused_kind[i], len = p->fused_len[i];
+            const dn_op_desc* e = (kind & 1) ? &p->ops[i] : nullptr;
+            const dn_op_desc& dwo = p->ops[i + ((kind & 1) ? 1 : 0)];
+            const dn_op_desc* pj = (kind & 2) ? &p->ops[i + len - 1] : nullptr;
+            const dn_tensor_desc& tin = p->tensors[p->ops[i].in];
+            const dn_tensor_desc& tdo = p->tensors[dwo.out];
+            FusedArgs a{};
+            a.x = reinterpret_cast<const half_t*>(tptr(p->ops[i].in));
+            a.out = reinterpret_cast<half_t*>(tptr(pj ? pj->out : dwo.out));
+            a.pool = dwo.pool >= 0 ? reinterpret_cast<float*>(tptr(dwo.pool)) : nullptr;
+            if (e) { a.w1 = reinterpret_cast<const half_t*>(W + e->w_off); a.b1 = reinterpret_cast<const float*>(W + e->b_off); a.act1 = e->act; }
+            a.wd = reinterpret_cast<const half_t*>(W + dwo.w_off); a.bd = reinterpret_cast<const float*>(W + dwo.b_off); a.act2 = dwo.act;
+            if (pj) { a.w3 = reinterpret_cast<const half_t*>(W + pj->w_off); a.b3 = reinterpret_cast<const float*>(W + pj->b_off); a.act3 = pj->act; }
+            a.n = n; a.H = tin.h; a.W = tin.w; a.Ho = tdo.h; a.Wo = tdo.w;
+            a.cin = tin.c; a.cexp = dwo.cin; a.cout = pj ? pj->cout : dwo.cin;
+            a.k = dwo.k; a.stride = dwo.stride; a.pad = dwo.pad;
+            a.has_res = (pj && pj->residual >= 0) ? 1 : 0;
+            rc = launch_fused(a, s);
+            if (rc != DN_OK) return rc;
+            for (int q = 1; q < len; ++q) {
+                if (record) (void)hipEventRecord(p->events[ev++], s);
+            }
+            i += len - 1;
+            continue;
+        }
+        if (p->op_group[i] >= 0 && L.mega_dev) {
+            const int g = p->op_group[i];
+            if ((int)i == p->group_first[g]) {
+                rc = launch_mega(L.mega_dev, L.mega_index[i], p->group_count[g], n, ws, W, s);
+                if (rc != DN_OK) return rc;
+            }
+            if (ms && p->op_feat_level[i] >= 0) DN_HIP_CHECK(hipEventRecord(p->ev_feat[p->op_feat_level[i]], main_stream));
+            continue;
+        }
         switch (o.type) {
             case DN_OP_STEM: {
                 StemArgs a;
@@ -468,6 +651,13 @@ extern "C" int dn_tensor_ptr(const dn_plan* p, void* workspace, int n, int tenso
     return DN_OK;
 }
 
+extern "C" int dn_op_groups(const dn_plan* p, int32_t* group_of_op, int capacity) {
+    DN_REQUIRE(p && group_of_op, "null argument");
+    DN_REQUIRE(capacity >= (int)p->ops.size(), "dn_op_groups: capacity too small");
+    for (size_t i = 0; i < p->ops.size(); ++i) group_of_op[i] = p->op_group[i];
+    return (int)p->group_first.size();
+}
+
 extern "C" int dn_profile_begin(dn_plan* p) {
     DN_REQUIRE(p, "null plan");
     p->profiling = true;
@@ -521,6 +711,26 @@ extern "C" int dn_pointwise_conv(const void* x, const void* w, const float* bias
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;
 }
+
+extern "C" int dn_fused_block(const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w3,
+                              const float* b3, void* out, float* pool_partial, int n, int h, int w, int cin, int cexp, int cout,
+                              int k, int stride, int act1, int act2, int act3, int has_res, void* stream) {
+    DN_REQUIRE(x && wd && bd && out, "dn_fused_block: null argument");
+    FusedArgs a{};
+    a.x = reinterpret_cast<const half_t*>(x); a.out = reinterpret_cast<half_t*>(out); a.pool = pool_partial;
+    a.w1 = reinterpret_cast<const half_t*>(w1); a.b1 = b1; a.wd = reinterpret_cast<const half_t*>(wd); a.bd = bd;
+    a.w3 = reinterpret_cast<const half_t*>(w3); a.b3 = b3;
+    a.n = n; a.H = h; a.W = w; a.k = k; a.stride = stride; a.pad = (k - 1) / 2;
+    a.Ho = (h + 2 * a.pad - k) / stride + 1; a.Wo = (w + 2 * a.pad - k) / stride + 1;
+    a.cin = cin; a.cexp = cexp; a.cout = w3 ? cout : cexp;
+    a.act1 = act1; a.act2 = act2; a.act3 = act3; a.has_res = has_res;
+    int rc = launch_fused(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    DN_HIP_CHECK(hipGetLastError());
+    return DN_OK;
+}
+
+extern "C" int dn_fused_tiles_per_image(int ho, int wo) { return fused_tiles_per_image(ho, wo); }
 
 extern "C" int dn_depthwise_conv(const void* x, const void* w, const float* bias, void* out, int n, int h, int wd, int c, int k,
                                  int stride, int pad, int act, void* stream) {
