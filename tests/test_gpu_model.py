@@ -227,3 +227,47 @@ def test_error_behaviour_matches_reference():
     m.eval()
     with pytest.raises(RuntimeError):
         m([torch.zeros(3, 320, 320)])                                    # CPU tensors: no fallback path
+
+
+OTHER_MODELS = [
+    # golden name, factory kwargs, logit tolerance (atol, rtol)
+    ("ssd_lite_mobilenet_v2", dict(score_thresh=0.02), (8e-2, 1.5e-2)),
+    ("ssd300_vgg16", dict(), (1.5e-1, 2e-2)),
+    ("ssd512_vgg16", dict(), (2e-1, 2e-2)),
+]
+
+
+@pytest.mark.parametrize("name,kw,tol", OTHER_MODELS)
+def test_other_model_families_match_golden(golden_dir, name, kw, tol):
+    """Config C3 (MobileNetV2 SSDLite remnants) and C5 (VGG16 SSD, dense 3x3 implicit-GEMM convs, max-pool, L2-norm):
+    head outputs against the real reference's, then detections as a set."""
+    z = _golden(golden_dir, name)
+    ncls = int(z["num_classes"])
+    if name == "ssd_lite_mobilenet_v2":
+        m = models.ssd_lite_mobilenet_v2(num_classes=ncls, **kw)
+    else:
+        m = getattr(models, name)(num_classes=ncls, **kw)
+    models.load_synthetic(m, int(z["weight_seed"]))
+    m.cuda()
+    st, nt, dpi, topk = z["post"]
+    assert abs(m.score_thresh - st) < 1e-9 and m.detections_per_img == int(dpi) and m.topk_candidates == int(topk)
+    imgs = _images(m.graph, z["image_seeds"])
+    logits, reg = m.forward_heads(torch.stack(imgs))
+    logits, reg = logits.cpu().numpy(), reg.cpu().numpy()
+    atol, rtol = tol
+    ref_rows = z["cls_logits_rows_0"]
+    err = np.abs(logits[0][::7] - ref_rows)
+    print(f"{name}: logits max|err| {err.max():.4g} mean|err| {err.mean():.4g} max|ref| {np.abs(ref_rows).max():.3g}")
+    np.testing.assert_allclose(logits[0][::7], ref_rows, rtol=rtol, atol=atol)
+    np.testing.assert_allclose(reg, z["bbox_regression"], rtol=rtol, atol=atol)
+    s = z["cls_logits_sum_0"]
+    assert abs(np.abs(logits[0]).astype(np.float64).sum() - s[1]) <= 5e-3 * s[1]
+    out = m(imgs)
+    d = out[0]
+    rb, rl = z["det_boxes_0"], z["det_labels_0"]
+    gb, gl = d["boxes"].cpu().numpy(), d["labels"].cpu().numpy()
+    assert abs(gl.shape[0] - rl.shape[0]) <= max(2, rl.shape[0] // 50)
+    iou = so.box_iou_np(rb, gb)
+    hit = ((iou > 0.9) & (rl[:, None] == gl[None, :])).any(1)
+    print(f"{name}: {hit.mean() * 100:.1f}% of reference detections reproduced")
+    assert hit.mean() > 0.8
