@@ -117,7 +117,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("DN_BENCH_FORCE_DIST") == "1"     # (the latter: 1-GPU smoke test of the RCCL path)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -125,7 +125,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from demonet_amd import models, synth
-    from demonet_amd.dist import pack_detections, gather_detections
+    from demonet_amd.dist import DetectionGatherer
     ncls = 21 if args.model == "ssd_lite_mobilenet_v2" else 91
     model = models.load_synthetic(getattr(models, args.model)(num_classes=ncls), 0).to(dev)
     g = model.graph
@@ -135,10 +135,15 @@ def main():
     if args.eager:
         model.set_graph_mode(False)
 
+    gatherer = DetectionGatherer(B, g.post["detections_per_img"], dev) if distributed else None
+
     def step():
-        boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True)
         if distributed:
-            gather_detections(pack_detections(boxes, scores, labels), counts)
+            # the merge kernel writes the gather payload itself; ONE packed all_gather on a side stream, overlapped with the next step
+            boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True, packed=gatherer.next_buffer())
+            gatherer.submit()
+        else:
+            boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True)
         return counts
 
     for _ in range(max(args.warmup, 2)):
@@ -150,6 +155,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         counts = step()
+    if distributed:
+        gatherer.flush()
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()

@@ -121,6 +121,7 @@ struct PostArgs {
     float img_h, img_w; const float* scale_xy;
     float score_thresh, nms_thresh; int topk, dets;
     float* boxes; float* scores; int64_t* labels; int32_t* counts; int32_t* kept_anchor;
+    float* packed = nullptr;    // optional [n][dets+1][6] fp32: rows (x1,y1,x2,y2,score,label), row `dets` = (count,0,..)
     void* ws; size_t ws_bytes;
 };
 size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets);

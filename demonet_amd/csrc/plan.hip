@@ -36,10 +36,10 @@ struct Layout {
 };
 
 struct GraphKey {
-    const void* img; int n, h, w; void* ws; void* boxes; void* scores; void* labels; void* counts; int heads_only;
+    const void* img; int n, h, w; void* ws; void* boxes; void* scores; void* labels; void* counts; int heads_only; void* packed;
     bool operator<(const GraphKey& o) const {
-        return std::tie(img, n, h, w, ws, boxes, scores, labels, counts, heads_only) <
-               std::tie(o.img, o.n, o.h, o.w, o.ws, o.boxes, o.scores, o.labels, o.counts, o.heads_only);
+        return std::tie(img, n, h, w, ws, boxes, scores, labels, counts, heads_only, packed) <
+               std::tie(o.img, o.n, o.h, o.w, o.ws, o.boxes, o.scores, o.labels, o.counts, o.heads_only, o.packed);
     }
 };
 
@@ -69,6 +69,7 @@ struct dn_plan {
     std::vector<int> group_first, group_count;
     std::vector<int> se_inplace_pw;         // SE op -> index of the in-group projection whose input it rescales in place, else -1
     bool mega_enabled = true;
+    float* packed_out = nullptr;            // optional extra output of the merge kernel (dn_set_packed_output)
     // fused inverted-residual groups (fused.hip): at the first op of a group fused_len = 2 or 3, fused_kind bit0 = has
     // expand, bit1 = has project
     std::vector<int> fused_len, fused_kind;
@@ -542,6 +543,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         if (resize) a.scale_xy = scale_xy;
         a.score_thresh = d.score_thresh; a.nms_thresh = d.nms_thresh; a.topk = d.topk_candidates; a.dets = d.detections_per_img;
         a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = nullptr;
+        a.packed = p->packed_out;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
@@ -592,7 +594,7 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     }
     if (!p->graph_mode) return enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
 
-    GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, heads_only ? 1 : 0};
+    GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, heads_only ? 1 : 0, p->packed_out};
     auto it = p->graphs.find(key);
     if (it == p->graphs.end()) {
         // first call with this signature: run once eagerly (sets function attributes, validates), then capture
@@ -648,6 +650,12 @@ extern "C" int dn_tensor_ptr(const dn_plan* p, void* workspace, int n, int tenso
     DN_REQUIRE(L.toff[tensor_id] != (size_t)-1, "dn_tensor_ptr: tensor %d is not materialised in the workspace", tensor_id);
     *ptr = reinterpret_cast<unsigned char*>(workspace) + L.toff[tensor_id];
     if (bytes) *bytes = L.tbytes[tensor_id];
+    return DN_OK;
+}
+
+extern "C" int dn_set_packed_output(dn_plan* p, float* packed_dev) {
+    DN_REQUIRE(p, "null plan");
+    p->packed_out = packed_dev;
     return DN_OK;
 }
 

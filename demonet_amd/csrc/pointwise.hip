@@ -30,16 +30,17 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
     constexpr int CPR = BK / 8;         // 16-B chunks per row per stage
-    constexpr int CSH = (BK == 32) ? 2 : 3;
+    constexpr int CSH = (BK == 32) ? 2 : (BK == 64) ? 3 : 4;
     constexpr int TP = BP / WP / 32;    // 32-pixel MFMA tiles per wave
     constexpr int TC = BC / WC / 32;    // 32-channel MFMA tiles per wave
     constexpr int NX = BP * CPR / 256;  // 16-B chunks of the pixel tile per thread per stage
     constexpr int NW = BC * CPR / 256;  // 16-B chunks of the weight tile per thread per stage
     static_assert(NX >= 1 && NW >= 0, "tile too small");
     constexpr int NWc = NW > 0 ? NW : 1;
-    extern __shared__ __attribute__((aligned(16))) half_t lds_dyn[];      // [2][(BP + BC) * LDS_ROW] halfs, then bias[BC] floats
+    extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];      // bias[BC] floats, then [1|2][(BP + BC) * LDS_ROW] halfs
+    float* bsh = reinterpret_cast<float*>(lds_raw);
+    half_t* lds_dyn = lds_raw + 2 * BC;
     half_t (*lds)[(BP + BC) * LDS_ROW] = reinterpret_cast<half_t (*)[(BP + BC) * LDS_ROW]>(lds_dyn);
-    float* bsh = reinterpret_cast<float*>(lds_dyn + 2 * (BP + BC) * LDS_ROW);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         // fp16 outputs: stage the finished tile in LDS ([BP][BC+8] halfs, reusing the K-loop buffers) and write it out as
         // row-contiguous 16-byte chunks -> every wave store covers whole 128-B lines; the residual is read the same way.
         constexpr int OROW = BC + 8;
-        static_assert(BP * OROW <= 2 * (BP + BC) * LDS_ROW, "output tile must fit the staging buffers");
+        // (the launcher sizes the dynamic LDS as max(K-loop buffers, output tile))
         half_t* ot = lds_dyn;
         // (the last K-loop iteration ended with a barrier: nobody reads the staging buffers any more)
 #pragma unroll
@@ -497,26 +498,38 @@ int launch_xs(const PwArgs& a, hipStream_t s) {
     return DN_OK;
 }
 
+template <int BP, int BC, int WP, int WC, bool CONV, int BK>
+int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
+    dim3 grid(dn_cdiv(a.m, BP), dn_cdiv(a.cout, BC));
+    size_t halfs = (size_t)nbuf * (BP + BC) * (BK + 8);
+    const size_t otile = (size_t)BP * (BC + 8);
+    if (otile > halfs) halfs = otile;
+    const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK>), grid, dim3(256), lds, s, a);
+    return DN_OK;
+}
+
+// K staging: when the whole K fits one LDS stage (K <= 128) the workgroup pays ONE memory round trip instead of
+// K/32 + 1 dependent ones (in-kernel stamps: ~1 us each; mid-size layers run as a single wave of workgroups, so the
+// kernel time IS the workgroup lifetime). Larger K keeps the 32-deep double buffer (BK=64 double-buffered lost to
+// occupancy when measured).
 template <int BP, int BC, int WP, int WC, bool CONV>
 int launch_cfg(const PwArgs& a, hipStream_t s) {
-    dim3 grid(dn_cdiv(a.m, BP), dn_cdiv(a.cout, BC));
     const_cast<PwArgs&>(a).stamps = g_pw_stamps;
-    static const int bk64 = getenv("DN_PW_BK64") ? atoi(getenv("DN_PW_BK64")) : 0;
-    // BK=64 halves the number of K stages but doubles LDS per workgroup; measured: no net win (occupancy), off by default
-    if (bk64 && a.cin >= 64 && (!CONV || a.cv_cin % 64 == 0)) {
-        constexpr size_t lds = (size_t)2 * (BP + BC) * 72 * sizeof(half_t) + BC * sizeof(float);
-        static bool attr = false;
-        if (!attr && lds > 64 * 1024) {
-            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, 64>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
-        attr = true;
-        hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, 64>), grid, dim3(256), lds, s, a);
-        return DN_OK;
+    static const int fullk = getenv("DN_PW_FULLK") ? atoi(getenv("DN_PW_FULLK")) : 0;   // measured slower: off
+    const bool conv_ok64 = !CONV || a.cv_cin % 64 == 0, conv_ok128 = !CONV || a.cv_cin % 128 == 0;
+    if (fullk && a.cin <= 32) return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 1);
+    if (fullk && a.cin <= 64 && conv_ok64) return launch_bk<BP, BC, WP, WC, CONV, 64>(a, s, 1);
+    if constexpr (BP + BC <= 192) {
+        if (fullk && a.cin <= 128 && conv_ok128) return launch_bk<BP, BC, WP, WC, CONV, 128>(a, s, 1);
     }
-    constexpr size_t lds32 = (size_t)2 * (BP + BC) * 40 * sizeof(half_t) + BC * sizeof(float);
-    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, 32>), grid, dim3(256), lds32, s, a);
-    return DN_OK;
+    return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 2);
 }
 
 }  // namespace

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
                                                     float* __restrict__ oboxes, float* __restrict__ oscores,
                                                     long long* __restrict__ olabels, int* __restrict__ ocounts,
                                                     int* __restrict__ oanchor, int mode, const unsigned* __restrict__ tauKey,
-                                                    int* __restrict__ needFull) {
+                                                    int* __restrict__ needFull, float* __restrict__ opacked) {
     // mode 0: after the fast per-class pass (may raise needFull); mode 1: after the full pass (only flagged images);
     // mode 2: unconditional (fast path disabled)
     if (mode == 0 && needFull[blockIdx.x]) return;
@@ -621,8 +621,18 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
         oscores[(size_t)n * D + i] = s;
         olabels[(size_t)n * D + i] = lab;
         if (oanchor) oanchor[(size_t)n * D + i] = anc;
+        if (opacked) {
+            float* pr = opacked + ((size_t)n * (D + 1) + i) * 6;
+            pr[0] = b.x; pr[1] = b.y; pr[2] = b.z; pr[3] = b.w; pr[4] = s; pr[5] = (float)lab;
+        }
     }
-    if (tid == 0) ocounts[n] = M;
+    if (tid == 0) {
+        ocounts[n] = M;
+        if (opacked) {
+            float* pr = opacked + ((size_t)n * (D + 1) + D) * 6;
+            pr[0] = (float)M; pr[1] = pr[2] = pr[3] = pr[4] = pr[5] = 0.f;
+        }
+    }
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -722,7 +732,7 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
         else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         hipLaunchKernelGGL(merge_kernel, dim3(a.n), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull);
+                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed);
     }
     const int* flag = fast ? needFull : nullptr;
     if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
@@ -733,7 +743,7 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     if (rc != DN_OK) return rc;
     if (ev) (void)hipEventRecord(ev[2], s);
     hipLaunchKernelGGL(merge_kernel, dim3(a.n), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull);
+                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull, a.packed);
     if (ev) (void)hipEventRecord(ev[3], s);
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;

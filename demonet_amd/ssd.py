@@ -144,10 +144,11 @@ class SSD(nn.Module):
         return b
 
     # ------------------------------------------------------------------------------------------------------
-    def forward_batch(self, images: Tensor, persistent_input: bool = False):
+    def forward_batch(self, images: Tensor, persistent_input: bool = False, packed: Optional[Tensor] = None):
         """images: [N,3,H,W] fp32 on the GPU. Returns padded device tensors (boxes [N,D,4], scores [N,D],
         labels [N,D] int64, counts [N] int32) that stay valid until the next call with the same shape.
-        persistent_input=True promises that `images` keeps its address between calls (lets the hipGraph replay)."""
+        persistent_input=True promises that `images` keeps its address between calls (lets the hipGraph replay).
+        packed: optional [N, D+1, 6] fp32 device tensor that additionally receives the gather payload (dist.py)."""
         if images.dim() != 4 or images.shape[1] != 3:
             raise ValueError("expected a [N,3,H,W] batch, got {}".format(tuple(images.shape)))
         if not images.is_floating_point():
@@ -161,6 +162,7 @@ class SSD(nn.Module):
             b["images"].copy_(images)
             src = b["images"]
         stream = torch.cuda.current_stream(images.device).cuda_stream
+        _lib.check(_lib.lib().dn_set_packed_output(C.c_void_p(handle), C.c_void_p(packed.data_ptr()) if packed is not None else None))
         with torch.cuda.device(images.device):
             _lib.check(_lib.lib().dn_forward(C.c_void_p(handle), C.c_void_p(src.data_ptr()), n, h, w,
                                              C.c_void_p(b["boxes"].data_ptr()), C.c_void_p(b["scores"].data_ptr()),

@@ -142,6 +142,11 @@ DN_API int dn_set_graph_mode(dn_plan* plan, int enabled);
 DN_API int dn_profile_begin(dn_plan* plan);
 DN_API int dn_profile_end(dn_plan* plan, float* ms_per_op /* [n_ops + 3] : ops..., softmax/decode, select/NMS, merge */, int capacity);
 
+/* Optional extra output of dn_forward for the multi-GPU gather: when non-NULL, the final merge kernel also writes
+ * packed_dev [n][D+1][6] fp32 -- rows (x1,y1,x2,y2,score,label), row D = (count,0,0,0,0,0) -- i.e. the fixed-shape payload of
+ * the detections all-gather (the analogue of util/misc.py:75-115 all_gather of pickled results). NULL disables it. */
+DN_API int dn_set_packed_output(dn_plan* plan, float* packed_dev);
+
 /* Which ops were grouped into per-image "tail" kernel runs (one launch per run): group id per op or -1. Returns #groups. */
 DN_API int dn_op_groups(const dn_plan* plan, int32_t* group_of_op, int capacity);
 

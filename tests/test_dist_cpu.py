@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from demonet_amd.dist import gather_detections, pack_detections, shard_range, unpack_detections
+from demonet_amd.dist import DetectionGatherer, gather_detections, pack_detections, shard_range, unpack_detections
 
 
 def _worker(rank, world, port, ret):
@@ -26,6 +26,17 @@ def _worker(rank, world, port, ret):
         c = int(counts[i])
         assert torch.equal(mine[i]["boxes"], boxes[i, :c]) and torch.equal(mine[i]["labels"], labels[i, :c])
         assert torch.equal(mine[i]["scores"], scores[i, :c])
+    # overlapped, double-buffered gatherer (the form bench.py uses), three consecutive steps
+    G = DetectionGatherer(B, D, "cpu")
+    idx = []
+    for step in range(3):
+        idx.append(G.submit(boxes + step, scores, labels, counts))
+    for step in (1, 2):                       # buffers of step 0 were recycled by step 2
+        pk, cn = G.result(idx[step])
+        assert pk.shape == (world * B, D, 6) and cn.tolist() == [D, 2, 0, 1, D, 3]
+        assert torch.equal(pk[rank * B:(rank + 1) * B, :, :4], boxes + step)
+        assert torch.equal(pk[rank * B:(rank + 1) * B, :, 5].to(torch.int64), labels)
+    G.flush()
     ret[rank] = float(gp.sum())
     dist.destroy_process_group()
 

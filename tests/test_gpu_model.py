@@ -271,3 +271,17 @@ def test_other_model_families_match_golden(golden_dir, name, kw, tol):
     hit = ((iou > 0.9) & (rl[:, None] == gl[None, :])).any(1)
     print(f"{name}: {hit.mean() * 100:.1f}% of reference detections reproduced")
     assert hit.mean() > 0.8
+
+
+def test_packed_gather_payload_matches_outputs():
+    """dn_set_packed_output: the [N, D+1, 6] payload written by the merge kernel equals the regular outputs."""
+    m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+    imgs = torch.from_numpy(synth.images(11, 3, 320, 320)).cuda()
+    D = m.detections_per_img
+    packed = torch.full((3, D + 1, 6), -1.0, device="cuda")
+    b, s, l, c = [t.clone() for t in m.forward_batch(imgs, persistent_input=True, packed=packed)]
+    torch.cuda.synchronize()
+    assert torch.equal(packed[:, :D, :4], b) and torch.equal(packed[:, :D, 4], s)
+    assert torch.equal(packed[:, :D, 5].to(torch.int64), l) and torch.equal(packed[:, D, 0].to(torch.int32), c)
+    b2 = m.forward_batch(imgs, persistent_input=True)[0]            # and it can be switched off again
+    assert torch.equal(b2, b)
