@@ -57,6 +57,7 @@ struct PwArgs {
     long long* stamps = nullptr;   // dev-only phase stamps
 };
 int launch_pointwise(const PwArgs& a, hipStream_t s);
+int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t s);
 
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;
@@ -64,6 +65,7 @@ struct DwArgs {
     float* pool = nullptr;      // optional: [n][blocks][c] fp32 per-workgroup sums of the outputs (SE squeeze)
 };
 int launch_depthwise(const DwArgs& a, hipStream_t s);
+int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s);
 int depthwise_pool_blocks(const DwArgs& a);       // workgroups per image == partial-sum rows per image
 
 struct StemArgs {
@@ -85,6 +87,7 @@ struct ConvArgs {
     long out_img_stride, out_base;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
+PwArgs conv_to_pw(const ConvArgs& c);
 int launch_maxpool(const half_t* x, half_t* out, int n, int h, int w, int c, int k, int stride, int pad, int ho, int wo,
                    hipStream_t s);
 int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels, int c, hipStream_t s);

@@ -11,12 +11,12 @@ namespace {
 
 // each thread: TW consecutive output pixels of one row x 8 channels; sliding input window kept in registers
 template <int K, int S, int TW>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
+__device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int nblocks) {
     constexpr int NIN = (TW - 1) * S + K;
     extern __shared__ float red[];            // [256][8], only when pooling
     const int C8 = a.c >> 3;
     const int XS = (a.wo + TW - 1) / TW;
-    int idx = blockIdx.x * 256 + threadIdx.x;
+    int idx = bx * 256 + threadIdx.x;
     const int n = blockIdx.y;
     const int cg = idx % C8;
     idx /= C8;
@@ -84,16 +84,53 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
         for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = psum[e];
         __syncthreads();
         if ((int)threadIdx.x < C8) {
-            const int cgp = (blockIdx.x * 256 + threadIdx.x) % C8;
+            const int cgp = (bx * 256 + threadIdx.x) % C8;
             float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int u = threadIdx.x; u < 256; u += C8)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t8[e] += red[u * 8 + e];
-            float* dst = a.pool + ((size_t)n * gridDim.x + blockIdx.x) * a.c + cgp * 8;
+            float* dst = a.pool + ((size_t)n * nblocks + bx) * a.c + cgp * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) dst[e] = t8[e];
         }
     }
+}
+
+template <int K, int S, int TW>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
+    dw_body<K, S, TW>(a, blockIdx.x, gridDim.x);
+}
+
+// Grouped launch: up to 12 independent depthwise problems of the same (k, stride) and batch in ONE launch (the head
+// depthwise convs of all pyramid levels, both heads). blockIdx.x is flat over the problems' per-image block counts.
+struct DwGroup {
+    int count;
+    int start[13];
+    DwArgs a[12];
+};
+
+template <int K, int S, int TW>
+__global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 12; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
+    dw_body<K, S, TW>(g.a[p], blockIdx.x - g.start[p], g.start[p + 1] - g.start[p]);
+}
+
+template <int K, int S, int TW>
+int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
+    DwGroup g{};
+    g.count = count;
+    int acc = 0;
+    for (int i = 0; i < count; ++i) {
+        g.a[i] = arr[i];
+        g.start[i] = acc;
+        acc += dn_cdiv((long)arr[i].ho * ((arr[i].wo + TW - 1) / TW) * (arr[i].c / 8), 256);
+    }
+    g.start[count] = acc;
+    hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].n), dim3(256), 0, s, g);
+    return DN_OK;
 }
 
 template <int K, int S, int TW>
@@ -256,6 +293,18 @@ int launch_depthwise(const DwArgs& a, hipStream_t s) {
     if (a.k == 5 && a.stride == 2) return launch_dw<5, 2, 2>(a, s);
     dn_set_error("depthwise: unsupported k=%d stride=%d", a.k, a.stride);
     return DN_E_UNSUPPORTED;
+}
+
+int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s) {
+    DN_REQUIRE(count >= 1 && count <= 12, "depthwise group: %d problems", count);
+    for (int i = 0; i < count; ++i) {
+        DN_REQUIRE(arr[i].c % 8 == 0 && !arr[i].pool && arr[i].k == arr[0].k && arr[i].stride == arr[0].stride && arr[i].n == arr[0].n,
+                   "depthwise group: problem %d is not compatible", i);
+    }
+    if (arr[0].k == 3 && arr[0].stride == 1) return launch_dw_group<3, 1, 4>(arr, count, s);
+    if (arr[0].k == 3 && arr[0].stride == 2) return launch_dw_group<3, 2, 2>(arr, count, s);
+    if (arr[0].k == 5 && arr[0].stride == 1) return launch_dw_group<5, 1, 4>(arr, count, s);
+    return launch_dw_group<5, 2, 2>(arr, count, s);
 }
 
 int depthwise_pool_blocks(const DwArgs& a) {

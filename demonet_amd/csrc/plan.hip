@@ -69,7 +69,10 @@ struct dn_plan {
     std::vector<int> group_first, group_count;
     std::vector<int> se_inplace_pw;         // SE op -> index of the in-group projection whose input it rescales in place, else -1
     bool mega_enabled = true;
-    float* packed_out = nullptr;            // optional extra output of the merge kernel (dn_set_packed_output)
+    float* packed_out = nullptr;
+    // head ops (dw -> 1x1 / dense 3x3 per level, both heads) run as grouped launches once the backbone is done
+    int head_first = -1;                    // index of the first head-chain op (all later ops are head-chain ops), -1: off
+    std::vector<int> head_dw, head_cls, head_reg;            // optional extra output of the merge kernel (dn_set_packed_output)
     // fused inverted-residual groups (fused.hip): at the first op of a group fused_len = 2 or 3, fused_kind bit0 = has
     // expand, bit1 = has project
     std::vector<int> fused_len, fused_kind;
@@ -267,6 +270,29 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (p->op_stream[i]) p->op_wait_level[i] = level_of(o.in);
         else p->op_feat_level[i] = level_of(o.out);
     }
+    {
+        const bool enabled = getenv("DN_HEAD_GROUPS") ? atoi(getenv("DN_HEAD_GROUPS")) != 0 : true;
+        int first = -1, last_main = -1;
+        for (int i = 0; i < desc->n_ops; ++i) {
+            if (p->op_stream[i]) { if (first < 0) first = i; }
+            else last_main = i;
+        }
+        bool ok = enabled && first > last_main && first >= 0;
+        int kinds = 0;
+        for (int i = first; ok && i < desc->n_ops; ++i) {
+            const dn_op_desc& o = p->ops[i];
+            if (o.type == DN_OP_DW) {
+                if (o.pool >= 0 || o.k != p->ops[first].k || o.stride != p->ops[first].stride || p->ops[first].type != DN_OP_DW) { ok = false; break; }
+                p->head_dw.push_back(i);
+            } else if ((o.type == DN_OP_PW || o.type == DN_OP_CONV) && o.head) {
+                kinds |= (o.type == DN_OP_PW) ? 1 : 2;
+                (o.head == 1 ? p->head_cls : p->head_reg).push_back(i);
+            } else ok = false;
+        }
+        if (ok && (kinds == 3 || p->head_dw.size() > 12 || p->head_cls.size() > 8 || p->head_reg.size() > 8 || p->head_cls.empty())) ok = false;
+        if (ok) p->head_first = first;
+        else { p->head_dw.clear(); p->head_cls.clear(); p->head_reg.clear(); }
+    }
     p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
     p->mega_enabled = getenv("DN_MEGA") ? atoi(getenv("DN_MEGA")) != 0 : false;   // measured slower than launches: opt-in
     p->op_group.assign(desc->n_ops, -1);
@@ -387,6 +413,64 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     }
     float* logits = reinterpret_cast<float*>(ws + L.logits_off);
     float* reg = reinterpret_cast<float*>(ws + L.reg_off);
+    const unsigned char* const Wb = p->weights_dev;
+    auto make_pw = [&](const dn_op_desc& o) {
+        const dn_tensor_desc& ti = p->tensors[o.in];
+        PwArgs a;
+        a.x = reinterpret_cast<const half_t*>(tptr(o.in));
+        a.w = reinterpret_cast<const half_t*>(Wb + o.w_off);
+        a.bias = reinterpret_cast<const float*>(Wb + o.b_off);
+        a.residual = o.residual >= 0 ? reinterpret_cast<const half_t*>(tptr(o.residual)) : nullptr;
+        a.se = o.se >= 0 ? reinterpret_cast<const float*>(tptr(o.se)) : nullptr;
+        a.hw = ti.h * ti.w;
+        a.m = n * a.hw;
+        a.cin = o.cin; a.cout = o.cout; a.act = o.act;
+        if (o.head) {
+            const int cols = (o.head == 1) ? d.num_classes : 4;
+            a.out = (o.head == 1) ? (void*)logits : (void*)reg;
+            a.out_fp32 = 1;
+            a.out_img_stride = (long)d.num_anchors * cols;
+            a.out_base = (long)p->level_off[o.level] * cols;
+        } else {
+            a.out = tptr(o.out);
+            a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
+        }
+        return a;
+    };
+    auto make_dw = [&](const dn_op_desc& o) {
+        const dn_tensor_desc& ti = p->tensors[o.in];
+        const dn_tensor_desc& to = p->tensors[o.out];
+        DwArgs a;
+        a.x = reinterpret_cast<const half_t*>(tptr(o.in));
+        a.w = reinterpret_cast<const half_t*>(Wb + o.w_off);
+        a.bias = reinterpret_cast<const float*>(Wb + o.b_off);
+        a.out = reinterpret_cast<half_t*>(tptr(o.out));
+        a.n = n; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
+        a.ho = to.h; a.wo = to.w;
+        a.pool = o.pool >= 0 ? reinterpret_cast<float*>(tptr(o.pool)) : nullptr;
+        return a;
+    };
+    auto make_conv = [&](const dn_op_desc& o) {
+        const dn_tensor_desc& ti = p->tensors[o.in];
+        const dn_tensor_desc& to = p->tensors[o.out];
+        ConvArgs a;
+        a.x = reinterpret_cast<const half_t*>(tptr(o.in));
+        a.w = reinterpret_cast<const half_t*>(Wb + o.w_off);
+        a.bias = reinterpret_cast<const float*>(Wb + o.b_off);
+        a.n = n; a.h = ti.h; a.w_ = ti.w; a.cin = o.cin; a.cout = o.cout; a.k = o.k; a.stride = o.stride;
+        a.pad = o.pad; a.dil = o.dil; a.act = o.act; a.ho = to.h; a.wo = to.w;
+        if (o.head) {
+            const int cols = (o.head == 1) ? d.num_classes : 4;
+            a.out = (o.head == 1) ? (void*)logits : (void*)reg;
+            a.out_fp32 = 1;
+            a.out_img_stride = (long)d.num_anchors * cols;
+            a.out_base = (long)p->level_off[o.level] * cols;
+        } else {
+            a.out = tptr(o.out);
+            a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
+        }
+        return a;
+    };
     int ev = 0;
     hipStream_t const main_stream = s;
     const bool ms = p->multi_stream && !record;
@@ -405,6 +489,28 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         if (record) (void)hipEventRecord(p->events[ev++], s);
         int rc = DN_OK;
         const unsigned char* W = p->weights_dev;
+        if ((int)i == p->head_first) {
+            // all remaining ops are head ops of the pyramid levels: three grouped launches instead of up to 28
+            if (!p->head_dw.empty()) {
+                DwArgs arr[12];
+                for (size_t q = 0; q < p->head_dw.size(); ++q) arr[q] = make_dw(p->ops[p->head_dw[q]]);
+                rc = launch_depthwise_group(arr, (int)p->head_dw.size(), s);
+                if (rc != DN_OK) return rc;
+            }
+            for (int kind = 0; kind < 2; ++kind) {
+                const std::vector<int>& lst = kind ? p->head_cls : p->head_reg;
+                if (lst.empty()) continue;
+                PwArgs arr[8];
+                const bool conv = p->ops[lst[0]].type == DN_OP_CONV;
+                for (size_t q = 0; q < lst.size(); ++q)
+                    arr[q] = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
+                rc = launch_pointwise_group(arr, (int)lst.size(), conv, s);
+                if (rc != DN_OK) return rc;
+            }
+            for (size_t q = i + 1; q < p->ops.size(); ++q)
+                if (record) (void)hipEventRecord(p->events[ev++], s);
+            break;
+        }
         if (p->fused_len[i] > 0) {
             const int kind = p->fused_kind[i], len = p->fused_len[i];
             const dn_op_desc* e = (kind & 1) ? &p->ops[i] : nullptr;
@@ -453,41 +559,12 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 rc = launch_stem(a, s);
                 break;
             }
-            case DN_OP_PW: {
-                PwArgs a;
-                a.x = reinterpret_cast<const half_t*>(tptr(o.in));
-                a.w = reinterpret_cast<const half_t*>(W + o.w_off);
-                a.bias = reinterpret_cast<const float*>(W + o.b_off);
-                a.residual = o.residual >= 0 ? reinterpret_cast<const half_t*>(tptr(o.residual)) : nullptr;
-                a.se = o.se >= 0 ? reinterpret_cast<const float*>(tptr(o.se)) : nullptr;
-                a.hw = ti.h * ti.w;
-                a.m = n * a.hw;
-                a.cin = o.cin; a.cout = o.cout; a.act = o.act;
-                if (o.head) {
-                    const int cols = (o.head == 1) ? d.num_classes : 4;
-                    a.out = (o.head == 1) ? (void*)logits : (void*)reg;
-                    a.out_fp32 = 1;
-                    a.out_img_stride = (long)d.num_anchors * cols;
-                    a.out_base = (long)p->level_off[o.level] * cols;
-                } else {
-                    a.out = tptr(o.out);
-                    a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
-                }
-                rc = launch_pointwise(a, s);
+            case DN_OP_PW:
+                rc = launch_pointwise(make_pw(o), s);
                 break;
-            }
-            case DN_OP_DW: {
-                DwArgs a;
-                a.x = reinterpret_cast<const half_t*>(tptr(o.in));
-                a.w = reinterpret_cast<const half_t*>(W + o.w_off);
-                a.bias = reinterpret_cast<const float*>(W + o.b_off);
-                a.out = reinterpret_cast<half_t*>(tptr(o.out));
-                a.n = n; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
-                a.ho = to.h; a.wo = to.w;
-                a.pool = o.pool >= 0 ? reinterpret_cast<float*>(tptr(o.pool)) : nullptr;
-                rc = launch_depthwise(a, s);
+            case DN_OP_DW:
+                rc = launch_depthwise(make_dw(o), s);
                 break;
-            }
             case DN_OP_SE: {
                 rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), p->pool_blocks[o.in], reinterpret_cast<const float*>(W + o.w_off),
                                   reinterpret_cast<const float*>(W + o.b_off), reinterpret_cast<const float*>(W + o.w2_off),
@@ -495,26 +572,9 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                                   o.cin, o.squeeze, o.pool_pixels, s);
                 break;
             }
-            case DN_OP_CONV: {
-                ConvArgs a;
-                a.x = reinterpret_cast<const half_t*>(tptr(o.in));
-                a.w = reinterpret_cast<const half_t*>(W + o.w_off);
-                a.bias = reinterpret_cast<const float*>(W + o.b_off);
-                a.n = n; a.h = ti.h; a.w_ = ti.w; a.cin = o.cin; a.cout = o.cout; a.k = o.k; a.stride = o.stride;
-                a.pad = o.pad; a.dil = o.dil; a.act = o.act; a.ho = to.h; a.wo = to.w;
-                if (o.head) {
-                    const int cols = (o.head == 1) ? d.num_classes : 4;
-                    a.out = (o.head == 1) ? (void*)logits : (void*)reg;
-                    a.out_fp32 = 1;
-                    a.out_img_stride = (long)d.num_anchors * cols;
-                    a.out_base = (long)p->level_off[o.level] * cols;
-                } else {
-                    a.out = tptr(o.out);
-                    a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
-                }
-                rc = launch_conv(a, s);
+            case DN_OP_CONV:
+                rc = launch_conv(make_conv(o), s);
                 break;
-            }
             case DN_OP_MAXPOOL:
                 rc = launch_maxpool(reinterpret_cast<const half_t*>(tptr(o.in)), reinterpret_cast<half_t*>(tptr(o.out)), n,
                                     ti.h, ti.w, ti.c, o.k, o.stride, o.pad, to.h, to.w, s);

@@ -17,7 +17,7 @@
 
 static long long* g_pw_stamps = nullptr;     // dev hook (tools/probe_pw_stamps.py): per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_pw_stamps(void* dev_ptr) { g_pw_stamps = (long long*)dev_ptr; }
-#define PW_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define PW_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)by * gridDim.x + bx) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 namespace {
 
@@ -26,17 +26,15 @@ namespace {
 // K runs over (ky, kx, cin) with the weight stored [cout][ky][kx][cin]; each 32-deep K stage lies inside one tap
 // (cin % 32 == 0), so the pixel tile of a stage is the NHWC rows of the tap-shifted input pixels (zeros outside).
 template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
-__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
+__device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
-    constexpr int CPR = BK / 8;         // 16-B chunks per row per stage
-    constexpr int CSH = (BK == 32) ? 2 : (BK == 64) ? 3 : 4;
+    constexpr int CPR = BK / 8;         // 16-B chunks per row per stage (any multiple of 2: divisions by a constant)
     constexpr int TP = BP / WP / 32;    // 32-pixel MFMA tiles per wave
     constexpr int TC = BC / WC / 32;    // 32-channel MFMA tiles per wave
-    constexpr int NX = BP * CPR / 256;  // 16-B chunks of the pixel tile per thread per stage
-    constexpr int NW = BC * CPR / 256;  // 16-B chunks of the weight tile per thread per stage
-    static_assert(NX >= 1 && NW >= 0, "tile too small");
-    constexpr int NWc = NW > 0 ? NW : 1;
+    constexpr int NX = (BP * CPR + 255) / 256;  // 16-B chunks of the pixel tile per thread per stage (last may be partial)
+    constexpr int NW = (BC * CPR + 255) / 256;  // 16-B chunks of the weight tile per thread per stage
+    constexpr int NWc = NW;
     extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];      // bias[BC] floats, then [1|2][(BP + BC) * LDS_ROW] halfs
     float* bsh = reinterpret_cast<float*>(lds_raw);
     half_t* lds_dyn = lds_raw + 2 * BC;
@@ -47,8 +45,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     const int wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC;
     const int r = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * BP;
-    const int n0 = blockIdx.y * BC;
+    const int m0 = bx * BP;
+    const int n0 = by * BC;
     const int M = a.m, K = a.cin, NC = a.cout;
     const int dbg = a.act >> 8;            // probe-only knobs: 1 = skip stores, 2 = skip global loads of x
     a.act &= 0xff;
@@ -67,7 +65,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     if constexpr (CONV) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int m = m0 + ((tid + 256 * i) >> CSH);
+            const int m = m0 + (tid + 256 * i) / CPR;
             const int img = m / a.hw, rem = m - img * a.hw;
             const int oy = rem / a.cv_wo, ox = rem - oy * a.cv_wo;
             cvn[i] = img;
@@ -88,8 +86,8 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + 256 * i;
-            const int row = c >> CSH, q = c & (CPR - 1);
-            const int m = m0 + row, k = k0 + q * 8;
+            const int row = c / CPR, q = c - row * CPR;
+            const int m = (row < BP) ? m0 + row : M, k = k0 + q * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
             if constexpr (CONV) {
                 const int iy = cvy[i] + dy, ix = cvx[i] + dx;
@@ -107,39 +105,28 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
             }
             sx[i] = v;
         }
-        if constexpr (NW > 0) {
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const int c = tid + 256 * i;
-                const int row = c >> CSH, q = c & (CPR - 1);
-                const int n = n0 + row, k = k0 + q * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
-                sw[i] = v;
-            }
-        } else {
-            // BC*CPR < 256: only the first BC*CPR threads carry a weight chunk
-            const int row = tid >> CSH, q = tid & (CPR - 1);
+        for (int i = 0; i < NW; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, q = c - row * CPR;
             const int n = n0 + row, k = k0 + q * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (tid < BC * CPR && n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
-            sw[0] = v;
+            if (row < BC && n < NC && k < K) v = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k);
+            sw[i] = v;
         }
     };
     auto store_stage = [&](int b) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + 256 * i;
-            *reinterpret_cast<uint4*>(&lds[b][(c >> CSH) * LDS_ROW + (c & (CPR - 1)) * 8]) = sx[i];
+            const int row = c / CPR, q = c - row * CPR;
+            if (row < BP) *reinterpret_cast<uint4*>(&lds[b][row * LDS_ROW + q * 8]) = sx[i];
         }
-        if constexpr (NW > 0) {
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                const int c = tid + 256 * i;
-                *reinterpret_cast<uint4*>(&lds[b][(BP + (c >> CSH)) * LDS_ROW + (c & (CPR - 1)) * 8]) = sw[i];
-            }
-        } else {
-            if (tid < BC * CPR) *reinterpret_cast<uint4*>(&lds[b][(BP + (tid >> CSH)) * LDS_ROW + (tid & (CPR - 1)) * 8]) = sw[0];
+        for (int i = 0; i < NW; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, q = c - row * CPR;
+            if (row < BC) *reinterpret_cast<uint4*>(&lds[b][(BP + row) * LDS_ROW + q * 8]) = sw[i];
         }
     };
 
@@ -302,6 +289,32 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
         }
     }
     PW_STAMP(3);
+}
+
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
+__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
+    pw_body<BP, BC, WP, WC, CONV, BK>(a, blockIdx.x, blockIdx.y);
+}
+
+// Grouped launch: up to 8 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
+// The fixed cost of a launch chain (~9 us per dependent launch at any batch size) dominates the small levels; here
+// their workgroups simply ride along with level 0's. blockIdx.x is flat; start[] are prefix sums of workgroup counts.
+struct PwGroup {
+    int count;
+    int start[9];
+    int gx[8];
+    PwArgs a[8];
+};
+
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
+__global__ __launch_bounds__(256) void pw_group_kernel(PwGroup g) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
+    const int local = blockIdx.x - g.start[p];
+    const int gx = g.gx[p];
+    pw_body<BP, BC, WP, WC, CONV, BK>(g.a[p], local % gx, local / gx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -522,12 +535,20 @@ int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
 template <int BP, int BC, int WP, int WC, bool CONV>
 int launch_cfg(const PwArgs& a, hipStream_t s) {
     const_cast<PwArgs&>(a).stamps = g_pw_stamps;
-    static const int fullk = getenv("DN_PW_FULLK") ? atoi(getenv("DN_PW_FULLK")) : 0;   // measured slower: off
+    static const int fullk = getenv("DN_PW_FULLK") ? atoi(getenv("DN_PW_FULLK")) : 0;   // single-stage K measured slower (no load/compute overlap): off
     const bool conv_ok64 = !CONV || a.cv_cin % 64 == 0, conv_ok128 = !CONV || a.cv_cin % 128 == 0;
-    if (fullk && a.cin <= 32) return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 1);
-    if (fullk && a.cin <= 64 && conv_ok64) return launch_bk<BP, BC, WP, WC, CONV, 64>(a, s, 1);
-    if constexpr (BP + BC <= 192) {
-        if (fullk && a.cin <= 128 && conv_ok128) return launch_bk<BP, BC, WP, WC, CONV, 128>(a, s, 1);
+    (void)conv_ok64; (void)conv_ok128;
+    if constexpr (!CONV) {
+        // exact-K single stage: one memory round trip per workgroup, LDS footprint ~ the 32-deep double buffer
+        if (fullk && a.cin <= 32) return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 1);
+        if (fullk && a.cin <= 48) return launch_bk<BP, BC, WP, WC, CONV, 48>(a, s, 1);
+        if (fullk && a.cin <= 64) return launch_bk<BP, BC, WP, WC, CONV, 64>(a, s, 1);
+        if (fullk && a.cin <= 80) return launch_bk<BP, BC, WP, WC, CONV, 80>(a, s, 1);
+        if (fullk && a.cin <= 96) return launch_bk<BP, BC, WP, WC, CONV, 96>(a, s, 1);
+        if (fullk && a.cin <= 112) return launch_bk<BP, BC, WP, WC, CONV, 112>(a, s, 1);
+        if constexpr (BP + BC <= 192) {
+            if (fullk && a.cin <= 128) return launch_bk<BP, BC, WP, WC, CONV, 128>(a, s, 1);
+        }
     }
     return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 2);
 }
@@ -555,6 +576,46 @@ int launch_select(const PwArgs& a, hipStream_t s) {
     return launch_cfg<64, 64, 2, 2, CONV>(a, s);
 }
 
+namespace {
+template <int BP, int BC, int WP, int WC, bool CONV>
+int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
+    PwGroup g{};
+    g.count = count;
+    int acc = 0;
+    for (int i = 0; i < count; ++i) {
+        g.a[i] = arr[i];
+        g.a[i].stamps = nullptr;
+        g.start[i] = acc;
+        g.gx[i] = dn_cdiv(arr[i].m, BP);
+        acc += g.gx[i] * dn_cdiv(arr[i].cout, BC);
+    }
+    g.start[count] = acc;
+    size_t halfs = (size_t)2 * (BP + BC) * 40;
+    const size_t otile = (size_t)BP * (BC + 8);
+    if (otile > halfs) halfs = otile;
+    const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
+    hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, 32>), dim3(acc), dim3(256), lds, s, g);
+    return DN_OK;
+}
+}  // namespace
+
+// All problems must be of the same kind (pointwise or implicit-GEMM conv); the tile is chosen for the widest one.
+int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t s) {
+    DN_REQUIRE(count >= 1 && count <= 8, "pointwise group: %d problems", count);
+    int maxc = 0;
+    long wg128 = 0;
+    for (int i = 0; i < count; ++i) {
+        DN_REQUIRE(arr[i].cin % 8 == 0 && arr[i].m > 0, "pointwise group: bad problem %d", i);
+        DN_REQUIRE(!conv || arr[i].cv_cin % 32 == 0, "conv group: cin=%d must be a multiple of 32", arr[i].cv_cin);
+        if (arr[i].cout > maxc) maxc = arr[i].cout;
+        wg128 += (long)dn_cdiv(arr[i].m, 128) * dn_cdiv(arr[i].cout, 128);
+    }
+    if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
+    if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
+    if (wg128 >= 1500) return conv ? launch_group_cfg<128, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
+    return conv ? launch_group_cfg<64, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
+}
+
 int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.cin % 8 == 0, "pointwise: cin=%d must be a multiple of 8", a.cin);
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
@@ -565,6 +626,18 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
         return launch_xs<32>(a, s);
     }
     return launch_select<false>(a, s);
+}
+
+PwArgs conv_to_pw(const ConvArgs& c) {
+    PwArgs a;
+    a.cv_k = c.k; a.cv_stride = c.stride; a.cv_pad = c.pad; a.cv_dil = c.dil; a.cv_h = c.h; a.cv_w = c.w_;
+    a.cv_ho = c.ho; a.cv_wo = c.wo; a.cv_cin = c.cin;
+    a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out;
+    a.hw = c.ho * c.wo;
+    a.m = c.n * a.hw;
+    a.cin = c.k * c.k * c.cin;
+    a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
+    return a;
 }
 
 int launch_conv(const ConvArgs& c, hipStream_t s) {
