@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16
+DEFAULT_MODEL, DEFAULT_BATCH = "ssdlite320_mobilenet_v3_large", 64   # BASELINE.json configs[1]
 
 
 def op_costs(graph, n):
@@ -46,8 +47,7 @@ def op_costs(graph, n):
             if nd.residual >= 0:
                 b += 2 * m * nd.cout
             f = 2 * m * kk * nd.cout
-            cfg = "256x32" if nd.cout <= 32 else ("128x64" if nd.cout <= 64 else "128x128")
-            kern = f"pw_kernel<{cfg}{',conv' if nd.op == 'conv' else ''}>"
+            kern = "pw_kernel"
         elif nd.op == "dw":
             b = 2 * n * (ti.h * ti.w + to.h * to.w) * nd.cin + 2 * nd.k * nd.k * nd.cin + 4 * nd.cin
             if nd.pool >= 0:
@@ -105,8 +105,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--model", default="ssdlite320_mobilenet_v3_large")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="images per GPU per step")
+    ap.add_argument("--model", default=DEFAULT_MODEL)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
@@ -178,7 +178,7 @@ def main():
         "dtype": "fp16", "data": "synthetic",
         "config": {"workload": f"{args.model} fp16, batch {B} per GPU, {H}x{W} synthetic images, K={ncls}, "
                                f"synthetic weights seed 0, post-process incl. per-class top-{g.post['topk_candidates']} + hard NMS",
-                   "global_batch": B * world, "launch": "eager" if args.eager else "hipGraph replay",
+                   "global_batch": B * world, "launch": ("eager" if args.eager else "hipGraph replay") + f", {model.batch_split(B)} sub-batch branch(es)",
                    "parallelism": f"image-sharded x{world}, RCCL all_gather of detections" if distributed else "single GPU",
                    "mean_detections": float(counts.float().mean().item())},
     }
@@ -195,33 +195,72 @@ def main():
         buf = (C.c_float * nseg)()
         runs = _lib.check(L.dn_profile_end(h, buf, nseg))
         costs = op_costs(g, B)
-        grp = (C.c_int32 * len(g.nodes))()
-        _lib.check(L.dn_op_groups(h, grp, len(g.nodes)))
-        for i in range(len(g.nodes)):
-            if grp[i] >= 0:
-                costs[i]["kernel"] = "mega_kernel (per-image tail runs)"
+        split = _lib.check(L.dn_batch_split(h, B))     # every kernel runs once per sub-batch branch
+        # the library reports which kernel each op launched and which op's event segment holds a grouped launch's time
+        name = C.create_string_buffer(96)
+        owner = C.c_int32()
+        post = ["softmax_decode_kernel", "select_nms_fast_kernel (+tau, fallback select)", "merge_kernel"]
         agg = {}
-        for c, ms in zip(costs, buf):
+        for i, c in enumerate(costs):
+            if i < len(g.nodes):
+                _lib.check(L.dn_profile_op_info(h, i, name, 96, C.byref(owner)))
+                c["kernel"], c["owner"] = name.value.decode(), owner.value
+            else:
+                c["kernel"], c["owner"] = post[i - len(g.nodes)], i
+        owners = {}
+        for i, c in enumerate(costs):
             a = agg.setdefault(c["kernel"], dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
-            a["ms"] += ms
             a["bytes"] += c["bytes"]
             a["flops"] += c["flops"]
-            a["launches"] += 1
+            if c["owner"] not in owners:
+                owners[c["owner"]] = c["kernel"]
+                a["ms"] += buf[c["owner"]]          # summed over the sub-batch launches of one forward
+                a["launches"] += split
         if args.per_op:
             with open(args.per_op, "w") as f:
                 names = [f"{nd.op}:{nd.conv_key or nd.fc1_key or nd.scale_key}" for nd in g.nodes] + ["softmax_decode", "select_nms", "merge"]
-                for i, (c, ms, nm) in enumerate(zip(costs, buf, names)):
+                members = {}
+                for i, c in enumerate(costs):
+                    members.setdefault(c["owner"], []).append(i)
+                for i, (c, nm) in enumerate(zip(costs, names)):
                     nd = g.nodes[i] if i < len(g.nodes) else None
                     shp = f"{g.t(nd.inp).c}x{g.t(nd.inp).h}x{g.t(nd.inp).w}->{g.t(nd.out).c}x{g.t(nd.out).h}x{g.t(nd.out).w} k{nd.k}s{nd.stride}" if nd else ""
+                    if len(members[c["owner"]]) > 1:      # member of a grouped launch: timed as a whole below
+                        f.write(f"{i:3d} {nm:58s} {shp:34s}  (slot {c['owner']:3d}) {c['bytes'] / 1e6:8.1f} MB {'':26s}  {c['kernel']}\n")
+                        continue
+                    ms = buf[i]
                     f.write(f"{i:3d} {nm:58s} {shp:34s} {ms * 1e3:8.1f} us {c['bytes'] / 1e6:8.1f} MB {c['bytes'] / max(ms, 1e-9) / 1e6:8.0f} GB/s {c['flops'] / max(ms, 1e-9) / 1e9:7.1f} TF/s  {c['kernel']}\n")
+                for slot, mem in sorted(members.items()):
+                    if len(mem) < 2:
+                        continue
+                    ms = buf[slot]
+                    gb = sum(costs[i]["bytes"] for i in mem)
+                    fl = sum(costs[i]["flops"] for i in mem)
+                    f.write(f"grouped launch, slot {slot:3d}: ops {mem}  {ms * 1e3:8.1f} us {gb / 1e6:8.1f} MB {gb / max(ms, 1e-9) / 1e6:8.0f} GB/s {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s  {costs[mem[0]]['kernel']}\n")
         total_ms = sum(a["ms"] for a in agg.values())
         dom = max(agg, key=lambda k: agg[k]["ms"])
         d = agg[dom]
-        ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+        # which roof bounds the dominant kernel: arithmetic intensity against the machine balance (2500 TF/s / 8 TB/s = 312 flop/B)
+        mfma_bound = d["flops"] / max(d["bytes"], 1.0) > MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+        if mfma_bound:
+            ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        traffic, traffic_src = None, None
+        if args.model == DEFAULT_MODEL and B == DEFAULT_BATCH:
+            # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc_collect.sh + tools/pmc_traffic.py)
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+                with open(path) as f:
+                    tk = json.load(f)["kernels"]
+                if dom in tk:
+                    traffic, traffic_src = tk[dom]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                    break
+        result["roofline"] = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                              "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                               "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
                               "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                              "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
                               "share_of_step": round(d["ms"] / total_ms, 3), "profiled_runs": runs,
                               "eager_sum_ms": round(total_ms, 4)}
         result["kernels"] = {k: {"ms": round(v["ms"], 4), "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),

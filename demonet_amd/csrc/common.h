@@ -13,6 +13,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 void dn_set_error(const char* fmt, ...);
+// label of the kernel the last launcher call on this thread enqueued (bench.py's roofline names; matches rocprofv3's kernel names)
+void dn_note_kernel(const char* fmt, ...);
+const char* dn_last_kernel();
 
 #define DN_HIP_CHECK(expr)                                                                   \
     do {                                                                                     \

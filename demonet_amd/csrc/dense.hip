@@ -96,12 +96,14 @@ int launch_maxpool(const half_t* x, half_t* out, int n, int h, int w, int c, int
                    hipStream_t s) {
     DN_REQUIRE(c % 8 == 0, "maxpool: c=%d must be a multiple of 8", c);
     const long threads = (long)n * ho * wo * (c / 8);
+    dn_note_kernel("maxpool_kernel");
     hipLaunchKernelGGL(maxpool_kernel, dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, x, out, n, h, w, c, k, stride, pad, ho, wo);
     return DN_OK;
 }
 
 int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels, int c, hipStream_t s) {
     DN_REQUIRE(c % 8 == 0, "l2norm: c=%d must be a multiple of 8", c);
+    dn_note_kernel("l2norm_kernel");
     hipLaunchKernelGGL(l2norm_kernel, dim3(dn_cdiv(pixels, 4)), dim3(256), 0, s, x, scale, out, pixels, c);
     return DN_OK;
 }

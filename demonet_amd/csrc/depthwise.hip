@@ -129,6 +129,7 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
         acc += dn_cdiv((long)arr[i].ho * ((arr[i].wo + TW - 1) / TW) * (arr[i].c / 8), 256);
     }
     g.start[count] = acc;
+    dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
     hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].n), dim3(256), 0, s, g);
     return DN_OK;
 }
@@ -136,6 +137,7 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
 template <int K, int S, int TW>
 int launch_dw(const DwArgs& a, hipStream_t s) {
     const long threads = (long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8);       // per image
+    dn_note_kernel("dw_kernel<%d,%d,%d>", K, S, TW);
     hipLaunchKernelGGL((dw_kernel<K, S, TW>), dim3(dn_cdiv(threads, 256), a.n), dim3(256), a.pool ? 256 * 8 * 4 : 0, s, a);
     return DN_OK;
 }
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
 
 template <int COUT, int K>
 int launch_stem_t(const StemArgs& a, hipStream_t s) {
+    dn_note_kernel("stem_kernel<%d,%d>", COUT, K);
     hipLaunchKernelGGL((stem_kernel<COUT, K>), dim3(dn_cdiv((long)a.ho * a.wo, 256), a.n), dim3(256), 0, s, a);
     return DN_OK;
 }
@@ -317,6 +320,7 @@ int depthwise_pool_blocks(const DwArgs& a) {
 int launch_se_fc(const float* partial, int nblk, const float* w1, const float* b1, const float* w2, const float* b2, float* scale,
                  int n, int c, int squeeze, int pool_pixels, hipStream_t s) {
     DN_REQUIRE(c <= 1024 && squeeze <= 256, "se: c=%d squeeze=%d exceed the kernel's register tiles", c, squeeze);
+    dn_note_kernel("se_fc_kernel");
     hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(1024), (size_t)(c + squeeze) * sizeof(float), s, partial, nblk, w1, b1, w2, b2,
                        scale, c, squeeze, 1.0f / (float)pool_pixels);
     return DN_OK;

@@ -379,6 +379,7 @@ int launch_tkm(const FusedArgs& a, hipStream_t s, size_t lds) {
         attr = true;
     }
     dim3 grid(dn_cdiv(a.Wo, TW), dn_cdiv(a.Ho, TH), a.n);
+    dn_note_kernel("fused_kernel<%d,%d,%d,%d>", TH, TW, K, MAXT);
     hipLaunchKernelGGL((fused_kernel<TH, TW, K, MAXT>), grid, dim3(FT), lds, s, a);
     return DN_OK;
 }

@@ -325,6 +325,7 @@ __global__ __launch_bounds__(MEGA_THREADS) void mega_kernel(const MegaOp* __rest
 }  // namespace
 
 int launch_mega(const MegaOp* ops_dev, int first, int count, int n, unsigned char* ws, const unsigned char* wts, hipStream_t s) {
+    dn_note_kernel("mega_kernel");
     hipLaunchKernelGGL(mega_kernel, dim3(n), dim3(MEGA_THREADS), MEGA_THREADS * 8 * sizeof(float), s, ops_dev, first, count, ws, wts);
     return DN_OK;
 }

@@ -14,6 +14,15 @@
 // ---------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
+static thread_local char g_kernel[96] = "";
+void dn_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+const char* dn_last_kernel() { return g_kernel; }
+
 void dn_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -64,6 +73,10 @@ struct dn_plan {
     std::vector<int> op_wait_level;         // head-chain op reading a feature map: its level, else -1
     std::vector<int> op_feat_level;         // main op producing a feature map: its level, else -1
     bool multi_stream = false;
+    int split = 2;                          // sub-batch branches per forward (see batch_split)
+    hipStream_t branch_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_branch[3] = {nullptr, nullptr, nullptr};
+    std::map<std::pair<int, int>, Layout> sub_layouts;
     // runs of consecutive small ops executed by one per-image workgroup (mega.hip)
     std::vector<int> op_group;              // group id per op or -1
     std::vector<int> group_first, group_count;
@@ -80,8 +93,20 @@ struct dn_plan {
     bool profiling = false;
     std::vector<hipEvent_t> events;
     std::vector<double> prof_ms;
+    std::vector<std::string> prof_kernel;   // label of the launch each op took part in
+    std::vector<int> prof_owner;            // op index whose event segment holds that launch's time
     int prof_runs = 0;
 };
+
+// The launch chain is latency-bound (~70 dependent launches, most of them far from filling 256 CUs), so a forward of n images
+// is issued as `split` independent sub-batch chains that the hipGraph runs as parallel branches (measured +6 % at n = 64 with
+// two branches; more branches lose again, and below 32 images there is nothing to gain). Every workspace tensor is
+// image-major, so a sub-batch simply addresses rows [n0, n0 + ns) of the same layout.
+static int batch_split(const dn_plan* p, int n) {
+    if (p->split <= 1 || n < 32 || p->multi_stream || !p->group_first.empty()) return 1;
+    return p->split;
+}
+static int sub_count(int n, int S, int k) { const int base = n / S, rem = n % S; return base + (k < rem ? 1 : 0); }
 
 static const Layout& get_layout(dn_plan* p, int n) {
     auto it = p->layouts.find(n);
@@ -112,7 +137,11 @@ static const Layout& get_layout(dn_plan* p, int n) {
     L.scale_off = off;
     off += align256((size_t)n * 2 * 4);
     L.post_off = off;
-    L.post_bytes = postprocess_ws_bytes(n, p->d.num_anchors, p->d.num_classes, p->d.topk_candidates, p->d.detections_per_img);
+    {
+        const int S = batch_split(p, n);          // one private post-process scratch slice per sub-batch branch
+        L.post_bytes = (size_t)S * align256(postprocess_ws_bytes(sub_count(n, S, 0), p->d.num_anchors, p->d.num_classes,
+                                                                 p->d.topk_candidates, p->d.detections_per_img));
+    }
     off += align256(L.post_bytes);
     L.total = off;
     L.mega_index.assign(p->ops.size(), -1);
@@ -294,6 +323,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         else { p->head_dw.clear(); p->head_cls.clear(); p->head_reg.clear(); }
     }
     p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
+    p->split = getenv("DN_SPLIT") ? atoi(getenv("DN_SPLIT")) : 2;
+    if (p->split < 1) p->split = 1;
+    if (p->split > 4) p->split = 4;
     p->mega_enabled = getenv("DN_MEGA") ? atoi(getenv("DN_MEGA")) != 0 : false;   // measured slower than launches: opt-in
     p->op_group.assign(desc->n_ops, -1);
     p->se_inplace_pw.assign(desc->n_ops, -1);
@@ -357,6 +389,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_feat[i], hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->branch_stream[i], hipStreamNonBlocking);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_branch[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
     if (e != hipSuccess) {
         dn_set_error("dn_create: stream/event creation failed: %s", hipGetErrorString(e));
         return fail(DN_E_HIP);
@@ -375,6 +410,9 @@ extern "C" void dn_destroy(dn_plan* p) {
     for (int i = 0; i < 2; ++i) if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
     for (int i = 0; i < 8; ++i) if (p->ev_feat[i]) (void)hipEventDestroy(p->ev_feat[i]);
     for (int i = 0; i < 2; ++i) if (p->ev_join[i]) (void)hipEventDestroy(p->ev_join[i]);
+    for (int i = 0; i < 3; ++i) if (p->branch_stream[i]) (void)hipStreamDestroy(p->branch_stream[i]);
+    for (int i = 0; i < 3; ++i) if (p->ev_branch[i]) (void)hipEventDestroy(p->ev_branch[i]);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     for (auto ev : p->events) (void)hipEventDestroy(ev);
     if (p->weights_dev) (void)hipFree(p->weights_dev);
     if (p->anchors_dev) (void)hipFree(p->anchors_dev);
@@ -392,11 +430,43 @@ extern "C" int dn_set_graph_mode(dn_plan* p, int enabled) {
     return DN_OK;
 }
 
+// view of rows [n0, n0 + ns) of the n-image layout, as a layout of its own (branch k of S)
+static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
+    auto key = std::make_pair(n, k);
+    auto it = p->sub_layouts.find(key);
+    if (it != p->sub_layouts.end()) return it->second;
+    const Layout& L = get_layout(p, n);
+    int n0 = 0;
+    for (int q = 0; q < k; ++q) n0 += sub_count(n, S, q);
+    const int ns = sub_count(n, S, k);
+    Layout V;
+    V.n = ns;
+    V.toff = L.toff;
+    V.tbytes = L.tbytes;
+    for (size_t t = 0; t < L.toff.size(); ++t) {
+        if (L.toff[t] == (size_t)-1) continue;
+        const size_t per = L.tbytes[t] / (size_t)n;
+        V.toff[t] = L.toff[t] + (size_t)n0 * per;
+        V.tbytes[t] = (size_t)ns * per;
+    }
+    V.resized_off = L.resized_off + (size_t)n0 * 3 * p->d.image_h * p->d.image_w * 4;
+    V.logits_off = L.logits_off + (size_t)n0 * p->d.num_anchors * p->d.num_classes * 4;
+    V.reg_off = L.reg_off + (size_t)n0 * p->d.num_anchors * 16;
+    V.scale_off = L.scale_off + (size_t)n0 * 8;
+    const size_t slice = L.post_bytes / (size_t)S;
+    V.post_off = L.post_off + (size_t)k * slice;
+    V.post_bytes = slice;
+    V.total = L.total;
+    V.mega_index.assign(p->ops.size(), -1);
+    return p->sub_layouts.emplace(key, std::move(V)).first->second;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // the launch sequence
 // ---------------------------------------------------------------------------------------------------------
 static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
-                   int32_t* counts, unsigned char* ws, const Layout& L, bool heads_only, hipStream_t s, bool record) {
+                   int32_t* counts, unsigned char* ws, const Layout& L, bool heads_only, hipStream_t s, bool record,
+                   float* packed, int ev0 = 0) {
     const dn_model_desc& d = p->d;
     auto tptr = [&](int tid) -> void* { return ws + L.toff[tid]; };
     const float* net_in = images;
@@ -471,7 +541,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         }
         return a;
     };
-    int ev = 0;
+    int ev = ev0;
     hipStream_t const main_stream = s;
     const bool ms = p->multi_stream && !record;
     bool side_used[2] = {false, false};
@@ -489,13 +559,23 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         if (record) (void)hipEventRecord(p->events[ev++], s);
         int rc = DN_OK;
         const unsigned char* W = p->weights_dev;
+        auto note = [&](size_t op, size_t owner) {
+            if (!record) return;
+            p->prof_kernel[op] = dn_last_kernel();
+            p->prof_owner[op] = (int)owner;
+        };
         if ((int)i == p->head_first) {
-            // all remaining ops are head ops of the pyramid levels: three grouped launches instead of up to 28
+            // all remaining ops are head ops of the pyramid levels: three grouped launches instead of up to 28.
+            // Profiling: the three launches take the event segments of ops i, i+1, i+2 (prof_owner maps members to them).
+            size_t seg = i;
             if (!p->head_dw.empty()) {
                 DwArgs arr[12];
                 for (size_t q = 0; q < p->head_dw.size(); ++q) arr[q] = make_dw(p->ops[p->head_dw[q]]);
                 rc = launch_depthwise_group(arr, (int)p->head_dw.size(), s);
                 if (rc != DN_OK) return rc;
+                for (int q : p->head_dw) note(q, seg);
+                ++seg;
+                if (record) (void)hipEventRecord(p->events[ev++], s);
             }
             for (int kind = 0; kind < 2; ++kind) {
                 const std::vector<int>& lst = kind ? p->head_cls : p->head_reg;
@@ -506,8 +586,11 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                     arr[q] = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
                 rc = launch_pointwise_group(arr, (int)lst.size(), conv, s);
                 if (rc != DN_OK) return rc;
+                for (int q : lst) note(q, seg);
+                ++seg;
+                if (record && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], s);
             }
-            for (size_t q = i + 1; q < p->ops.size(); ++q)
+            for (size_t q = seg + 1; q < p->ops.size(); ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             break;
         }
@@ -531,6 +614,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             a.has_res = (pj && pj->residual >= 0) ? 1 : 0;
             rc = launch_fused(a, s);
             if (rc != DN_OK) return rc;
+            for (int q = 0; q < len; ++q) note(i + q, i);
             for (int q = 1; q < len; ++q) {
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             }
@@ -543,6 +627,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 rc = launch_mega(L.mega_dev, L.mega_index[i], p->group_count[g], n, ws, W, s);
                 if (rc != DN_OK) return rc;
             }
+            note(i, p->group_first[g]);
             if (ms && p->op_feat_level[i] >= 0) DN_HIP_CHECK(hipEventRecord(p->ev_feat[p->op_feat_level[i]], main_stream));
             continue;
         }
@@ -585,6 +670,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 break;
         }
         if (rc != DN_OK) return rc;
+        note(i, i);
         if (ms && p->op_feat_level[i] >= 0) DN_HIP_CHECK(hipEventRecord(p->ev_feat[p->op_feat_level[i]], main_stream));
     }
     s = main_stream;
@@ -603,7 +689,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         if (resize) a.scale_xy = scale_xy;
         a.score_thresh = d.score_thresh; a.nms_thresh = d.nms_thresh; a.topk = d.topk_candidates; a.dets = d.detections_per_img;
         a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = nullptr;
-        a.packed = p->packed_out;
+        a.packed = packed;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
@@ -620,6 +706,36 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     return DN_OK;
 }
 
+// the whole forward: one chain, or batch_split() sub-batch chains forked onto branch streams (parallel graph branches when
+// captured). record = profiling: the sub-batches run back to back on `s`, each with its own block of events.
+static int enqueue_all(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
+                       int32_t* counts, unsigned char* ws, bool heads_only, hipStream_t s, bool record) {
+    const int S = batch_split(p, n);
+    if (S == 1) return enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, get_layout(p, n), heads_only, s, record, p->packed_out, 0);
+    const size_t D = (size_t)p->d.detections_per_img;
+    const int ev_stride = (int)p->ops.size() + 5;
+    if (!record) DN_HIP_CHECK(hipEventRecord(p->ev_fork, s));
+    size_t n0 = 0;
+    for (int k = 0; k < S; ++k) {
+        const int ns = sub_count(n, S, k);
+        const Layout& V = get_sub_layout(p, n, S, k);
+        hipStream_t bs = s;
+        if (!record && k > 0) {
+            bs = p->branch_stream[k - 1];
+            DN_HIP_CHECK(hipStreamWaitEvent(bs, p->ev_fork, 0));
+        }
+        int rc = enqueue(p, images + n0 * 3 * (size_t)h * w, ns, h, w, boxes ? boxes + n0 * D * 4 : nullptr, scores ? scores + n0 * D : nullptr,
+                         labels ? labels + n0 * D : nullptr, counts ? counts + n0 : nullptr, ws, V, heads_only, bs, record,
+                         p->packed_out ? p->packed_out + n0 * (D + 1) * 6 : nullptr, k * ev_stride);
+        if (rc) return rc;
+        if (!record && k > 0) DN_HIP_CHECK(hipEventRecord(p->ev_branch[k - 1], bs));
+        n0 += ns;
+    }
+    if (!record)
+        for (int k = 1; k < S; ++k) DN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_branch[k - 1], 0));
+    return DN_OK;
+}
+
 static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
                         int32_t* counts, void* workspace, size_t ws_bytes, void* stream, bool heads_only) {
     DN_REQUIRE(p && images && workspace, "dn_forward: null argument");
@@ -633,38 +749,43 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     if (p->profiling) {
-        const size_t need = p->ops.size() + 5;
+        const int S = batch_split(p, n);
+        const size_t stride = p->ops.size() + 5;
+        const size_t need = stride * S;
         while (p->events.size() < need) {
             hipEvent_t e;
             DN_HIP_CHECK(hipEventCreate(&e));
             p->events.push_back(e);
         }
-        int rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, true);
+        p->prof_kernel.assign(p->ops.size(), "");
+        p->prof_owner.assign(p->ops.size(), -1);
+        int rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, true);
         if (rc) return rc;
         DN_HIP_CHECK(hipStreamSynchronize(s));
         const size_t nseg = heads_only ? p->ops.size() : p->ops.size() + 3;
         if (p->prof_ms.size() < p->ops.size() + 3) p->prof_ms.assign(p->ops.size() + 3, 0.0);
-        for (size_t i = 0; i < nseg; ++i) {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, p->events[i], p->events[i + 1]);
-            p->prof_ms[i] += ms;
-        }
+        for (int k = 0; k < S; ++k)
+            for (size_t i = 0; i < nseg; ++i) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, p->events[k * stride + i], p->events[k * stride + i + 1]);
+                p->prof_ms[i] += ms;        // per op: summed over the sub-batch launches of one forward
+            }
         p->prof_runs++;
         return DN_OK;
     }
-    if (!p->graph_mode) return enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
+    if (!p->graph_mode) return enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, false);
 
     GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, heads_only ? 1 : 0, p->packed_out};
     auto it = p->graphs.find(key);
     if (it == p->graphs.end()) {
         // first call with this signature: run once eagerly (sets function attributes, validates), then capture
-        int rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, s, false);
+        int rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, false);
         if (rc) return rc;
         hipGraph_t g = nullptr;
         if (!p->capture_stream) DN_HIP_CHECK(hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking));
         hipStream_t cs = p->capture_stream;
         DN_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        rc = enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, L, heads_only, cs, false);
+        rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, cs, false);
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) { dn_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DN_E_HIP; }
@@ -713,6 +834,11 @@ extern "C" int dn_tensor_ptr(const dn_plan* p, void* workspace, int n, int tenso
     return DN_OK;
 }
 
+extern "C" int dn_batch_split(const dn_plan* p, int n) {
+    DN_REQUIRE(p && n > 0, "dn_batch_split: bad argument");
+    return batch_split(p, n);
+}
+
 extern "C" int dn_set_packed_output(dn_plan* p, float* packed_dev) {
     DN_REQUIRE(p, "null plan");
     p->packed_out = packed_dev;
@@ -731,6 +857,14 @@ extern "C" int dn_profile_begin(dn_plan* p) {
     p->profiling = true;
     p->prof_ms.assign(p->ops.size() + 3, 0.0);
     p->prof_runs = 0;
+    return DN_OK;
+}
+
+extern "C" int dn_profile_op_info(const dn_plan* p, int op_index, char* kernel, int capacity, int32_t* owner) {
+    DN_REQUIRE(p && kernel && owner && capacity > 0, "dn_profile_op_info: null argument");
+    DN_REQUIRE(op_index >= 0 && (size_t)op_index < p->prof_kernel.size(), "dn_profile_op_info: op %d not profiled", op_index);
+    snprintf(kernel, (size_t)capacity, "%s", p->prof_kernel[op_index].c_str());
+    *owner = p->prof_owner[op_index];
     return DN_OK;
 }
 

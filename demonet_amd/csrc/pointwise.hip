@@ -15,6 +15,8 @@
 
 #include "common.h"
 
+static int g_pw_tile = 0;                   // dev hook (tools/tune_pw.py): force a tile variant for every launch
+extern "C" __attribute__((visibility("default"))) void dn_debug_pw_tile(int t) { g_pw_tile = t; }
 static long long* g_pw_stamps = nullptr;     // dev hook (tools/probe_pw_stamps.py): per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_pw_stamps(void* dev_ptr) { g_pw_stamps = (long long*)dev_ptr; }
 #define PW_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)by * gridDim.x + bx) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
@@ -220,6 +222,53 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
                     v = *reinterpret_cast<uint4*>(&hv);
                 }
                 *reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(a.out) + (size_t)m * NC + n) = v;
+            }
+        }
+        PW_STAMP(3);
+        return;
+    }
+    if (a.out_fp32 && !(dbg & 1)) {
+        // fp32 head outputs: rows of the [anchor][class] arrays are NC floats long at arbitrary 8-byte alignment, and the
+        // accumulator layout has every lane on a different row -> direct stores touch each 128-B line 8 times. Stage the
+        // tile in LDS ([BP][BC+4] floats over the K-loop buffers) and write row-contiguous float2 runs instead.
+        constexpr int FROW = BC + 4;
+        float* ot = reinterpret_cast<float*>(lds_dyn);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int prow = (wp * TP + j) * 32 + r;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                    const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
+                    float4 v;
+                    v.x = dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
+                    v.y = dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
+                    v.z = dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
+                    v.w = dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                    *reinterpret_cast<float4*>(&ot[prow * FROW + cl]) = v;
+                }
+            }
+        }
+        __syncthreads();
+        float* outp = reinterpret_cast<float*>(a.out);
+        const bool pair_ok = ((NC | (int)(a.out_base & 1) | (int)(a.out_img_stride & 1)) & 1) == 0 &&
+                             (reinterpret_cast<size_t>(outp) & 7) == 0;       // every row start 8-byte aligned
+        constexpr int PPR = BC / 2;                     // float2 per tile row
+#pragma unroll 4
+        for (int c = tid; c < BP * PPR; c += 256) {
+            const int row = c / PPR, cp = (c - row * PPR) * 2;
+            const int m = m0 + row, n = n0 + cp;
+            if (m >= M || n >= NC) continue;
+            const int img = m / a.hw;
+            float* o = outp + (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m - img * a.hw) * NC + n;
+            const float2 v = *reinterpret_cast<const float2*>(&ot[row * FROW + cp]);
+            if (pair_ok && n + 1 < NC) {
+                *reinterpret_cast<float2*>(o) = v;
+            } else {
+                o[0] = v.x;
+                if (n + 1 < NC) o[1] = v.y;
             }
         }
         PW_STAMP(3);
@@ -507,6 +556,7 @@ int launch_xs(const PwArgs& a, hipStream_t s) {
                                          160 * 1024));
         attr = true;
     }
+    dn_note_kernel("pw_xs_kernel<%d>", BP);
     hipLaunchKernelGGL((pw_xs_kernel<BP>), dim3(dn_cdiv(a.m, BP)), dim3(256), lds, s, a);
     return DN_OK;
 }
@@ -515,7 +565,7 @@ template <int BP, int BC, int WP, int WC, bool CONV, int BK>
 int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
     dim3 grid(dn_cdiv(a.m, BP), dn_cdiv(a.cout, BC));
     size_t halfs = (size_t)nbuf * (BP + BC) * (BK + 8);
-    const size_t otile = (size_t)BP * (BC + 8);
+    const size_t otile = a.out_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);     // epilogue staging tile, in halfs
     if (otile > halfs) halfs = otile;
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
     static bool attr = false;
@@ -524,32 +574,16 @@ int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
+    dn_note_kernel("pw_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK);
     hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK>), grid, dim3(256), lds, s, a);
     return DN_OK;
 }
 
-// K staging: when the whole K fits one LDS stage (K <= 128) the workgroup pays ONE memory round trip instead of
-// K/32 + 1 dependent ones (in-kernel stamps: ~1 us each; mid-size layers run as a single wave of workgroups, so the
-// kernel time IS the workgroup lifetime). Larger K keeps the 32-deep double buffer (BK=64 double-buffered lost to
-// occupancy when measured).
+// 32-deep double-buffered K staging. (Measured and dropped: a single exact-K stage for K <= 128 -- no load/compute overlap,
+// slower; 64-deep double buffer -- lost to occupancy.)
 template <int BP, int BC, int WP, int WC, bool CONV>
 int launch_cfg(const PwArgs& a, hipStream_t s) {
     const_cast<PwArgs&>(a).stamps = g_pw_stamps;
-    static const int fullk = getenv("DN_PW_FULLK") ? atoi(getenv("DN_PW_FULLK")) : 0;   // single-stage K measured slower (no load/compute overlap): off
-    const bool conv_ok64 = !CONV || a.cv_cin % 64 == 0, conv_ok128 = !CONV || a.cv_cin % 128 == 0;
-    (void)conv_ok64; (void)conv_ok128;
-    if constexpr (!CONV) {
-        // exact-K single stage: one memory round trip per workgroup, LDS footprint ~ the 32-deep double buffer
-        if (fullk && a.cin <= 32) return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 1);
-        if (fullk && a.cin <= 48) return launch_bk<BP, BC, WP, WC, CONV, 48>(a, s, 1);
-        if (fullk && a.cin <= 64) return launch_bk<BP, BC, WP, WC, CONV, 64>(a, s, 1);
-        if (fullk && a.cin <= 80) return launch_bk<BP, BC, WP, WC, CONV, 80>(a, s, 1);
-        if (fullk && a.cin <= 96) return launch_bk<BP, BC, WP, WC, CONV, 96>(a, s, 1);
-        if (fullk && a.cin <= 112) return launch_bk<BP, BC, WP, WC, CONV, 112>(a, s, 1);
-        if constexpr (BP + BC <= 192) {
-            if (fullk && a.cin <= 128) return launch_bk<BP, BC, WP, WC, CONV, 128>(a, s, 1);
-        }
-    }
     return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 2);
 }
 
@@ -561,6 +595,25 @@ int launch_cfg(const PwArgs& a, hipStream_t s) {
 template <bool CONV>
 int launch_select(const PwArgs& a, hipStream_t s) {
     auto wgs = [&](int bp, int bc) { return (long)dn_cdiv(a.m, bp) * dn_cdiv(a.cout, bc); };
+    switch (g_pw_tile) {
+        case 1: return launch_cfg<256, 32, 4, 1, CONV>(a, s);
+        case 2: return launch_cfg<128, 32, 4, 1, CONV>(a, s);
+        case 3: return launch_cfg<128, 64, 4, 1, CONV>(a, s);
+        case 4: return launch_cfg<64, 64, 2, 2, CONV>(a, s);
+        case 5: return launch_cfg<128, 128, 2, 2, CONV>(a, s);
+        case 6: return launch_cfg<64, 128, 2, 2, CONV>(a, s);
+        case 7: if constexpr (!CONV) return launch_cfg<128, 96, 4, 1, CONV>(a, s); break;
+        default: break;
+    }
+    if constexpr (!CONV) {
+        // 1x1 convs with a thin side (cin < 256 or cout < 128) are HBM/latency-bound: tools/tune_pw.py over every layer shape
+        // of the model shows the small tiles (most workgroups, fewest registers: 64 VGPRs -> 8 waves/SIMD) winning or tying
+        // everywhere, 128x32 when there is a single channel tile. The big tiles only pay off for MFMA-bound shapes.
+        if (a.cin < 256 || a.cout < 128) {
+            if (a.cout <= 32) return launch_cfg<128, 32, 4, 1, CONV>(a, s);
+            return launch_cfg<64, 64, 2, 2, CONV>(a, s);
+        }
+    }
     if (a.cout <= 32) {
         if (wgs(256, 32) >= 1500) return launch_cfg<256, 32, 4, 1, CONV>(a, s);
         return launch_cfg<128, 32, 4, 1, CONV>(a, s);
@@ -591,9 +644,18 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     }
     g.start[count] = acc;
     size_t halfs = (size_t)2 * (BP + BC) * 40;
-    const size_t otile = (size_t)BP * (BC + 8);
+    bool any_fp32 = false;
+    for (int i = 0; i < count; ++i) any_fp32 |= arr[i].out_fp32 != 0;
+    const size_t otile = any_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);
     if (otile > halfs) halfs = otile;
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, 32>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    dn_note_kernel("pw_group_kernel<%d,%d,%d,%d,%s,32>", BP, BC, WP, WC, CONV ? "true" : "false");
     hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, 32>), dim3(acc), dim3(256), lds, s, g);
     return DN_OK;
 }
@@ -610,6 +672,11 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         if (arr[i].cout > maxc) maxc = arr[i].cout;
         wg128 += (long)dn_cdiv(arr[i].m, 128) * dn_cdiv(arr[i].cout, 128);
     }
+    static const int gt = getenv("DN_PW_GROUP_TILE") ? atoi(getenv("DN_PW_GROUP_TILE")) : 0;   // dev knob
+    if (!conv && maxc > 64 && gt == 4) return launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
+    if (!conv && maxc > 64 && gt == 5) return launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
+    if (!conv && maxc > 64 && gt == 6) return launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
+    if (!conv && maxc > 64 && gt == 7) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
     if (wg128 >= 1500) return conv ? launch_group_cfg<128, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
@@ -621,7 +688,8 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
     static const int xs_mode = getenv("DN_PW_XS") ? atoi(getenv("DN_PW_XS")) : 1;
-    if (xs_mode && a.cin <= 1024 && a.cin >= 64 && a.cout <= 160 && a.m <= 8192 && !(a.act >> 8)) {
+    if (g_pw_tile == 8) return launch_xs<32>(a, s);
+    if (xs_mode && !g_pw_tile && a.cin <= 1024 && a.cin >= 64 && a.cout <= 160 && a.m <= 8192 && !(a.act >> 8)) {
         // measured: the strip kernel wins only where the tiled kernel cannot fill the chip (M <= ~8k rows)
         return launch_xs<32>(a, s);
     }

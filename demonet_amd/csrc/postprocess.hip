@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __res
                                                              int A, int Km1, float score_thr, float nms_thr, int topk,
                                                              const unsigned* __restrict__ tauKey, int* __restrict__ needFull,
                                                              float* __restrict__ keptScore, int* __restrict__ keptAnchor,
-                                                             int* __restrict__ keptCount) {
+                                                             int* __restrict__ keptCount, long long* __restrict__ stamps) {
     constexpr int MC = 64 * NW;
     __shared__ unsigned long long cand[MC];
     __shared__ unsigned long long tmp[MC];
@@ -477,18 +477,33 @@ __global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __res
     const int cls = blockIdx.x, n = blockIdx.y;
     const float* col = scoresT + ((size_t)n * Km1 + cls) * A;
     const unsigned tau = tauKey[n];
+    PP_STAMP(0);
     if (tid == 0) cnt_sh = 0;
     if (tid < 8) removed[tid] = 0ull;
     __syncthreads();
-    for (int a = tid; a < A; a += 256) {
-        const float sc = col[a];
-        const unsigned k = __float_as_uint(sc);
-        if (sc > score_thr && k >= tau) {
-            const unsigned pos = atomicAdd(&cnt_sh, 1u);
-            if (pos < (unsigned)MC) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
+    // the scan is pure latency (13 KB per workgroup for A = 3234): keep 8 independent loads in flight per thread instead of
+    // one dependent round trip per 256 anchors
+    for (int a0 = 0; a0 < A; a0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int a = a0 + u * 256 + tid;
+            v[u] = (a < A) ? col[a] : -1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned k = __float_as_uint(v[u]);
+            if (v[u] > score_thr && k >= tau) {          // out-of-range lanes are re-checked below (a < A)
+                const int a = a0 + u * 256 + tid;
+                if (a < A) {
+                    const unsigned pos = atomicAdd(&cnt_sh, 1u);
+                    if (pos < (unsigned)MC) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
+                }
+            }
         }
     }
     __syncthreads();
+    PP_STAMP(1);
     const unsigned cnt = cnt_sh;
     const size_t obase = ((size_t)n * Km1 + cls) * topk;
     if (cnt > (unsigned)topk) {                 // cap would bite -> whole image goes through the full path
@@ -497,10 +512,12 @@ __global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __res
     }
     if (cnt == 0) {
         if (tid == 0) keptCount[(size_t)n * Km1 + cls] = 0;
+        PP_STAMP(2); PP_STAMP(3); PP_STAMP(4); PP_STAMP(5);
         return;
     }
     const int M = (int)cnt;
     rank_sort_desc<256>(cand, tmp, M);          // unique keys: order is the canonical (score desc, anchor asc)
+    PP_STAMP(2);
     for (int i = tid; i < MC; i += 256) {
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < M) b = boxes[(size_t)n * A + (0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFull))];
@@ -508,9 +525,12 @@ __global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __res
         carea[i] = (b.z - b.x) * (b.w - b.y);
     }
     __syncthreads();
+    PP_STAMP(3);
     nms_mask_phase<NW>(cbox, carea, mask, M, nms_thr);
     __syncthreads();
+    PP_STAMP(4);
     if (tid < 64) nms_serial_phase<NW>(cand, mask, removed, M, keptScore + obase, keptAnchor + obase, keptCount + (size_t)n * Km1 + cls);
+    PP_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -554,18 +574,44 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
         if (tid == 0) needFull[n] = 1;
         return;
     }
+    // survivors live in per-class slots [c][0..ccount[c]); walk them through the class prefix sums (e -> class by binary
+    // search) instead of scanning all Km1*topk slots: `total` is a few thousand, the slot array 27k.
+    __shared__ int cpre[257];
+    if (tid < 64) {
+        // exclusive scan of ccount over classes, one wave (Km1 <= 256)
+        int run = 0;
+        for (int c0 = 0; c0 < Km1; c0 += 64) {
+            const int c = c0 + tid;
+            const int v = (c < Km1) ? ccount[c] : 0;
+            int inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d);
+                if (tid >= d) inc += o;
+            }
+            if (c < Km1) cpre[c] = run + inc - v;
+            run += __shfl(inc, 63);
+        }
+        if (tid == 0) cpre[Km1] = run;
+    }
+    __syncthreads();
+    auto slot_of = [&](int e) {
+        int lo = 0, hi = Km1;               // largest c with cpre[c] <= e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cpre[mid] <= e) lo = mid; else hi = mid;
+        }
+        return lo * topk + (e - cpre[lo]);
+    };
     unsigned T = 0, quota = 0;
     if (total > (unsigned)D) {
         unsigned prefix = 0, need = D;
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (int f = tid; f < F; f += 1024) {
-                const int c = f / topk, p = f - c * topk;
-                if (p < ccount[c]) {
-                    const unsigned k = __float_as_uint(ks[f]);
-                    if (shift == 24 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-                }
+            for (int e = tid; e < (int)total; e += 1024) {
+                const unsigned k = __float_as_uint(ks[slot_of(e)]);
+                if (shift == 24 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
             }
             __syncthreads();
             radix_pick_digit(hist, need, sh);
@@ -581,18 +627,18 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
     {
         unsigned base_gt = 0, base_eq = 0;
         const unsigned g_total = (total > (unsigned)D) ? (unsigned)D - quota : total;
-        for (int f0 = 0; f0 < F; f0 += 1024) {
-            const int f = f0 + tid;
-            unsigned k = 0;
-            if (f < F) {
-                const int c = f / topk, p = f - c * topk;
-                if (p < ccount[c]) k = __float_as_uint(ks[f]);
+        for (int e0i = 0; e0i < (int)total; e0i += 1024) {
+            const int e = e0i + tid;
+            unsigned k = 0, f = 0;
+            if (e < (int)total) {
+                f = (unsigned)slot_of(e);
+                k = __float_as_uint(ks[f]);
             }
             const bool gt = (k > T);
             const bool eq = (T != 0u) && (k == T);
             unsigned e0, e1, t0, t1;
             block_scan2<1024>(gt, eq, sh, e0, e1, t0, t1);
-            const unsigned long long kv = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)f);
+            const unsigned long long kv = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - f);
             if (gt) fin[base_gt + e0] = kv;
             if (eq && base_eq + e1 < quota) fin[g_total + base_eq + e1] = kv;
             base_gt += t0;
@@ -667,7 +713,7 @@ template <int NW>
 int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes, const unsigned* tauKey, int* needFull,
                    float* keptScore, int* keptAnchor, int* keptCount, hipStream_t s) {
     hipLaunchKernelGGL((select_nms_fast_kernel<NW>), dim3(a.K - 1, a.n), dim3(256), 0, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount);
+                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps);
     return DN_OK;
 }
 

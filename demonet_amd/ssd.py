@@ -170,6 +170,12 @@ class SSD(nn.Module):
                                              C.c_void_p(b["ws"].data_ptr()), b["ws"].numel(), C.c_void_p(stream)), "dn_forward")
         return b["boxes"], b["scores"], b["labels"], b["counts"]
 
+    def batch_split(self, n: int) -> int:
+        """Number of parallel sub-batch launch chains a forward of n images is issued as (1 = a single chain)."""
+        if self._handle is None:
+            raise RuntimeError("batch_split: the plan is built on the first forward / .cuda()")
+        return _lib.check(_lib.lib().dn_batch_split(C.c_void_p(self._handle), int(n)))
+
     def forward_heads(self, images: Tensor):
         """Backbone + heads only: returns (cls_logits [N,A,K], bbox_regression [N,A,4]) fp32 device tensors (copies)."""
         handle = self._plan(images.device)

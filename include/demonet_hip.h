@@ -141,11 +141,19 @@ DN_API int dn_set_graph_mode(dn_plan* plan, int enabled);
  * dn_profile_begin (HIP events on the forward stream, eager mode). */
 DN_API int dn_profile_begin(dn_plan* plan);
 DN_API int dn_profile_end(dn_plan* plan, float* ms_per_op /* [n_ops + 3] : ops..., softmax/decode, select/NMS, merge */, int capacity);
+/* After a profiled forward: the label of the kernel launch op `op_index` took part in (same spelling as rocprofv3's kernel
+ * names, e.g. "pw_kernel<128,64,4,1,false,32>") and the op whose ms_per_op slot holds that launch's time (grouped launches
+ * serve several ops; their members report the same owner). */
+DN_API int dn_profile_op_info(const dn_plan* plan, int op_index, char* kernel, int capacity, int32_t* owner);
 
 /* Optional extra output of dn_forward for the multi-GPU gather: when non-NULL, the final merge kernel also writes
  * packed_dev [n][D+1][6] fp32 -- rows (x1,y1,x2,y2,score,label), row D = (count,0,0,0,0,0) -- i.e. the fixed-shape payload of
  * the detections all-gather (the analogue of util/misc.py:75-115 all_gather of pickled results). NULL disables it. */
 DN_API int dn_set_packed_output(dn_plan* plan, float* packed_dev);
+
+/* Number of independent sub-batch launch chains a forward of n images is issued as (parallel hipGraph branches; 1 = a single
+ * chain). Every kernel then runs once per sub-batch on ~n/split images; results are identical to the unsplit forward. */
+DN_API int dn_batch_split(const dn_plan* plan, int n);
 
 /* Which ops were grouped into per-image "tail" kernel runs (one launch per run): group id per op or -1. Returns #groups. */
 DN_API int dn_op_groups(const dn_plan* plan, int32_t* group_of_op, int capacity);

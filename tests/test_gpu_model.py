@@ -215,6 +215,49 @@ def test_graph_replay_equals_eager():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,hw", [(33, 320), (34, 300)])
+def test_sub_batch_branches_equal_separate_forwards(n, hw):
+    """n >= 32 images run as two parallel sub-batch launch chains (dn_batch_split). The result must be bit-identical to
+    running the two sub-batches as separate single-chain forwards (DN_SPLIT=1) -- eager and replayed, odd sizes and the
+    resize path included. (Against ONE unsplit forward only the tolerance holds: tile/kernel choice depends on the row count.)"""
+    imgs = torch.from_numpy(synth.images(11, n, hw, hw)).cuda()
+    n0 = (n + 1) // 2
+    os.environ["DN_SPLIT"] = "1"
+    try:
+        ref_model = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+        parts = []
+        for chunk in (imgs[:n0].contiguous(), imgs[n0:].contiguous()):
+            parts.append([t.clone() for t in ref_model.forward_batch(chunk, persistent_input=True)])
+        assert ref_model.batch_split(n) == 1
+    finally:
+        del os.environ["DN_SPLIT"]
+    ref = [torch.cat([a, b]) for a, b in zip(*parts)]
+    m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+    packed = torch.zeros(n, ref[1].shape[1] + 1, 6, device="cuda")
+    m.set_graph_mode(False)
+    eager = [t.clone() for t in m.forward_batch(imgs, persistent_input=True, packed=packed)]
+    assert m.batch_split(n) == 2 and m.batch_split(16) == 1
+    m.set_graph_mode(True)
+    for _ in range(3):
+        replay = [t.clone() for t in m.forward_batch(imgs, persistent_input=True, packed=packed)]
+    torch.cuda.synchronize()
+    for a, b, c in zip(ref, eager, replay):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(packed[:, :-1, :4], ref[0]) and torch.equal(packed[:, :-1, 4], ref[1])
+    assert torch.equal(packed[:, -1, 0].to(torch.int32), ref[3])
+    assert int(ref[3].sum()) > 0
+    # and against one unsplit forward: same detections up to the fp16 tolerance of the path
+    os.environ["DN_SPLIT"] = "1"
+    try:
+        whole = [t.clone() for t in _model("ssdlite320_mobilenet_v3_large", num_classes=91).forward_batch(imgs, persistent_input=True)]
+    finally:
+        del os.environ["DN_SPLIT"]
+    assert torch.equal(whole[3], ref[3])
+    # (ranks may swap between near-equal scores; the sorted score lists must agree)
+    d = (whole[1] - ref[1]).abs()          # fp16 activations: logits agree to ~2e-2 between kernel variants
+    assert d.max().item() < 2e-2 and d.mean().item() < 2e-3
+
+
 def test_error_behaviour_matches_reference():
     m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
     with pytest.raises(ValueError):
