@@ -59,7 +59,6 @@ _SIGNATURES = {
     "dn_fused_tiles_per_image": (C.c_int, [C.c_int, C.c_int]),
     "dn_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dn_set_packed_output": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "dn_op_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dn_profile_begin": (C.c_int, [C.c_void_p]),
     "dn_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "dn_batch_split": (C.c_int, [C.c_void_p, C.c_int]),

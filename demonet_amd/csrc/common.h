@@ -111,15 +111,6 @@ int launch_fused(const FusedArgs& a, hipStream_t s);
 int fused_tiles_per_image(int Ho, int Wo);
 void fused_tile(int Ho, int Wo, int* th, int* tw);
 
-// one op of a per-image "tail" kernel run (mega.hip); offsets are bytes from the workspace / weight-blob base
-struct MegaOp {
-    int type, cin, cout, k, stride, pad, act;
-    int hin, win, hout, wout;
-    int out_fp32, pool, pool_rows, pool_pixels, squeeze, pad0;
-    long x_off, x_stride, out_off, out_stride, res_off, res_stride, se_off, se_stride, pool_off, pool_stride;
-    long w_off, b_off, w2_off, b2_off;
-};
-int launch_mega(const MegaOp* ops_dev, int first, int count, int n, unsigned char* ws, const unsigned char* wts, hipStream_t s);
 
 struct PostArgs {
     const float* logits; const float* reg; const float* anchors;

@@ -7,6 +7,9 @@
 // channel index fastest across lanes so every wave instruction touches whole 128-B lines, fp32 accumulation.
 #include "common.h"
 
+static long long* g_se_stamps = nullptr;     // dev hook (tools/probe_se.py)
+extern "C" __attribute__((visibility("default"))) void dn_debug_se_stamps(void* dev_ptr) { g_se_stamps = (long long*)dev_ptr; }
+
 namespace {
 
 // each thread: TW consecutive output pixels of one row x 8 channels; sliding input window kept in registers
@@ -146,84 +149,107 @@ template <int K, int S, int TW>
 int dw_blocks(const DwArgs& a) { return dn_cdiv((long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8), 256); }
 
 // ---- SE FCs: (sum of partials)/pixels -> fc1(+b) -> ReLU -> fc2(+b) -> Hardsigmoid   (mobilenetv3.py:31-36) ------------
-// One 1024-thread workgroup per image; every dot product is spread over the 64 lanes of a wave (coalesced weight rows,
-// shuffle reduction) instead of one serial loop per thread: the serial form was latency-bound at ~130 us per launch.
-// w1: [squeeze][c] (fc1.weight), w2: [c][squeeze] (fc2.weight), both in the reference's native layout.
-__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ w1,
-                                                   const float* __restrict__ b1, const float* __restrict__ w2,
+// One 1024-thread workgroup per image. Both weight matrices are stored TRANSPOSED at plan time (w1t [c][sq], w2t [sq][c]),
+// so a thread owns one output and walks a slice of the reduction axis with loads that are coalesced across the wave and
+// all independent -- no cross-lane reductions (the earlier wave-per-output form spent most of its time in 6-step shuffle
+// trees), one LDS combine of the K-slices per FC. Loads are issued in batches of 16 before their first use: a plain
+// `t += w[i] * x[i]` loop waits one full L2/HBM latency per iteration on this chip.
+__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ w1t,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2t,
                                                    const float* __restrict__ b2, float* __restrict__ scale,
-                                                   int c, int sq, float inv_pixels) {
-    // Every phase issues a whole batch of independent loads into registers before the first use: a plain
-    // `for (...) t += w[i] * x[i]` loop waits one full L2 latency per iteration on this chip.
-    constexpr int MAXC64 = 16;         // c <= 1024
-    constexpr int MAXS64 = 4;          // squeeze <= 256
-    extern __shared__ float sh[];      // mean[c] then z[sq]
+                                                   int c, int sq, float inv_pixels, long long* __restrict__ stamps) {
+#define SE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    extern __shared__ float sh[];      // mean[c], z[sq], part[1024]
     float* mean = sh;
     float* z = sh + c;
+    float* part = z + sq;
     const int n = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < c; i += 1024) {
-        const float* p = partial + (size_t)n * nblk * c + i;
+    const int tid = threadIdx.x;
+    SE_STAMP(0);
+    // work split of the two FCs: thread (output, K-slice)
+    const int JP = (sq + 63) & ~63;                   // fc1: output j, slice r1 of the c inputs
+    const int KS1 = 1024 / JP;                        // sq <= 256 -> at least 4 slices
+    const int j = tid % JP, r1 = tid / JP;
+    const int per1 = (c + KS1 - 1) / KS1;
+    const int i0 = r1 * per1, i1 = min(c, i0 + per1);
+    const bool act1 = j < sq && r1 < KS1;
+    const int CP = (c + 63) & ~63;                    // fc2: output i, slice r2 of the sq inputs
+    const int KS2 = max(1, 1024 / CP);
+    const int i = tid % CP, r2 = tid / CP;
+    const int per2 = (sq + KS2 - 1) / KS2;
+    const int j0 = r2 * per2, j1 = min(sq, j0 + per2);
+    const bool act2 = i < c && r2 < KS2;
+    constexpr int FB = 32;                            // weight rows in flight per thread
+    // (Measured and dropped: requesting the next phase's first weight rows early -- before or right after the loads the
+    // current phase waits for. Memory returns in order; both variants were slower than the plain phase-by-phase form.)
+    // pooled mean: thread (channel, row slice r) sums every RS-th partial row; slices combined through LDS
+    {
+        const int RS = max(1, min(1024 / CP, nblk));
+        const int r = r2;
         float t = 0.f;
-        for (int b0 = 0; b0 < nblk; b0 += 16) {
-            float v[16];
+        if (i < c && r < RS) {
+            const float* p = partial + (size_t)n * nblk * c + i;
+            for (int b0 = r; b0 < nblk; b0 += RS * 16) {
+                float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = (b0 + u < nblk) ? p[(size_t)(b0 + u) * c] : 0.f;
+                for (int u = 0; u < 16; ++u) v[u] = (b0 + u * RS < nblk) ? p[(size_t)(b0 + u * RS) * c] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t += v[u];
-        }
-        mean[i] = t * inv_pixels;
-    }
-    __syncthreads();
-    // fc1: 4 outputs per wave per batch
-    for (int j0 = wave * 4; j0 < sq; j0 += 64) {
-        float wv[4][MAXC64];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int q = 0; q < MAXC64; ++q) {
-                const int i = lane + 64 * q;
-                wv[u][q] = (j0 + u < sq && i < c) ? w1[(size_t)(j0 + u) * c + i] : 0.f;
+                for (int u = 0; u < 16; ++u) t += v[u];
             }
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < MAXC64; ++q) {
-            const int i = lane + 64 * q;
-            const float m = (i < c) ? mean[i] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] += wv[u][q] * m;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) t[u] += __shfl_xor(t[u], d);
-            if (lane == 0 && j0 + u < sq) z[j0 + u] = fmaxf(t[u] + b1[j0 + u], 0.f);
+        part[tid] = t;
+        __syncthreads();
+        if (tid < c) {
+            float m = 0.f;
+            for (int q = 0; q < RS; ++q) m += part[q * CP + tid];
+            mean[tid] = m * inv_pixels;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    // fc2: 16 outputs per wave per batch
-    for (int i0 = wave * 16; i0 < c; i0 += 256) {
-        float wv[16][MAXS64];
+    SE_STAMP(1);
+    // fc1: z[j] = relu(b1[j] + sum_i w1t[i][j] * mean[i])
+    {
+        float t = 0.f;
+        if (act1) {
+            for (int ib = i0; ib < i1; ib += FB) {
+                float v[FB];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < FB; ++u) v[u] = (ib + u < i1) ? w1t[(size_t)(ib + u) * sq + j] : 0.f;
 #pragma unroll
-            for (int q = 0; q < MAXS64; ++q) {
-                const int j = lane + 64 * q;
-                wv[u][q] = (i0 + u < c && j < sq) ? w2[(size_t)(i0 + u) * sq + j] : 0.f;
+                for (int u = 0; u < FB; ++u) t += v[u] * ((ib + u < i1) ? mean[ib + u] : 0.f);
             }
-        float zz[MAXS64];
+        }
+        part[tid] = t;
+        __syncthreads();
+        if (tid < sq) {
+            float a = b1[tid];
+            for (int q = 0; q < KS1; ++q) a += part[q * JP + tid];
+            z[tid] = fmaxf(a, 0.f);
+        }
+        __syncthreads();
+    }
+    SE_STAMP(2);
+    // fc2: scale[i] = hardsigmoid(b2[i] + sum_j w2t[j][i] * z[j])
+    {
+        float t = 0.f;
+        if (act2) {
+            for (int jb = j0; jb < j1; jb += FB) {
+                float v[FB];
 #pragma unroll
-        for (int q = 0; q < MAXS64; ++q) zz[q] = (lane + 64 * q < sq) ? z[lane + 64 * q] : 0.f;
+                for (int u = 0; u < FB; ++u) v[u] = (jb + u < j1) ? w2t[(size_t)(jb + u) * c + i] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < MAXS64; ++q) t += wv[u][q] * zz[q];
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
-            if (lane == 0 && i0 + u < c) scale[(size_t)n * c + i0 + u] = fminf(fmaxf(t + b2[i0 + u] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                for (int u = 0; u < FB; ++u) t += v[u] * ((jb + u < j1) ? z[jb + u] : 0.f);
+            }
+        }
+        part[tid] = t;
+        __syncthreads();
+        if (tid < c) {
+            float a = b2[tid];
+            for (int q = 0; q < KS2; ++q) a += part[q * CP + tid];
+            scale[(size_t)n * c + tid] = fminf(fmaxf(a + 3.f, 0.f), 6.f) * (1.f / 6.f);
         }
     }
+    SE_STAMP(3);
 }
 
 // ---- stem: dense kxk conv on the NCHW fp32 image, normalisation on load, NHWC fp16 out ------------------
@@ -321,8 +347,8 @@ int launch_se_fc(const float* partial, int nblk, const float* w1, const float* b
                  int n, int c, int squeeze, int pool_pixels, hipStream_t s) {
     DN_REQUIRE(c <= 1024 && squeeze <= 256, "se: c=%d squeeze=%d exceed the kernel's register tiles", c, squeeze);
     dn_note_kernel("se_fc_kernel");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(1024), (size_t)(c + squeeze) * sizeof(float), s, partial, nblk, w1, b1, w2, b2,
-                       scale, c, squeeze, 1.0f / (float)pool_pixels);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(1024), (size_t)(c + squeeze + 1024) * sizeof(float), s, partial, nblk, w1, b1, w2, b2,
+                       scale, c, squeeze, 1.0f / (float)pool_pixels, g_se_stamps);
     return DN_OK;
 }
 

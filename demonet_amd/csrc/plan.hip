@@ -40,8 +40,6 @@ struct Layout {
     std::vector<size_t> toff;       // per tensor byte offset in workspace (SIZE_MAX: not materialised)
     std::vector<size_t> tbytes;
     size_t resized_off = 0, logits_off = 0, reg_off = 0, scale_off = 0, post_off = 0, post_bytes = 0, total = 0;
-    MegaOp* mega_dev = nullptr;     // device copy of the tail-kernel op table for this batch size
-    std::vector<int> mega_index;    // op -> index in the table (-1: not in a group)
 };
 
 struct GraphKey {
@@ -77,11 +75,6 @@ struct dn_plan {
     hipStream_t branch_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_branch[3] = {nullptr, nullptr, nullptr};
     std::map<std::pair<int, int>, Layout> sub_layouts;
-    // runs of consecutive small ops executed by one per-image workgroup (mega.hip)
-    std::vector<int> op_group;              // group id per op or -1
-    std::vector<int> group_first, group_count;
-    std::vector<int> se_inplace_pw;         // SE op -> index of the in-group projection whose input it rescales in place, else -1
-    bool mega_enabled = true;
     float* packed_out = nullptr;
     // head ops (dw -> 1x1 / dense 3x3 per level, both heads) run as grouped launches once the backbone is done
     int head_first = -1;                    // index of the first head-chain op (all later ops are head-chain ops), -1: off
@@ -103,7 +96,7 @@ struct dn_plan {
 // two branches; more branches lose again, and below 32 images there is nothing to gain). Every workspace tensor is
 // image-major, so a sub-batch simply addresses rows [n0, n0 + ns) of the same layout.
 static int batch_split(const dn_plan* p, int n) {
-    if (p->split <= 1 || n < 32 || p->multi_stream || !p->group_first.empty()) return 1;
+    if (p->split <= 1 || n < 32 || p->multi_stream) return 1;
     return p->split;
 }
 static int sub_count(int n, int S, int k) { const int base = n / S, rem = n % S; return base + (k < rem ? 1 : 0); }
@@ -144,51 +137,6 @@ static const Layout& get_layout(dn_plan* p, int n) {
     }
     off += align256(L.post_bytes);
     L.total = off;
-    L.mega_index.assign(p->ops.size(), -1);
-    if (!p->group_first.empty()) {
-        std::vector<MegaOp> tab;
-        std::vector<char> pw_se_applied(p->ops.size(), 0);
-        for (size_t i = 0; i < p->ops.size(); ++i)
-            if (p->se_inplace_pw[i] >= 0) pw_se_applied[p->se_inplace_pw[i]] = 1;
-        for (size_t i = 0; i < p->ops.size(); ++i) {
-            if (p->op_group[i] < 0) continue;
-            const dn_op_desc& o = p->ops[i];
-            const dn_tensor_desc& ti = p->tensors[o.in];
-            const dn_tensor_desc& to = p->tensors[o.out];
-            MegaOp m{};
-            m.type = o.type; m.cin = o.cin; m.cout = o.cout; m.k = o.k; m.stride = o.stride; m.pad = o.pad; m.act = o.act;
-            m.hin = ti.h; m.win = ti.w; m.hout = to.h; m.wout = to.w;
-            m.squeeze = o.squeeze; m.pool_pixels = o.pool_pixels; m.pool = -1; m.pool_rows = 0;
-            m.res_off = m.se_off = m.pool_off = -1;
-            m.w_off = o.w_off; m.b_off = o.b_off; m.w2_off = o.w2_off; m.b2_off = o.b2_off;
-            auto per_img = [&](int t) { return (long)(L.tbytes[t] / n); };
-            m.x_off = (long)L.toff[o.in]; m.x_stride = per_img(o.in);
-            if (o.type == DN_OP_PW && o.head) {
-                const int cols = (o.head == 1) ? p->d.num_classes : 4;
-                m.out_fp32 = 1;
-                m.out_off = (long)((o.head == 1) ? L.logits_off : L.reg_off) + (long)p->level_off[o.level] * cols * 4;
-                m.out_stride = (long)p->d.num_anchors * cols * 4;
-            } else {
-                m.out_off = (long)L.toff[o.out]; m.out_stride = per_img(o.out);
-            }
-            if (o.type == DN_OP_PW) {
-                if (o.residual >= 0) { m.res_off = (long)L.toff[o.residual]; m.res_stride = per_img(o.residual); }
-                if (o.se >= 0 && !pw_se_applied[i]) { m.se_off = (long)L.toff[o.se]; m.se_stride = per_img(o.se); }
-            } else if (o.type == DN_OP_DW) {
-                if (o.pool >= 0) { m.pool = 1; m.pool_off = (long)L.toff[o.pool]; m.pool_stride = per_img(o.pool); m.pool_rows = p->pool_blocks[o.pool]; }
-            } else if (o.type == DN_OP_SE) {
-                m.pool_rows = p->pool_blocks[o.in];
-                if (p->se_inplace_pw[i] >= 0) {
-                    const int xt = p->ops[p->se_inplace_pw[i]].in;      // the depthwise output the projection reads
-                    m.res_off = (long)L.toff[xt]; m.res_stride = per_img(xt);
-                }
-            }
-            L.mega_index[i] = (int)tab.size();
-            tab.push_back(m);
-        }
-        if (hipMalloc((void**)&L.mega_dev, tab.size() * sizeof(MegaOp)) == hipSuccess)
-            (void)hipMemcpy(L.mega_dev, tab.data(), tab.size() * sizeof(MegaOp), hipMemcpyHostToDevice);
-    }
     return p->layouts.emplace(n, std::move(L)).first->second;
 }
 
@@ -326,45 +274,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     p->split = getenv("DN_SPLIT") ? atoi(getenv("DN_SPLIT")) : 2;
     if (p->split < 1) p->split = 1;
     if (p->split > 4) p->split = 4;
-    p->mega_enabled = getenv("DN_MEGA") ? atoi(getenv("DN_MEGA")) != 0 : false;   // measured slower than launches: opt-in
-    p->op_group.assign(desc->n_ops, -1);
-    p->se_inplace_pw.assign(desc->n_ops, -1);
-    if (p->mega_enabled) {
-        const long mac_limit = getenv("DN_MEGA_MACS") ? atol(getenv("DN_MEGA_MACS")) : 12000000L;
-        const int hw_limit = getenv("DN_MEGA_HW") ? atoi(getenv("DN_MEGA_HW")) : 25;
-        auto eligible = [&](int i) {
-            const dn_op_desc& o = p->ops[i];
-            const dn_tensor_desc& ti = p->tensors[o.in];
-            const dn_tensor_desc& to = p->tensors[o.out];
-            if (o.type == DN_OP_PW)
-                return ti.kind == DN_T_ACT && to.h * to.w <= hw_limit && (long)to.h * to.w * o.cin * o.cout <= mac_limit && o.cin % 8 == 0 &&
-                       (o.head || o.cout % 4 == 0);
-            if (o.type == DN_OP_DW)
-                return ti.h * ti.w <= hw_limit && (o.k == 3 || o.k == 5) && o.cin % 8 == 0 && o.cin / 8 <= 512 && o.dil == 1;
-            if (o.type == DN_OP_SE) return o.cin <= 1024 && o.squeeze <= 256 && o.pool_pixels <= hw_limit;
-            return false;
-        };
-        int i = 0;
-        while (i < desc->n_ops) {
-            if (!eligible(i)) { ++i; continue; }
-            int j = i;
-            while (j < desc->n_ops && eligible(j)) ++j;
-            if (j - i >= 2) {
-                const int g = (int)p->group_first.size();
-                p->group_first.push_back(i);
-                p->group_count.push_back(j - i);
-                for (int q = i; q < j; ++q) p->op_group[q] = g;
-            }
-            i = j;
-        }
-        // SE ops whose consumer projection sits in the same group rescale the depthwise output in place
-        for (int i2 = 0; i2 < desc->n_ops; ++i2) {
-            const dn_op_desc& o = p->ops[i2];
-            if (o.type != DN_OP_SE || p->op_group[i2] < 0) continue;
-            for (int j = i2 + 1; j < desc->n_ops && p->op_group[j] == p->op_group[i2]; ++j)
-                if (p->ops[j].type == DN_OP_PW && p->ops[j].se == o.out) { p->se_inplace_pw[i2] = j; break; }
-        }
-    }
     // anchor offsets per level
     int acc = 0;
     for (int l = 0; l < desc->n_levels; ++l) {
@@ -405,7 +314,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
 extern "C" void dn_destroy(dn_plan* p) {
     if (!p) return;
     for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (auto& kv : p->layouts) if (kv.second.mega_dev) (void)hipFree(kv.second.mega_dev);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     for (int i = 0; i < 2; ++i) if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
     for (int i = 0; i < 8; ++i) if (p->ev_feat[i]) (void)hipEventDestroy(p->ev_feat[i]);
@@ -457,7 +365,6 @@ static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
     V.post_off = L.post_off + (size_t)k * slice;
     V.post_bytes = slice;
     V.total = L.total;
-    V.mega_index.assign(p->ops.size(), -1);
     return p->sub_layouts.emplace(key, std::move(V)).first->second;
 }
 
@@ -619,16 +526,6 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             }
             i += len - 1;
-            continue;
-        }
-        if (p->op_group[i] >= 0 && L.mega_dev) {
-            const int g = p->op_group[i];
-            if ((int)i == p->group_first[g]) {
-                rc = launch_mega(L.mega_dev, L.mega_index[i], p->group_count[g], n, ws, W, s);
-                if (rc != DN_OK) return rc;
-            }
-            note(i, p->group_first[g]);
-            if (ms && p->op_feat_level[i] >= 0) DN_HIP_CHECK(hipEventRecord(p->ev_feat[p->op_feat_level[i]], main_stream));
             continue;
         }
         switch (o.type) {
@@ -843,13 +740,6 @@ extern "C" int dn_set_packed_output(dn_plan* p, float* packed_dev) {
     DN_REQUIRE(p, "null plan");
     p->packed_out = packed_dev;
     return DN_OK;
-}
-
-extern "C" int dn_op_groups(const dn_plan* p, int32_t* group_of_op, int capacity) {
-    DN_REQUIRE(p && group_of_op, "null argument");
-    DN_REQUIRE(capacity >= (int)p->ops.size(), "dn_op_groups: capacity too small");
-    for (size_t i = 0; i < p->ops.size(); ++i) group_of_op[i] = p->op_group[i];
-    return (int)p->group_first.size();
 }
 
 extern "C" int dn_profile_begin(dn_plan* p) {

@@ -89,9 +89,9 @@ class LoweredModel:
             elif nd.op == "se":
                 w1 = _np(state_dict, nd.fc1_key + ".weight").reshape(nd.squeeze, nd.cin)
                 w2 = _np(state_dict, nd.fc2_key + ".weight").reshape(nd.cin, nd.squeeze)
-                o.w_off = blob.add(w1.astype(np.float32))                  # [squeeze][c]
+                o.w_off = blob.add(np.ascontiguousarray(w1.T).astype(np.float32))   # fc1 transposed: [c][squeeze]
                 o.b_off = blob.add(_np(state_dict, nd.fc1_key + ".bias").astype(np.float32))
-                o.w2_off = blob.add(w2.astype(np.float32))                 # [c][squeeze]
+                o.w2_off = blob.add(np.ascontiguousarray(w2.T).astype(np.float32))  # fc2 transposed: [squeeze][c]
                 o.b2_off = blob.add(_np(state_dict, nd.fc2_key + ".bias").astype(np.float32))
                 o.pool_pixels = nd.stride
                 o.stride = 1

@@ -53,7 +53,7 @@ typedef struct dn_op_desc {
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob; -1 none.
                                                PW/CONV: w = fp16 [cout][k*k*cin] (tap-major, channel-minor), b = fp32 [cout]
                                                DW/STEM: w = fp16 [k*k][c] / fp32 [k*k*3][cout], b = fp32 [c]
-                                               SE: w = fp32 fc1 [squeeze][c], b = fc1 bias, w2 = fc2 [c][squeeze], b2 = fc2 bias (native layouts)
+                                               SE: w = fp32 fc1 weight TRANSPOSED [c][squeeze], b = fc1 bias, w2 = fc2 weight TRANSPOSED [squeeze][c], b2 = fc2 bias
                                                L2NORM: w = fp32 scale [c] */
 } dn_op_desc;
 
@@ -154,9 +154,6 @@ DN_API int dn_set_packed_output(dn_plan* plan, float* packed_dev);
 /* Number of independent sub-batch launch chains a forward of n images is issued as (parallel hipGraph branches; 1 = a single
  * chain). Every kernel then runs once per sub-batch on ~n/split images; results are identical to the unsplit forward. */
 DN_API int dn_batch_split(const dn_plan* plan, int n);
-
-/* Which ops were grouped into per-image "tail" kernel runs (one launch per run): group id per op or -1. Returns #groups. */
-DN_API int dn_op_groups(const dn_plan* plan, int32_t* group_of_op, int capacity);
 
 DN_API const char* dn_last_error(void);
 DN_API int dn_abi_version(void);
