@@ -98,18 +98,18 @@ int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels,
 int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s);
 
 // fused inverted-residual block (fused.hip): [expand 1x1] -> depthwise -> [project 1x1 (+residual)]
-struct FusedArgs {
-    const half_t* x; half_t* out; float* pool;
-    const half_t* w1; const float* b1;     // expand [cexp][cin] (null: none)
-    const half_t* wd; const float* bd;     // depthwise [k*k][cexp]
-    const half_t* w3; const float* b3;     // project [cout][cexp] (null: stop after the depthwise stage)
-    int n, H, W, Ho, Wo, cin, cexp, cout, k, stride, pad, act1, act2, act3, has_res;
-    int ch, xw;                            // filled by the launcher
-    long long* stamps = nullptr;           // dev-only
+// expand 1x1 + depthwise kxk in one launch (expdw.hip)
+struct ExpDwArgs {
+    const half_t* x; half_t* out; float* pool;     // pool (optional): [n][tiles][cexp] fp32 per-tile channel sums
+    const half_t* w1; const float* b1;             // expand [cexp][cin]
+    const half_t* wd; const float* bd;             // depthwise [k*k][cexp]
+    int n, H, W, Ho, Wo, cin, cexp, k, stride, pad, act1, act2;
+    int xw, chunks_per_wg;                         // filled by the launcher
+    long long* stamps;                             // dev-only
 };
-int launch_fused(const FusedArgs& a, hipStream_t s);
-int fused_tiles_per_image(int Ho, int Wo);
-void fused_tile(int Ho, int Wo, int* th, int* tw);
+int launch_expdw(const ExpDwArgs& a, hipStream_t s);
+int expdw_tiles_per_image(int Ho, int Wo, int stride);
+bool expdw_supported(int cin, int cexp, int k, int stride);
 
 
 struct PostArgs {

@@ -79,9 +79,8 @@ struct dn_plan {
     // head ops (dw -> 1x1 / dense 3x3 per level, both heads) run as grouped launches once the backbone is done
     int head_first = -1;                    // index of the first head-chain op (all later ops are head-chain ops), -1: off
     std::vector<int> head_dw, head_cls, head_reg;            // optional extra output of the merge kernel (dn_set_packed_output)
-    // fused inverted-residual groups (fused.hip): at the first op of a group fused_len = 2 or 3, fused_kind bit0 = has
-    // expand, bit1 = has project
-    std::vector<int> fused_len, fused_kind;
+    // expand 1x1 + depthwise pairs run as one launch (expdw.hip): fused_len = 2 at the 1x1 op of such a pair
+    std::vector<int> fused_len;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -165,12 +164,13 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (o.type < DN_OP_STEM || o.type > DN_OP_L2NORM) { dn_set_error("dn_create: op %d unknown type %d", i, o.type); return fail(DN_E_INVALID); }
         if (o.head && (o.level < 0 || o.level >= desc->n_levels)) { dn_set_error("dn_create: head op %d bad level", i); return fail(DN_E_INVALID); }
     }
-    // ---- fused inverted-residual groups
+    // ---- expand (1x1) -> depthwise pairs whose expanded tensor has no other reader: one launch, the tensor never leaves LDS
     p->fused_len.assign(desc->n_ops, 0);
-    p->fused_kind.assign(desc->n_ops, 0);
     {
-        const bool enabled = getenv("DN_FUSED") ? atoi(getenv("DN_FUSED")) != 0 : false;   // measured: instruction-bound, opt-in
-        const int min_hw = getenv("DN_FUSED_MINHW") ? atoi(getenv("DN_FUSED_MINHW")) : 1;
+        const bool enabled = getenv("DN_EXPDW") ? atoi(getenv("DN_EXPDW")) != 0 : true;
+        const int max_hw = getenv("DN_EXPDW_MAXHW") ? atoi(getenv("DN_EXPDW_MAXHW")) : (1 << 30);
+        // measured per layer (bench.py --per-op, tools/probe_expdw.py): the fused kernel currently wins on the large maps only
+        const int min_hw = getenv("DN_EXPDW_MINHW") ? atoi(getenv("DN_EXPDW_MINHW")) : 6400;
         std::vector<int> uses(desc->n_tensors, 0);
         for (int i = 0; i < desc->n_ops; ++i) {
             const dn_op_desc& o = p->ops[i];
@@ -179,47 +179,25 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             if (o.se >= 0) uses[o.se]++;
         }
         for (int l = 0; l < desc->n_levels; ++l) uses[desc->level_tensor[l]] += 100;    // features must be materialised
-        auto plain_pw = [&](const dn_op_desc& o) { return o.type == DN_OP_PW && !o.head && o.se < 0 && o.cin % 8 == 0 && o.cout % 8 == 0; };
-        auto proj_pw = [&](const dn_op_desc& o) { return plain_pw(o) && o.cout <= 96; };
-        auto dw_ok = [&](const dn_op_desc& o) { return o.type == DN_OP_DW && (o.k == 3 || o.k == 5) && o.dil == 1 && o.cin % 8 == 0; };
-        auto proj_fits = [&](const dn_op_desc& pw) {
-            const dn_tensor_desc& to = p->tensors[pw.out];
-            int th, tw;
-            fused_tile(to.h, to.w, &th, &tw);
-            return ((th * tw + 31) / 32) * ((pw.cout + 31) / 32) <= 16;
-        };
-        int i = 0;
-        while (enabled && i < desc->n_ops) {
+        for (int i = 0; enabled && i + 1 < desc->n_ops; ++i) {
             const dn_op_desc& a = p->ops[i];
-            const bool has_b = i + 1 < desc->n_ops, has_c = i + 2 < desc->n_ops;
-            // expand -> dw [-> project]
-            if (plain_pw(a) && a.residual < 0 && a.cin <= 120 && uses[a.out] == 1 && has_b && dw_ok(p->ops[i + 1]) &&
-                p->ops[i + 1].in == a.out && p->tensors[p->ops[i + 1].out].h >= min_hw) {
-                const dn_op_desc& d = p->ops[i + 1];
-                if (d.pool < 0 && has_c && proj_pw(p->ops[i + 2]) && p->ops[i + 2].in == d.out && uses[d.out] == 1 &&
-                    (p->ops[i + 2].residual < 0 || (p->ops[i + 2].residual == a.in && d.stride == 1 && a.cin == p->ops[i + 2].cout)) &&
-                    proj_fits(p->ops[i + 2])) {
-                    p->fused_len[i] = 3; p->fused_kind[i] = 3; i += 3; continue;
-                }
-                p->fused_len[i] = 2; p->fused_kind[i] = 1; i += 2; continue;
+            const dn_op_desc& d = p->ops[i + 1];
+            const dn_tensor_desc& to = p->tensors[d.out];
+            if (a.type == DN_OP_PW && !a.head && a.se < 0 && a.residual < 0 && uses[a.out] == 1 && d.type == DN_OP_DW && !d.head &&
+                d.in == a.out && d.dil == 1 && p->tensors[a.in].kind == DN_T_ACT && expdw_supported(a.cin, a.cout, d.k, d.stride) &&
+                to.h * to.w <= max_hw && to.h * to.w >= min_hw) {
+                p->fused_len[i] = 2;
+                ++i;
             }
-            // dw -> project (no expand)
-            if (dw_ok(a) && a.pool < 0 && uses[a.out] == 1 && has_b && proj_pw(p->ops[i + 1]) && p->ops[i + 1].in == a.out &&
-                p->tensors[a.out].h >= min_hw && p->tensors[a.in].kind == DN_T_ACT &&
-                (p->ops[i + 1].residual < 0 || (p->ops[i + 1].residual == a.in && a.stride == 1 && a.cin == p->ops[i + 1].cout)) &&
-                proj_fits(p->ops[i + 1])) {
-                p->fused_len[i] = 2; p->fused_kind[i] = 2; i += 2; continue;
-            }
-            ++i;
         }
     }
     // partial-sum rows of every pooled tensor = workgroups per image of its producing depthwise op
     p->pool_blocks.assign(desc->n_tensors, 0);
     for (int i = 0; i < desc->n_ops; ++i) {
         const dn_op_desc& o = p->ops[i];
-        if (o.type == DN_OP_DW && o.pool >= 0 && i > 0 && p->fused_len[i - 1] == 2 && (p->fused_kind[i - 1] & 1)) {
+        if (o.type == DN_OP_DW && o.pool >= 0 && i > 0 && p->fused_len[i - 1] == 2) {
             const dn_tensor_desc& to = p->tensors[o.out];
-            p->pool_blocks[o.pool] = fused_tiles_per_image(to.h, to.w);
+            p->pool_blocks[o.pool] = expdw_tiles_per_image(to.h, to.w, o.stride);
             continue;
         }
         if (o.type == DN_OP_DW && o.pool >= 0) {
@@ -502,30 +480,24 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             break;
         }
         if (p->fused_len[i] > 0) {
-            const int kind = p->fused_kind[i], len = p->fused_len[i];
-            const dn_op_desc* e = (kind & 1) ? &p->ops[i] : nullptr;
-            const dn_op_desc& dwo = p->ops[i + ((kind & 1) ? 1 : 0)];
-            const dn_op_desc* pj = (kind & 2) ? &p->ops[i + len - 1] : nullptr;
-            const dn_tensor_desc& tin = p->tensors[p->ops[i].in];
+            const dn_op_desc& e = p->ops[i];
+            const dn_op_desc& dwo = p->ops[i + 1];
+            const dn_tensor_desc& tin = p->tensors[e.in];
             const dn_tensor_desc& tdo = p->tensors[dwo.out];
-            FusedArgs a{};
-            a.x = reinterpret_cast<const half_t*>(tptr(p->ops[i].in));
-            a.out = reinterpret_cast<half_t*>(tptr(pj ? pj->out : dwo.out));
+            ExpDwArgs a{};
+            a.x = reinterpret_cast<const half_t*>(tptr(e.in));
+            a.out = reinterpret_cast<half_t*>(tptr(dwo.out));
             a.pool = dwo.pool >= 0 ? reinterpret_cast<float*>(tptr(dwo.pool)) : nullptr;
-            if (e) { a.w1 = reinterpret_cast<const half_t*>(W + e->w_off); a.b1 = reinterpret_cast<const float*>(W + e->b_off); a.act1 = e->act; }
+            a.w1 = reinterpret_cast<const half_t*>(W + e.w_off); a.b1 = reinterpret_cast<const float*>(W + e.b_off); a.act1 = e.act;
             a.wd = reinterpret_cast<const half_t*>(W + dwo.w_off); a.bd = reinterpret_cast<const float*>(W + dwo.b_off); a.act2 = dwo.act;
-            if (pj) { a.w3 = reinterpret_cast<const half_t*>(W + pj->w_off); a.b3 = reinterpret_cast<const float*>(W + pj->b_off); a.act3 = pj->act; }
             a.n = n; a.H = tin.h; a.W = tin.w; a.Ho = tdo.h; a.Wo = tdo.w;
-            a.cin = tin.c; a.cexp = dwo.cin; a.cout = pj ? pj->cout : dwo.cin;
-            a.k = dwo.k; a.stride = dwo.stride; a.pad = dwo.pad;
-            a.has_res = (pj && pj->residual >= 0) ? 1 : 0;
-            rc = launch_fused(a, s);
+            a.cin = e.cin; a.cexp = e.cout; a.k = dwo.k; a.stride = dwo.stride; a.pad = dwo.pad;
+            rc = launch_expdw(a, s);
             if (rc != DN_OK) return rc;
-            for (int q = 0; q < len; ++q) note(i + q, i);
-            for (int q = 1; q < len; ++q) {
-                if (record) (void)hipEventRecord(p->events[ev++], s);
-            }
-            i += len - 1;
+            note(i, i);
+            note(i + 1, i);
+            if (record) (void)hipEventRecord(p->events[ev++], s);
+            ++i;
             continue;
         }
         switch (o.type) {
@@ -804,25 +776,23 @@ extern "C" int dn_pointwise_conv(const void* x, const void* w, const float* bias
     return DN_OK;
 }
 
-extern "C" int dn_fused_block(const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w3,
-                              const float* b3, void* out, float* pool_partial, int n, int h, int w, int cin, int cexp, int cout,
-                              int k, int stride, int act1, int act2, int act3, int has_res, void* stream) {
-    DN_REQUIRE(x && wd && bd && out, "dn_fused_block: null argument");
-    FusedArgs a{};
+extern "C" int dn_expand_depthwise(const void* x, const void* w1, const float* b1, const void* wd, const float* bd, void* out,
+                                   float* pool_partial, int n, int h, int w, int cin, int cexp, int k, int stride, int act1,
+                                   int act2, void* stream) {
+    DN_REQUIRE(x && w1 && b1 && wd && bd && out, "dn_expand_depthwise: null argument");
+    ExpDwArgs a{};
     a.x = reinterpret_cast<const half_t*>(x); a.out = reinterpret_cast<half_t*>(out); a.pool = pool_partial;
     a.w1 = reinterpret_cast<const half_t*>(w1); a.b1 = b1; a.wd = reinterpret_cast<const half_t*>(wd); a.bd = bd;
-    a.w3 = reinterpret_cast<const half_t*>(w3); a.b3 = b3;
     a.n = n; a.H = h; a.W = w; a.k = k; a.stride = stride; a.pad = (k - 1) / 2;
     a.Ho = (h + 2 * a.pad - k) / stride + 1; a.Wo = (w + 2 * a.pad - k) / stride + 1;
-    a.cin = cin; a.cexp = cexp; a.cout = w3 ? cout : cexp;
-    a.act1 = act1; a.act2 = act2; a.act3 = act3; a.has_res = has_res;
-    int rc = launch_fused(a, reinterpret_cast<hipStream_t>(stream));
+    a.cin = cin; a.cexp = cexp; a.act1 = act1; a.act2 = act2;
+    int rc = launch_expdw(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;
 }
 
-extern "C" int dn_fused_tiles_per_image(int ho, int wo) { return fused_tiles_per_image(ho, wo); }
+extern "C" int dn_expand_depthwise_tiles(int ho, int wo, int stride) { return expdw_tiles_per_image(ho, wo, stride); }
 
 extern "C" int dn_depthwise_conv(const void* x, const void* w, const float* bias, void* out, int n, int h, int wd, int c, int k,
                                  int stride, int pad, int act, void* stream) {

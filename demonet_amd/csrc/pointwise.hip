@@ -689,8 +689,10 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
     static const int xs_mode = getenv("DN_PW_XS") ? atoi(getenv("DN_PW_XS")) : 1;
     if (g_pw_tile == 8) return launch_xs<32>(a, s);
-    if (xs_mode && !g_pw_tile && a.cin <= 1024 && a.cin >= 64 && a.cout <= 160 && a.m <= 8192 && !(a.act >> 8)) {
-        // measured: the strip kernel wins only where the tiled kernel cannot fill the chip (M <= ~8k rows)
+    if (xs_mode && !g_pw_tile && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&
+        ((a.cin >= 64 && a.m <= 8192) || (a.cin >= 160 && a.m <= 16384))) {
+        // measured (tools/tune_pw.py): the strip kernel wins where the tiled kernel cannot fill the chip -- M <= ~8k rows, or
+        // M <= ~16k rows when K is long (the tiled kernel pays one exposed round trip per 32-deep K stage)
         return launch_xs<32>(a, s);
     }
     return launch_select<false>(a, s);
