@@ -47,17 +47,18 @@ struct ExpDwGeom {
     static constexpr int RT = (NPIX + 31) / 32, ROWS = RT * 32;
 };
 
-template <int K, int S, int OH, int OW>
+template <int K, int S, int OH, int OW, int KSM>
 __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
+    static_assert(K * K * 8 <= NT, "one 16-byte piece of the chunk's depthwise weights per thread");
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     const int XW = a.xw;                                    // halfs per X row: round16(cin) + 8
     half_t* Xs = lds;                                       // [ROWS][XW]
     half_t* Es = Xs + ROWS * XW;                            // [ROWS][EW]
     half_t* Wd = Es + ROWS * EW;                            // [K*K][64]   depthwise weights of the chunk
     float* Bd = reinterpret_cast<float*>(Wd + K * K * 64);  // [64]        depthwise bias of the chunk
-    float* Ps = Bd + 64;                                    // [NT/8][64]  pooled-sum scratch
+    float* Ps = Bd + 64;                                    // [NT/64][64] pooled-sum scratch (one row per wave)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -68,6 +69,36 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
     const int cin = a.cin, cexp = a.cexp;
     const int KS = (cin + 15) >> 4;
+    const int c_begin = blockIdx.z * a.chunks_per_wg * 64;
+    const int c_end = min(cexp, c_begin + a.chunks_per_wg * 64);
+
+    // Per-chunk operands that come from global memory, requested one phase ahead of their use so that their latency hides
+    // under the staging / depthwise work: this wave's A fragments (channel tile t = wave & 1) and bias of the expand, and
+    // this thread's 16-byte piece of the chunk's depthwise weights / bias (written to LDS at the top of the chunk).
+    const int t = wave & 1;
+    half8 wf[KSM];
+    float4 bv[4];
+    uint4 wdreg = make_uint4(0, 0, 0, 0);
+    float bdreg = 0.f;
+    auto request_chunk = [&](int c0) {
+        const int ch = c0 + t * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+            const int k = ks * 16 + hh * 8;
+            half8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ks < KS && ch < cexp && k < cin) w = *reinterpret_cast<const half8*>(a.w1 + (size_t)ch * cin + k);
+            wf[ks] = w;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = c0 + t * 32 + 8 * g + 4 * hh;
+            bv[g] = (c < cexp) ? *reinterpret_cast<const float4*>(a.b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        wdreg = make_uint4(0, 0, 0, 0);
+        if (tid < K * K * 8 && c0 + (tid & 7) * 8 < cexp)
+            wdreg = *reinterpret_cast<const uint4*>(a.wd + (size_t)(tid >> 3) * cexp + c0 + (tid & 7) * 8);
+        bdreg = (tid < 64 && c0 + tid < cexp) ? a.bd[c0 + tid] : 0.f;
+    };
 
     XD_STAMP(0);
     // ---- 1. input region -> LDS (zeros outside the image, in the K padding and in the row padding)
@@ -88,6 +119,7 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
                 if (idx < ROWS * xc8 && pix < NPIX && q < c8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                     v[u] = *reinterpret_cast<const uint4*>(xin + ((size_t)gy * a.W + gx) * cin + q * 8);
             }
+            if (i0 == tid) request_chunk(c_begin);      // behind the first batch of region loads (memory returns in order)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (dst[u] >= 0) *reinterpret_cast<uint4*>(&Xs[dst[u]]) = v[u];
@@ -108,65 +140,39 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
 
     const int cg = tid & 7;                 // this thread's 8-channel group in the depthwise stage (NT % 8 == 0)
     const int tiles = gridDim.x;
-    const int c_begin = blockIdx.z * a.chunks_per_wg * 64;
-    const int c_end = min(cexp, c_begin + a.chunks_per_wg * 64);
     for (int c0 = c_begin; c0 < c_end; c0 += 64) {
-        // depthwise weights / bias of the chunk -> LDS (read after the barrier that ends the MFMA stage)
-        for (int idx = tid; idx < K * K * 8; idx += NT) {
-            const int tap = idx >> 3, q = idx & 7;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c0 + q * 8 < cexp) v = *reinterpret_cast<const uint4*>(a.wd + (size_t)tap * cexp + c0 + q * 8);
-            *reinterpret_cast<uint4*>(&Wd[tap * 64 + q * 8]) = v;
-        }
-        if (tid < 64) Bd[tid] = (c0 + tid < cexp) ? a.bd[c0 + tid] : 0.f;
-
+        if (tid < K * K * 8) *reinterpret_cast<uint4*>(&Wd[(tid >> 3) * 64 + (tid & 7) * 8]) = wdreg;
+        if (tid < 64) Bd[tid] = bdreg;
         // ---- 2. expand on the matrix cores. A = weight rows (channels), B = pixel rows: the accumulator then holds, per lane,
         //         pixel (lane & 31) and channels 8g + 4*(lane >> 5) .. +3 in registers 4g .. 4g+3.
-        // wave w: channel tile t = w & 1 of the chunk, row tiles (w >> 1), (w >> 1) + 4, ...
-        {
-            const int t = wave & 1;
-            half8 wf[XKS];
-            float4 bv[4];
-            const int ch = c0 + t * 32 + r;
+        //         wave w: channel tile t = w & 1 of the chunk, row tiles (w >> 1), (w >> 1) + 4, ...
+        for (int rt = wave >> 1; rt < RT && c0 + t * 32 < cexp; rt += NT / 128) {
+            floatx16 acc;
 #pragma unroll
-            for (int ks = 0; ks < XKS; ++ks) {
-                const int k = ks * 16 + hh * 8;
-                half8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ks < KS && ch < cexp && k < cin) w = *reinterpret_cast<const half8*>(a.w1 + (size_t)ch * cin + k);
-                wf[ks] = w;
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const half_t* xrow = &Xs[(rt * 32 + r) * XW + hh * 8];
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks) {
+                if (ks < KS) {
+                    const half8 xf = *reinterpret_cast<const half8*>(xrow + ks * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf, acc, 0, 0, 0);
+                }
             }
+            const bool inside = (inside_bits >> rt) & 1u;
+            half_t* erow = &Es[(rt * 32 + r) * EW + t * 32 + 4 * hh];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = c0 + t * 32 + 8 * g + 4 * hh;
-                bv[g] = (c < cexp) ? *reinterpret_cast<const float4*>(a.b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            for (int rt = wave >> 1; rt < RT && c0 + t * 32 < cexp; rt += NT / 128) {
-                floatx16 acc;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                const half_t* xrow = &Xs[(rt * 32 + r) * XW + hh * 8];
-#pragma unroll
-                for (int ks = 0; ks < XKS; ++ks) {
-                    if (ks < KS) {
-                        const half8 xf = *reinterpret_cast<const half8*>(xrow + ks * 16);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf, acc, 0, 0, 0);
-                    }
+                half4 hv = {0, 0, 0, 0};
+                if (inside) {
+                    hv[0] = (half_t)dn_act(acc[4 * g + 0] + bv[g].x, a.act1);
+                    hv[1] = (half_t)dn_act(acc[4 * g + 1] + bv[g].y, a.act1);
+                    hv[2] = (half_t)dn_act(acc[4 * g + 2] + bv[g].z, a.act1);
+                    hv[3] = (half_t)dn_act(acc[4 * g + 3] + bv[g].w, a.act1);
                 }
-                const bool inside = (inside_bits >> rt) & 1u;
-                half_t* erow = &Es[(rt * 32 + r) * EW + t * 32 + 4 * hh];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    half4 hv = {0, 0, 0, 0};
-                    if (inside) {
-                        hv[0] = (half_t)dn_act(acc[4 * g + 0] + bv[g].x, a.act1);
-                        hv[1] = (half_t)dn_act(acc[4 * g + 1] + bv[g].y, a.act1);
-                        hv[2] = (half_t)dn_act(acc[4 * g + 2] + bv[g].z, a.act1);
-                        hv[3] = (half_t)dn_act(acc[4 * g + 3] + bv[g].w, a.act1);
-                    }
-                    *reinterpret_cast<half4*>(erow + 8 * g) = hv;
-                }
+                *reinterpret_cast<half4*>(erow + 8 * g) = hv;
             }
         }
+        if (c0 + 64 < c_end) request_chunk(c0 + 64);       // lands under the depthwise stage
         __syncthreads();
         if (c0 == c_begin) XD_STAMP(2);
 
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
                     fma_mix_h8(acc, ev, wv);
                 }
             const int gy = oy0 + oy, gx = ox0 + ox;
-            if (cvalid && gy < a.Ho && gx < a.Wo) {
+            if (gy < a.Ho && gx < a.Wo) {
                 half8 hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -206,15 +212,24 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
             }
         }
         if (a.pool) {
-            // per-tile channel sums in a fixed order: NT/8 partial rows (threads sharing a channel group) -> one row
-            float* prow = &Ps[(tid >> 3) * 64 + cg * 8];
+            // per-tile channel sums in a fixed order: the 8 lanes of a wave that share a channel group, then the waves
 #pragma unroll
-            for (int e = 0; e < 8; ++e) prow[e] = psum[e];
+            for (int e = 0; e < 8; ++e) {
+                float v = psum[e];
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                psum[e] = v;
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Ps[wave * 64 + lane * 8 + e] = psum[e];
+            }
             __syncthreads();
             if (tid < 64 && c0 + tid < cexp) {
                 float s = 0.f;
-#pragma unroll 8
-                for (int q = 0; q < NT / 8; ++q) s += Ps[q * 64 + tid];
+#pragma unroll
+                for (int q = 0; q < NT / 64; ++q) s += Ps[q * 64 + tid];
                 a.pool[((size_t)n * tiles + tile) * cexp + c0 + tid] = s;
             }
         }
@@ -224,17 +239,24 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     XD_STAMP(4);
 }
 
+template <int K, int S, int OH, int OW, int KSM>
+int launch_k(const ExpDwArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d>", K, S, OH, OW, KSM);
+    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM>), grid, dim3(NT), lds, s, a);
+    return DN_OK;
+}
+
 template <int K, int S, int OH, int OW>
 int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     using G = ExpDwGeom<K, S, OH, OW>;
     ExpDwArgs a = a0;
-    const size_t lds = ((size_t)G::ROWS * a.xw + (size_t)G::ROWS * EW + K * K * 64) * sizeof(half_t) + (64 + NT / 8 * 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    const size_t lds = ((size_t)G::ROWS * a.xw + (size_t)G::ROWS * EW + K * K * 64) * sizeof(half_t) + (64 + NT / 64 * 64) * sizeof(float);
     DN_REQUIRE(lds <= 160 * 1024, "expand+depthwise: LDS %zu B exceeds 160 KB", lds);
     // split the 64-channel chunks over grid.z until there are enough workgroups to fill the chip a few times over
     const int tiles = dn_cdiv(a.Ho, OH) * dn_cdiv(a.Wo, OW), chunks = dn_cdiv(a.cexp, 64);
@@ -244,9 +266,9 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     a.chunks_per_wg = cpw;
     a.stamps = g_xd_stamps;
     const dim3 grid(tiles, a.n, dn_cdiv(chunks, cpw));
-    dn_note_kernel("expdw_kernel<%d,%d,%d,%d>", K, S, OH, OW);
-    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW>), grid, dim3(NT), lds, s, a);
-    return DN_OK;
+    // the A fragments of the expand live in registers: 2 K steps cover cin <= 32 (fewer registers -> more waves), else 8
+    if (a.cin <= 32) return launch_k<K, S, OH, OW, 2>(a, grid, lds, s);
+    return launch_k<K, S, OH, OW, XKS>(a, grid, lds, s);
 }
 
 template <int K, int S>
@@ -255,7 +277,7 @@ int launch_ks(const ExpDwArgs& a, int oh, int ow, hipStream_t s) {
         if constexpr (S == 1) return launch_t<K, S, 8, 16>(a, s);
         else return launch_t<K, S, 8, 8>(a, s);
     }
-    if (oh == 10) return launch_t<K, S, 10, 10>(a, s);
+    if constexpr (S == 1) { if (oh == 10) return launch_t<K, S, 10, 10>(a, s); }
     if (ow == 10) return launch_t<K, S, 5, 10>(a, s);
     return launch_t<K, S, 5, 5>(a, s);
 }
