@@ -42,6 +42,18 @@ __device__ __forceinline__ float dn_act(float v, int act) {
     return v;
 }
 
+// acc[0..7] += e[0..7] * w[0..7] with fp16 operands and fp32 accumulation in ONE instruction per element (v_fma_mix_f32).
+// Left to itself hipcc converts every half to fp32 first (2 v_cvt per multiply-add): the depthwise kernels are VALU-heavy and
+// that triples their instruction count.
+__device__ __forceinline__ void fma_mix_h8(float (&acc)[8], const uint4& e, const uint4& w) {
+    const unsigned ee[4] = {e.x, e.y, e.z, e.w}, ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[2 * i]) : "v"(ee[i]), "v"(ww[i]));
+        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * i + 1]) : "v"(ee[i]), "v"(ww[i]));
+    }
+}
+
 static inline int dn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // launchers implemented by the per-kernel translation units (used by plan.hip and by the single-op C entry points)

@@ -63,8 +63,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
         for (int t = 0; t < TW; ++t)
 #pragma unroll
             for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[t][e] += (float)xin[t * S + kx][e] * (float)wv[kx][e];
+                fma_mix_h8(acc[t], *reinterpret_cast<const uint4*>(&xin[t * S + kx]), *reinterpret_cast<const uint4*>(&wv[kx]));
     }
     half_t* orow = a.out + ((size_t)(n * a.ho + oy) * a.wo) * a.c + c0;
 #pragma unroll
@@ -304,8 +303,84 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     }
 }
 
+// 3x3 stride 2 pad 1 on an even-width image (every model here). The three taps of pixel ox are input columns 2ox-1, 2ox, 2ox+1;
+// lanes hold consecutive ox, so one aligned float2 per lane covers whole 128-B lines across the wave and the left tap is the
+// previous lane's second element. All nine (channel, row) loads are requested before the first use -- the generic kernel
+// above pays one exposed memory round trip per (channel, row) step because its loop must not be unrolled (SGPR pressure);
+// here the loads are hoisted and the normalised taps wait in LDS for the (still not unrolled) weight loop.
+template <int COUT>
+__global__ __launch_bounds__(256) void stem3s2_kernel(StemArgs a) {
+    __shared__ float taps[27][256];     // this thread's 27 normalised taps, parked in its own LDS column between the phases
+    const float* __restrict__ wts = a.w;
+    const float* __restrict__ bias = a.bias;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    const int ox = idx % a.wo;
+    int oy = idx / a.wo;
+    const bool live = oy < a.ho;        // no early return: the shuffle needs every lane; dead threads redo the last row
+    if (!live) oy = a.ho - 1;
+    {
+        float2 p[3][3];
+        float left[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * 2 - 1 + ky;
+                const bool yok = iy >= 0 && iy < a.h;
+                const float* prow = a.img + (((size_t)n * 3 + c) * a.h + (yok ? iy : 0)) * a.w_;
+                p[c][ky] = yok ? *reinterpret_cast<const float2*>(prow + 2 * ox) : make_float2(0.f, 0.f);
+                left[c][ky] = ((threadIdx.x & 63) == 0 && ox > 0 && yok) ? prow[2 * ox - 1] : 0.f;
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float mean = a.mean[c], inv = a.inv_std[c];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * 2 - 1 + ky;
+                const bool yok = iy >= 0 && iy < a.h;
+                float l = __shfl_up(p[c][ky].y, 1);
+                if ((threadIdx.x & 63) == 0) l = left[c][ky];
+                const int st = (c * 3 + ky) * 3;
+                taps[st + 0][threadIdx.x] = (yok && ox > 0) ? (l - mean) * inv : 0.f;      // zero padding of the NORMALISED image
+                taps[st + 1][threadIdx.x] = yok ? (p[c][ky].x - mean) * inv : 0.f;
+                taps[st + 2][threadIdx.x] = yok ? (p[c][ky].y - mean) * inv : 0.f;
+            }
+        }
+    }
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
+    // one (channel, row) step at a time: K*COUT weights live in SGPRs per step (see stem_kernel)
+#pragma unroll 1
+    for (int st = 0; st < 9; ++st) {
+        const float* wp = wts + st * 3 * COUT;
+        const float v0 = taps[st * 3 + 0][threadIdx.x], v1 = taps[st * 3 + 1][threadIdx.x], v2 = taps[st * 3 + 2][threadIdx.x];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] += v0 * wp[o];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] += v1 * wp[COUT + o];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] += v2 * wp[2 * COUT + o];
+    }
+    if (!live) return;
+    half_t* op = a.out + ((size_t)(n * a.ho + oy) * a.wo + ox) * COUT;
+#pragma unroll
+    for (int o8 = 0; o8 < COUT / 8; ++o8) {
+        half8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (half_t)dn_act(acc[o8 * 8 + e], a.act);
+        *reinterpret_cast<half8*>(op + o8 * 8) = hv;
+    }
+}
+
 template <int COUT, int K>
 int launch_stem_t(const StemArgs& a, hipStream_t s) {
+    if (K == 3 && a.stride == 2 && a.pad == 1 && (a.w_ & 1) == 0 && 2 * a.wo == a.w_) {
+        dn_note_kernel("stem3s2_kernel<%d>", COUT);
+        hipLaunchKernelGGL((stem3s2_kernel<COUT>), dim3(dn_cdiv((long)a.ho * a.wo, 256), a.n), dim3(256), 0, s, a);
+        return DN_OK;
+    }
     dn_note_kernel("stem_kernel<%d,%d>", COUT, K);
     hipLaunchKernelGGL((stem_kernel<COUT, K>), dim3(dn_cdiv((long)a.ho * a.wo, 256), a.n), dim3(256), 0, s, a);
     return DN_OK;

@@ -29,18 +29,6 @@ constexpr int EW = 72;          // halfs per E row in LDS: 64 channels + 8 pad (
 constexpr int XKS = 8;          // max 16-deep K steps of the expand (cin <= 128)
 constexpr int NT = 512;         // threads per workgroup: 8 waves; two workgroups per CU give 4 waves per SIMD to hide LDS/L2 latency
 
-// acc[0..7] += e[0..7] * w[0..7] with fp16 operands and fp32 accumulation in ONE instruction per element (v_fma_mix_f32).
-// Left to itself hipcc converts every half to fp32 first (2 v_cvt per multiply-add): the depthwise stage is VALU-bound and
-// that triples its instruction count.
-__device__ __forceinline__ void fma_mix_h8(float (&acc)[8], const uint4& e, const uint4& w) {
-    const unsigned ee[4] = {e.x, e.y, e.z, e.w}, ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[2 * i]) : "v"(ee[i]), "v"(ww[i]));
-        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * i + 1]) : "v"(ee[i]), "v"(ww[i]));
-    }
-}
-
 template <int K, int S, int OH, int OW>
 struct ExpDwGeom {
     static constexpr int IH = (OH - 1) * S + K, IW = (OW - 1) * S + K, NPIX = IH * IW;
