@@ -43,27 +43,40 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
         }
     }
     const int ix0 = ox0 * S - a.pad;
+    // RP kernel rows are requested together before their first use: hipcc otherwise waits for each row's loads before
+    // issuing the next row's (vmcnt(0) per row), i.e. K dependent memory round trips per thread. 3x3 takes all rows at once;
+    // 5x5 two at a time (all five would need 260 VGPRs of staging).
+    constexpr int RP = (K == 3) ? 3 : 2;
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * S - a.pad + ky;
-        if (iy < 0 || iy >= a.h) continue;
-        half8 wv[K];
+    for (int ky0 = 0; ky0 < K; ky0 += RP) {
+        half8 wv[RP][K];
+        half8 xin[RP][NIN];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) wv[kx] = *reinterpret_cast<const half8*>(a.w + (size_t)(ky * K + kx) * a.c + c0);
-        half8 xin[NIN];
-        const half_t* rowp = a.x + ((size_t)(n * a.h + iy) * a.w_) * a.c + c0;
+        for (int rr = 0; rr < RP; ++rr) {
+            const int ky = ky0 + rr;
+            if (ky >= K) continue;
+            const int iy = oy * S - a.pad + ky;
+            const bool yok = iy >= 0 && iy < a.h;
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) {
-            const int ix = ix0 + i;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ix >= 0 && ix < a.w_) v = *reinterpret_cast<const half8*>(rowp + (size_t)ix * a.c);
-            xin[i] = v;
+            for (int kx = 0; kx < K; ++kx) wv[rr][kx] = *reinterpret_cast<const half8*>(a.w + (size_t)(ky * K + kx) * a.c + c0);
+            const half_t* rowp = a.x + ((size_t)(n * a.h + (yok ? iy : 0)) * a.w_) * a.c + c0;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const int ix = ix0 + i;
+                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (yok && ix >= 0 && ix < a.w_) v = *reinterpret_cast<const half8*>(rowp + (size_t)ix * a.c);
+                xin[rr][i] = v;
+            }
         }
 #pragma unroll
-        for (int t = 0; t < TW; ++t)
+        for (int rr = 0; rr < RP; ++rr) {
+            if (ky0 + rr >= K) continue;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx)
-                fma_mix_h8(acc[t], *reinterpret_cast<const uint4*>(&xin[t * S + kx]), *reinterpret_cast<const uint4*>(&wv[kx]));
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+                    fma_mix_h8(acc[t], *reinterpret_cast<const uint4*>(&xin[rr][t * S + kx]), *reinterpret_cast<const uint4*>(&wv[rr][kx]));
+        }
     }
     half_t* orow = a.out + ((size_t)(n * a.ho + oy) * a.wo) * a.c + c0;
 #pragma unroll

@@ -27,7 +27,7 @@ namespace {
 // CONV = true: implicit GEMM for a dense kxk convolution (VGG path, SSDHead 3x3 heads; ssd_vgg16.py, generalized_ssd.py:77-92):
 // K runs over (ky, kx, cin) with the weight stored [cout][ky][kx][cin]; each 32-deep K stage lies inside one tap
 // (cin % 32 == 0), so the pixel tile of a stage is the NHWC rows of the tap-shifted input pixels (zeros outside).
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
 __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
@@ -76,7 +76,7 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
         }
     }
 
-    auto load_stage = [&](int k0) {
+    auto load_into = [&](uint4 (&sx)[NX], uint4 (&sw)[NWc], int k0) {
         int tap_c0 = 0, dy = 0, dx = 0;
         if constexpr (CONV) {
             const int tap = k0 / a.cv_cin;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
             sw[i] = v;
         }
     };
-    auto store_stage = [&](int b) {
+    auto store_from = [&](const uint4 (&sx)[NX], const uint4 (&sw)[NWc], int b) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + 256 * i;
@@ -134,13 +134,7 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
 
     const int KT = (K + BK - 1) / BK;
     if (tid < BC) bsh[tid] = (n0 + tid < NC) ? a.bias[n0 + tid] : 0.f;      // visible after the first barrier below
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    PW_STAMP(1);
-    for (int kt = 0; kt < KT; ++kt) {
-        const int b = kt & 1;
-        if (kt + 1 < KT) load_stage((kt + 1) * BK);
+    auto mfma_stage = [&](int b, int kt) {
         const int ksteps = min(BK / 16, (K - kt * BK + 15) >> 4);
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -159,8 +153,37 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < KT) store_stage(b ^ 1);
+    };
+    if constexpr (PF > 1) {
+        // short K (KT <= PF stages, launcher-checked): every stage's global loads are requested up front, so the workgroup pays
+        // ONE exposed memory round trip instead of one per 32-deep stage; the LDS double buffer and its barriers stay as they are.
+        uint4 px[PF][NX], pwt[PF][NWc];
+#pragma unroll
+        for (int st = 0; st < PF; ++st)
+            if (st < KT) load_into(px[st], pwt[st], st * BK);
+        store_from(px[0], pwt[0], 0);
         __syncthreads();
+        PW_STAMP(1);
+#pragma unroll
+        for (int kt = 0; kt < PF; ++kt) {
+            if (kt < KT) {
+                mfma_stage(kt & 1, kt);
+                if (kt + 1 < KT) store_from(px[(kt + 1) % PF], pwt[(kt + 1) % PF], (kt + 1) & 1);
+                __syncthreads();
+            }
+        }
+    } else {
+        load_into(sx, sw, 0);
+        store_from(sx, sw, 0);
+        __syncthreads();
+        PW_STAMP(1);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int b = kt & 1;
+            if (kt + 1 < KT) load_into(sx, sw, (kt + 1) * BK);
+            mfma_stage(b, kt);
+            if (kt + 1 < KT) store_from(sx, sw, b ^ 1);
+            __syncthreads();
+        }
     }
 
     PW_STAMP(2);
@@ -340,9 +363,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
     PW_STAMP(3);
 }
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
-    pw_body<BP, BC, WP, WC, CONV, BK>(a, blockIdx.x, blockIdx.y);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF>(a, blockIdx.x, blockIdx.y);
 }
 
 // Grouped launch: up to 8 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
@@ -561,7 +584,7 @@ int launch_xs(const PwArgs& a, hipStream_t s) {
     return DN_OK;
 }
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK, int PF = 1>
 int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
     dim3 grid(dn_cdiv(a.m, BP), dn_cdiv(a.cout, BC));
     size_t halfs = (size_t)nbuf * (BP + BC) * (BK + 8);
@@ -570,12 +593,12 @@ int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK>),
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK, PF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    dn_note_kernel("pw_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK);
-    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK>), grid, dim3(256), lds, s, a);
+    dn_note_kernel(PF > 1 ? "pw_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK, PF);
+    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK, PF>), grid, dim3(256), lds, s, a);
     return DN_OK;
 }
 
@@ -610,6 +633,12 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         // of the model shows the small tiles (most workgroups, fewest registers: 64 VGPRs -> 8 waves/SIMD) winning or tying
         // everywhere, 128x32 when there is a single channel tile. The big tiles only pay off for MFMA-bound shapes.
         if (a.cin < 256 || a.cout < 128) {
+            static const int shortk = getenv("DN_PW_SHORTK") ? atoi(getenv("DN_PW_SHORTK")) : 1;
+            if (shortk && a.cin > 32 && a.cin <= 128) {       // 2..4 K stages: all loads up front
+                const_cast<PwArgs&>(a).stamps = g_pw_stamps;
+                if (a.cout <= 32) return launch_bk<128, 32, 4, 1, CONV, 32, 4>(a, s, 2);
+                return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
+            }
             if (a.cout <= 32) return launch_cfg<128, 32, 4, 1, CONV>(a, s);
             return launch_cfg<64, 64, 2, 2, CONV>(a, s);
         }
