@@ -93,8 +93,8 @@ struct StemArgs {
 };
 int launch_stem(const StemArgs& a, hipStream_t s);
 
-int launch_se_fc(const float* partial, int nblk, const float* w1, const float* b1, const float* w2, const float* b2,
-                 float* scale, int n, int c, int squeeze, int pool_pixels, hipStream_t s);
+int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b1, const void* w2t, const float* b2, float* scale,
+                 int n, int c, int squeeze, int pool_pixels, hipStream_t s);
 
 struct ConvArgs {
     const half_t* x; const half_t* w; const float* bias; void* out;

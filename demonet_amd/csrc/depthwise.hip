@@ -161,81 +161,93 @@ template <int K, int S, int TW>
 int dw_blocks(const DwArgs& a) { return dn_cdiv((long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8), 256); }
 
 // ---- SE FCs: (sum of partials)/pixels -> fc1(+b) -> ReLU -> fc2(+b) -> Hardsigmoid   (mobilenetv3.py:31-36) ------------
-// One 1024-thread workgroup per image. Both weight matrices are stored TRANSPOSED at plan time (w1t [c][sq], w2t [sq][c]),
+// One 1024-thread workgroup per image. Both weight matrices are stored TRANSPOSED and in fp16 at plan time (w1t [c][sq], w2t [sq][c];
+// fp32 accumulation -- the rounding of a weight is below the fp16 rounding of the activations the scale multiplies),
 // so a thread owns one output and walks a slice of the reduction axis with loads that are coalesced across the wave and
 // all independent -- no cross-lane reductions (the earlier wave-per-output form spent most of its time in 6-step shuffle
 // trees), one LDS combine of the K-slices per FC. Loads are issued in batches of 16 before their first use: a plain
 // `t += w[i] * x[i]` loop waits one full L2/HBM latency per iteration on this chip.
-__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ w1t,
-                                                   const float* __restrict__ b1, const float* __restrict__ w2t,
+__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ partial, int nblk, const unsigned* __restrict__ w1t,
+                                                   const float* __restrict__ b1, const unsigned* __restrict__ w2t,
                                                    const float* __restrict__ b2, float* __restrict__ scale,
                                                    int c, int sq, float inv_pixels, long long* __restrict__ stamps) {
 #define SE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-    extern __shared__ float sh[];      // mean[c], z[sq], part[1024]
+    // w1t: fc1 weight transposed [c][sq] fp16, read as [c][sq/2] half pairs; w2t: fc2 weight transposed [sq][c] fp16 as
+    // [sq][c/2] pairs. A thread owns TWO adjacent outputs (one 4-byte load per weight row) and a K-slice.
+    extern __shared__ float sh[];      // mean[c], z[sq], part[2][1024]
     float* mean = sh;
     float* z = sh + c;
     float* part = z + sq;
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
     SE_STAMP(0);
-    // work split of the two FCs: thread (output, K-slice)
-    const int JP = (sq + 63) & ~63;                   // fc1: output j, slice r1 of the c inputs
-    const int KS1 = 1024 / JP;                        // sq <= 256 -> at least 4 slices
+    const int sq2 = sq >> 1, c2 = c >> 1;
+    const int JP = (sq2 + 63) & ~63;                  // fc1: output pair j, slice r1 of the c inputs
+    const int KS1 = 1024 / JP;
     const int j = tid % JP, r1 = tid / JP;
     const int per1 = (c + KS1 - 1) / KS1;
     const int i0 = r1 * per1, i1 = min(c, i0 + per1);
-    const bool act1 = j < sq && r1 < KS1;
-    const int CP = (c + 63) & ~63;                    // fc2: output i, slice r2 of the sq inputs
+    const bool act1 = j < sq2 && r1 < KS1;
+    const int CP = (c2 + 63) & ~63;                   // fc2: output pair i, slice r2 of the sq inputs
     const int KS2 = max(1, 1024 / CP);
     const int i = tid % CP, r2 = tid / CP;
     const int per2 = (sq + KS2 - 1) / KS2;
     const int j0 = r2 * per2, j1 = min(sq, j0 + per2);
-    const bool act2 = i < c && r2 < KS2;
+    const bool act2 = i < c2 && r2 < KS2;
     constexpr int FB = 32;                            // weight rows in flight per thread
     // (Measured and dropped: requesting the next phase's first weight rows early -- before or right after the loads the
     // current phase waits for. Memory returns in order; both variants were slower than the plain phase-by-phase form.)
     // pooled mean: thread (channel, row slice r) sums every RS-th partial row; slices combined through LDS
     {
-        const int RS = max(1, min(1024 / CP, nblk));
-        const int r = r2;
+        const int CPm = (c + 63) & ~63;
+        const int RS = max(1, min(1024 / CPm, nblk));
+        const int ic = tid % CPm, r = tid / CPm;
         float t = 0.f;
-        if (i < c && r < RS) {
-            const float* p = partial + (size_t)n * nblk * c + i;
+        if (ic < c && r < RS) {
+            const float* p = partial + (size_t)n * nblk * c + ic;
             for (int b0 = r; b0 < nblk; b0 += RS * 16) {
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = (b0 + u * RS < nblk) ? p[(size_t)(b0 + u * RS) * c] : 0.f;
+                for (int u = 0; u < 16; ++u) v[u] = p[(size_t)min(b0 + u * RS, nblk - 1) * c];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t += v[u];
+                for (int u = 0; u < 16; ++u) t += (b0 + u * RS < nblk) ? v[u] : 0.f;
             }
         }
         part[tid] = t;
         __syncthreads();
         if (tid < c) {
             float m = 0.f;
-            for (int q = 0; q < RS; ++q) m += part[q * CP + tid];
+            for (int q = 0; q < RS; ++q) m += part[q * CPm + tid];
             mean[tid] = m * inv_pixels;
         }
         __syncthreads();
     }
     SE_STAMP(1);
+    auto lo = [](unsigned w) { return (float)__builtin_bit_cast(half_t, (unsigned short)(w & 0xffffu)); };
+    auto hi = [](unsigned w) { return (float)__builtin_bit_cast(half_t, (unsigned short)(w >> 16)); };
     // fc1: z[j] = relu(b1[j] + sum_i w1t[i][j] * mean[i])
     {
-        float t = 0.f;
+        float t0 = 0.f, t1 = 0.f;
         if (act1) {
             for (int ib = i0; ib < i1; ib += FB) {
-                float v[FB];
+                unsigned v[FB];
 #pragma unroll
-                for (int u = 0; u < FB; ++u) v[u] = (ib + u < i1) ? w1t[(size_t)(ib + u) * sq + j] : 0.f;
+                for (int u = 0; u < FB; ++u) v[u] = w1t[(size_t)min(ib + u, i1 - 1) * sq2 + j];     // clamped, not predicated: a predicated load costs a branch and a wait each
 #pragma unroll
-                for (int u = 0; u < FB; ++u) t += v[u] * ((ib + u < i1) ? mean[ib + u] : 0.f);
+                for (int u = 0; u < FB; ++u) {
+                    const float m = (ib + u < i1) ? mean[ib + u] : 0.f;
+                    t0 += lo(v[u]) * m;
+                    t1 += hi(v[u]) * m;
+                }
             }
         }
-        part[tid] = t;
+        part[tid] = t0;
+        part[1024 + tid] = t1;
         __syncthreads();
         if (tid < sq) {
             float a = b1[tid];
-            for (int q = 0; q < KS1; ++q) a += part[q * JP + tid];
+            const float* pp = part + (tid & 1) * 1024 + (tid >> 1);
+            for (int q = 0; q < KS1; ++q) a += pp[q * JP];
             z[tid] = fmaxf(a, 0.f);
         }
         __syncthreads();
@@ -243,21 +255,27 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ p
     SE_STAMP(2);
     // fc2: scale[i] = hardsigmoid(b2[i] + sum_j w2t[j][i] * z[j])
     {
-        float t = 0.f;
+        float t0 = 0.f, t1 = 0.f;
         if (act2) {
             for (int jb = j0; jb < j1; jb += FB) {
-                float v[FB];
+                unsigned v[FB];
 #pragma unroll
-                for (int u = 0; u < FB; ++u) v[u] = (jb + u < j1) ? w2t[(size_t)(jb + u) * c + i] : 0.f;
+                for (int u = 0; u < FB; ++u) v[u] = w2t[(size_t)min(jb + u, j1 - 1) * c2 + i];
 #pragma unroll
-                for (int u = 0; u < FB; ++u) t += v[u] * ((jb + u < j1) ? z[jb + u] : 0.f);
+                for (int u = 0; u < FB; ++u) {
+                    const float zz = (jb + u < j1) ? z[jb + u] : 0.f;
+                    t0 += lo(v[u]) * zz;
+                    t1 += hi(v[u]) * zz;
+                }
             }
         }
-        part[tid] = t;
+        part[tid] = t0;
+        part[1024 + tid] = t1;
         __syncthreads();
         if (tid < c) {
             float a = b2[tid];
-            for (int q = 0; q < KS2; ++q) a += part[q * CP + tid];
+            const float* pp = part + (tid & 1) * 1024 + (tid >> 1);
+            for (int q = 0; q < KS2; ++q) a += pp[q * CP];
             scale[(size_t)n * c + tid] = fminf(fmaxf(a + 3.f, 0.f), 6.f) * (1.f / 6.f);
         }
     }
@@ -431,12 +449,13 @@ int depthwise_pool_blocks(const DwArgs& a) {
     return dw_blocks<5, 2, 2>(a);
 }
 
-int launch_se_fc(const float* partial, int nblk, const float* w1, const float* b1, const float* w2, const float* b2, float* scale,
+int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b1, const void* w2t, const float* b2, float* scale,
                  int n, int c, int squeeze, int pool_pixels, hipStream_t s) {
-    DN_REQUIRE(c <= 1024 && squeeze <= 256, "se: c=%d squeeze=%d exceed the kernel's register tiles", c, squeeze);
+    DN_REQUIRE(c <= 1024 && squeeze <= 256 && c % 2 == 0 && squeeze % 2 == 0, "se: c=%d squeeze=%d outside the kernel's range (even, <= 1024 / 256)", c, squeeze);
     dn_note_kernel("se_fc_kernel");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(1024), (size_t)(c + squeeze + 1024) * sizeof(float), s, partial, nblk, w1, b1, w2, b2,
-                       scale, c, squeeze, 1.0f / (float)pool_pixels, g_se_stamps);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(1024), (size_t)(c + squeeze + 2048) * sizeof(float), s, partial, nblk,
+                       reinterpret_cast<const unsigned*>(w1t), b1, reinterpret_cast<const unsigned*>(w2t), b2, scale, c, squeeze,
+                       1.0f / (float)pool_pixels, g_se_stamps);
     return DN_OK;
 }
 

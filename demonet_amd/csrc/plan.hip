@@ -520,8 +520,8 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 rc = launch_depthwise(make_dw(o), s);
                 break;
             case DN_OP_SE: {
-                rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), p->pool_blocks[o.in], reinterpret_cast<const float*>(W + o.w_off),
-                                  reinterpret_cast<const float*>(W + o.b_off), reinterpret_cast<const float*>(W + o.w2_off),
+                rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), p->pool_blocks[o.in], W + o.w_off,
+                                  reinterpret_cast<const float*>(W + o.b_off), W + o.w2_off,
                                   reinterpret_cast<const float*>(W + o.b2_off), reinterpret_cast<float*>(tptr(o.out)), n,
                                   o.cin, o.squeeze, o.pool_pixels, s);
                 break;

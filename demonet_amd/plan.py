@@ -2,7 +2,7 @@
 
 BatchNorm (eval) is folded here in float64:  w' = w * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps)
 (+ conv bias carried through). Weights are stored fp16 in the layouts the kernels read directly (see
-include/demonet_hip.h, dn_op_desc); biases and SE FCs stay fp32.
+include/demonet_hip.h, dn_op_desc); biases stay fp32, SE FC weights are fp16 (transposed).
 """
 import ctypes as C
 from typing import Dict
@@ -89,9 +89,9 @@ class LoweredModel:
             elif nd.op == "se":
                 w1 = _np(state_dict, nd.fc1_key + ".weight").reshape(nd.squeeze, nd.cin)
                 w2 = _np(state_dict, nd.fc2_key + ".weight").reshape(nd.cin, nd.squeeze)
-                o.w_off = blob.add(np.ascontiguousarray(w1.T).astype(np.float32))   # fc1 transposed: [c][squeeze]
+                o.w_off = blob.add(np.ascontiguousarray(w1.T).astype(np.float16))   # fc1 transposed: [c][squeeze] fp16
                 o.b_off = blob.add(_np(state_dict, nd.fc1_key + ".bias").astype(np.float32))
-                o.w2_off = blob.add(np.ascontiguousarray(w2.T).astype(np.float32))  # fc2 transposed: [squeeze][c]
+                o.w2_off = blob.add(np.ascontiguousarray(w2.T).astype(np.float16))  # fc2 transposed: [squeeze][c] fp16
                 o.b2_off = blob.add(_np(state_dict, nd.fc2_key + ".bias").astype(np.float32))
                 o.pool_pixels = nd.stride
                 o.stride = 1
