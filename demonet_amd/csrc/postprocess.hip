@@ -17,6 +17,7 @@
 // (score desc, class asc, anchor asc): bit-exact indices whenever scores/boxes agree.
 // This file is compiled with -ffp-contract=off: decode and IoU must round like the reference (no FMA fusion).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -29,7 +30,7 @@ namespace {
 
 constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
 constexpr int HSHIFT = 19;                               // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
-constexpr int HBINS = 4096;
+constexpr int HBINS = 256;                               // bins kept: the top 256 (scores down to 2^-16); anything lower shares bin 0
 
 // ------------------------------------------------------------------------------------------------------------
 // P1
@@ -37,19 +38,49 @@ constexpr int HBINS = 4096;
 __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __restrict__ logits, const float* __restrict__ reg,
                                                             const float* __restrict__ anchors, float* __restrict__ scoresT,
                                                             float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
-                                                            float score_thr, unsigned* __restrict__ ghist) {
+                                                            float score_thr, unsigned* __restrict__ phist, int hb0, int nb,
+                                                            long long* __restrict__ stamps) {
     extern __shared__ float tile[];            // [64][K] then rowsum[64] then hist[HBINS]
     float* rowsum = tile + 64 * K;
     unsigned* lhist = reinterpret_cast<unsigned*>(rowsum + 64);
-    for (int i = threadIdx.x; i < HBINS; i += 256) lhist[i] = 0u;
+    // only bins [hb0, hb0 + nb) can be hit: scores lie in (score_thr, 1] (161 bins for score_thr = 0.001; nb <= HBINS)
+    if (threadIdx.x < nb) lhist[threadIdx.x] = 0u;
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int a0 = blockIdx.x * 64;
+    PP_STAMP(8);
     const int na = min(64, A - a0);
     const float* src = logits + ((size_t)n * A + a0) * K;
     const int total = na * K;
-    for (int i = tid; i < total; i += 256) tile[i] = src[i];
+    {
+        // 23 KB per workgroup: 8 independent 8-byte loads in flight per thread (rows of K floats are only 8-byte aligned when
+        // A*K is even; odd products fall back to 4-byte loads). A plain copy loop exposes one memory round trip per iteration.
+        const bool pair_ok = ((reinterpret_cast<size_t>(src) & 7) == 0) && ((total & 1) == 0);
+        if (pair_ok) {
+            const float2* s2 = reinterpret_cast<const float2*>(src);
+            float2* t2 = reinterpret_cast<float2*>(tile);
+            const int n2 = total >> 1;
+            for (int i0 = tid; i0 < n2; i0 += 256 * 8) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = s2[min(i0 + 256 * u, n2 - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 256 * u < n2) t2[i0 + 256 * u] = v[u];
+            }
+        } else {
+            for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + 256 * u, total - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 256 * u < total) tile[i0 + 256 * u] = v[u];
+            }
+        }
+    }
     __syncthreads();
+    PP_STAMP(9);
     {
         const int row = tid >> 2, sub = tid & 3;
         float mx = -INFINITY;
@@ -69,20 +100,21 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
         if (sub == 0) rowsum[row] = sm;
     }
     __syncthreads();
+    PP_STAMP(10);
     const int Km1 = K - 1;
     for (int idx = tid; idx < Km1 * 64; idx += 256) {
         const int k = 1 + (idx >> 6), a = idx & 63;
         if (a < na) {
             const float sc = tile[a * K + k] / rowsum[a];
             scoresT[((size_t)n * Km1 + (k - 1)) * A + a0 + a] = sc;
-            if (sc > score_thr) atomicAdd(&lhist[__float_as_uint(sc) >> HSHIFT], 1u);
+            if (sc > score_thr) atomicAdd(&lhist[min(max((int)(__float_as_uint(sc) >> HSHIFT) - hb0, 0), nb - 1)], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HBINS; i += 256) {
-        const unsigned v = lhist[i];
-        if (v) atomicAdd(&ghist[(size_t)n * HBINS + i], v);       // integer atomics: order-independent result
-    }
+    PP_STAMP(11);
+    // this workgroup's histogram goes to its own row; tau_kernel adds the rows. (Device-scope atomics into one per-image table
+    // made a few workgroups per launch wait 15-25 us on the hot bins: the kernel's whole tail.)
+    phist[(((size_t)n * gridDim.x + blockIdx.x) << 8) + threadIdx.x] = (threadIdx.x < nb) ? lhist[threadIdx.x] : 0u;
     if (tid < na) {
         const int a = a0 + tid;
         const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
@@ -104,6 +136,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
         b.w = fminf(fmaxf(b.w, 0.f), img_h);
         boxes[(size_t)n * A + a] = b;
     }
+    PP_STAMP(12);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -425,30 +458,27 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
 // is exact for that prefix (decisions only depend on higher-scored boxes); if at least D boxes survive, every box
 // with score < tau ranks below them and cannot appear in the output. Otherwise needFull[n] triggers the full path.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ ghist, unsigned want, unsigned* __restrict__ tauKey,
-                                                 int* __restrict__ needFull) {
+__global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ phist, int tiles, int hb0, int clamped, unsigned want,
+                                                 unsigned* __restrict__ tauKey, int* __restrict__ needFull) {
     __shared__ unsigned part[256];
     const int n = blockIdx.x, tid = threadIdx.x;
-    const unsigned* h = ghist + (size_t)n * HBINS;
-    // thread t owns bins [16t, 16t+16); suffix sums from the top
-    unsigned loc[16];
+    // thread t owns bin t: sum of the per-workgroup rows of softmax_decode_kernel (fixed order, 16 loads in flight)
+    const unsigned* h = phist + ((size_t)n * tiles << 8) + tid;
     unsigned s = 0;
+    for (int t0 = 0; t0 < tiles; t0 += 16) {
+        unsigned v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { loc[i] = h[16 * tid + i]; s += loc[i]; }
+        for (int u = 0; u < 16; ++u) v[u] = h[(size_t)min(t0 + u, tiles - 1) << 8];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += (t0 + u < tiles) ? v[u] : 0u;
+    }
     part[tid] = s;
     __syncthreads();
     unsigned above = 0;
     for (int t = tid + 1; t < 256; ++t) above += part[t];
-    // the unique thread where the suffix count crosses `want`
-    if (above < want && above + s >= want) {
-        unsigned run = above;
-        int bin = 16 * tid;
-        for (int i = 15; i >= 0; --i) {
-            run += loc[i];
-            if (run >= want) { bin = 16 * tid + i; break; }
-        }
-        tauKey[n] = (unsigned)bin << HSHIFT;
-    }
+    // the unique thread where the suffix count (from the top bin down) crosses `want`: tau = lower edge of its bin. Bin 0 of a
+    // clamped table also holds every lower score -> tau 0 (take everything above the score threshold).
+    if (above < want && above + s >= want) tauKey[n] = (clamped && tid == 0) ? 0u : (unsigned)(hb0 + tid) << HSHIFT;
     if (tid == 0) {
         unsigned total = 0;
         for (int t = 0; t < 256; ++t) total += part[t];
@@ -723,7 +753,7 @@ size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
     (void)dets;
     const size_t Km1 = K - 1;
     return align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) +
-           align256((size_t)n * Km1 * 4) + align256((size_t)n * HBINS * 4 + (size_t)n * 8);
+           align256((size_t)n * Km1 * 4) + align256((size_t)n * dn_cdiv(A, 64) * HBINS * 4 + (size_t)n * 8);
 }
 
 // DN_PP_FAST=0 disables the cut-off fast path (A/B and tests of the full path); DN_PP_WANT overrides the multiple of D.
@@ -754,8 +784,9 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     p += align256((size_t)a.n * Km1 * a.topk * 4);
     int* keptCount = reinterpret_cast<int*>(p);
     p += align256((size_t)a.n * Km1 * 4);
-    unsigned* ghist = reinterpret_cast<unsigned*>(p);                      // [n][HBINS], then tauKey[n], needFull[n]
-    unsigned* tauKey = ghist + (size_t)a.n * HBINS;
+    const int tiles = dn_cdiv(a.A, 64);
+    unsigned* phist = reinterpret_cast<unsigned*>(p);                      // [n][tiles][HBINS], then tauKey[n], needFull[n]
+    unsigned* tauKey = phist + (size_t)a.n * tiles * HBINS;
     int* needFull = reinterpret_cast<int*>(tauKey + a.n);
 
     static const int fast = pp_env("DN_PP_FAST", 1);
@@ -767,14 +798,25 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     const int nw = (a.topk + 63) / 64;
 
     if (ev) (void)hipEventRecord(ev[0], s);
-    DN_HIP_CHECK(hipMemsetAsync(ghist, 0, (size_t)a.n * HBINS * 4 + (size_t)a.n * 8, s));
-    const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + HBINS * sizeof(unsigned);
+    // histogram bins that scores in (score_thresh, 1] can reach (float bits >> HSHIFT is monotone for positive floats)
+    unsigned thr_bits, one_bits;
+    {
+        const float t = a.score_thresh > 0.f ? a.score_thresh : 0.f, one = 1.0f;
+        memcpy(&thr_bits, &t, 4);
+        memcpy(&one_bits, &one, 4);
+    }
+    const int top = (int)(one_bits >> HSHIFT);
+    const int hb_thr = (int)(thr_bits >> HSHIFT);
+    const int hb0 = hb_thr > top + 1 - HBINS ? hb_thr : top + 1 - HBINS;
+    const int clamped = hb_thr < hb0;
+    const int nb = top + 1 - hb0;
+    const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)nb * sizeof(unsigned);
     hipLaunchKernelGGL(softmax_decode_kernel, dim3(dn_cdiv(a.A, 64), a.n), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, ghist);
+                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr);
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
     if (fast) {
-        hipLaunchKernelGGL(tau_kernel, dim3(a.n), dim3(256), 0, s, ghist, (unsigned)(want_mult * a.dets), tauKey, needFull);
+        hipLaunchKernelGGL(tau_kernel, dim3(a.n), dim3(256), 0, s, phist, tiles, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull);
         if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
