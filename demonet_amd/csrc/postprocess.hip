@@ -227,8 +227,9 @@ __device__ __forceinline__ void block_scan2(bool f0, bool f1, unsigned* wtot, un
 }
 
 // ---- NMS phases shared by the fast and the full per-class kernels -------------------------------------------------
-template <int NW>
-__device__ __forceinline__ void nms_mask_phase(const float4* cbox, const float* carea, unsigned long long* mask, int M, float nms_thr) {
+template <int NW, int NWV = 4>
+__device__ __forceinline__ void nms_mask_phase(const float4* __restrict__ cbox, const float* __restrict__ carea,
+                                               unsigned long long* __restrict__ mask, int M, float nms_thr) {
     // 6. IoU mask: mask[i][w] bit j-64w set iff j > i and IoU(i, j) > nms_thr  (strict >, float32, inter/(a_i+a_j-inter)).
     //    Lane = column j (box in registers); two rows per iteration in packed fp32 (v_pk_*); the row boxes are LDS
     //    broadcasts; one __ballot per row yields the 64-bit word. The division is only executed when some lane is within
@@ -248,12 +249,22 @@ __device__ __forceinline__ void nms_mask_phase(const float4* cbox, const float* 
             const f2 jx1 = {bj.x, bj.x}, jy1 = {bj.y, bj.y}, jx2 = {bj.z, bj.z}, jy2 = {bj.w, bj.w}, ja = {aj, aj};
             const f2 zero = {0.f, 0.f};
             for (int rb = 0; rb <= w; ++rb, ++item) {
-                if ((item & 3) != wave) continue;
+                if ((item % NWV) != wave) continue;
                 const int iend = min(M, 64 * (rb + 1));
                 const bool diag = (rb == w);
+                // software-pipelined: the next row pair's boxes are read from LDS before this pair's math. A heavy class (M ~ topk)
+                // runs this loop ~130 times per wave and each pass is a chain LDS read -> packed math -> ballot; with one wave per
+                // SIMD there is nothing else to hide the read latency behind.
+                float4 nb0 = cbox[64 * rb], nb1 = cbox[64 * rb + 1];
+                float na0 = carea[64 * rb], na1 = carea[64 * rb + 1];
                 for (int i = 64 * rb; i < iend; i += 2) {
-                    const float4 b0 = cbox[i], b1 = cbox[i + 1];      // i+1 <= MC-1; a row >= M is a zero box -> inter 0
-                    const f2 ia = {carea[i], carea[i + 1]};
+                    const float4 b0 = nb0, b1 = nb1;      // i+1 <= MC-1; a row >= M is a zero box -> inter 0
+                    const f2 ia = {na0, na1};
+                    {
+                        const int in = min(i + 2, 64 * rb + 62);     // stays inside this 64-row block (< MC)
+                        nb0 = cbox[in]; nb1 = cbox[in + 1];
+                        na0 = carea[in]; na1 = carea[in + 1];
+                    }
                     const f2 ix1 = {b0.x, b1.x}, iy1 = {b0.y, b1.y}, ix2 = {b0.z, b1.z}, iy2 = {b0.w, b1.w};
                     const f2 xx1 = __builtin_elementwise_max(ix1, jx1), yy1 = __builtin_elementwise_max(iy1, jy1);
                     const f2 xx2 = __builtin_elementwise_min(ix2, jx2), yy2 = __builtin_elementwise_min(iy2, jy2);
@@ -301,12 +312,19 @@ __device__ __forceinline__ void nms_serial_phase(const unsigned long long* cand,
             unsigned rem_lo = __builtin_amdgcn_readfirstlane((unsigned)rem0);
             unsigned rem_hi = __builtin_amdgcn_readfirstlane((unsigned)(rem0 >> 32));
             const int nvalid = min(64, M - 64 * c);
-            for (int l = 0; l < nvalid; ++l) {
-                const unsigned bit = (l < 32) ? ((rem_lo >> l) & 1u) : ((rem_hi >> (l - 32)) & 1u);
-                if (!bit) {
-                    rem_lo |= __builtin_amdgcn_readlane(lo, l);
-                    rem_hi |= __builtin_amdgcn_readlane(hi, l);
-                }
+            // visit only the candidates that are still alive when their turn comes (find-first-set over the not-removed mask):
+            // a suppressed candidate costs nothing, a kept one ORs its row into the removed set. Same order, same result as
+            // testing l = 0..nvalid-1 one by one.
+            const unsigned vmask_lo = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
+            const unsigned vmask_hi = nvalid >= 64 ? 0xFFFFFFFFu : (nvalid > 32 ? ((1u << (nvalid - 32)) - 1u) : 0u);
+            unsigned done_lo = 0u, done_hi = 0u;          // candidates already visited
+            while (true) {
+                const unsigned cur_lo = ~(rem_lo | done_lo) & vmask_lo, cur_hi = ~(rem_hi | done_hi) & vmask_hi;
+                if ((cur_lo | cur_hi) == 0u) break;
+                const int l = cur_lo ? __builtin_ctz(cur_lo) : 32 + __builtin_ctz(cur_hi);
+                rem_lo |= __builtin_amdgcn_readlane(lo, l);
+                rem_hi |= __builtin_amdgcn_readlane(hi, l);
+                if (l < 32) done_lo |= 1u << l; else done_hi |= 1u << (l - 32);
             }
             const unsigned long long rem = ((unsigned long long)rem_hi << 32) | rem_lo;
             const bool kept = (lane < nvalid) && !((rem >> lane) & 1ull);
@@ -489,8 +507,8 @@ __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ p
 
 // Fast path of P2: same semantics as select_nms_kernel restricted to keys >= tau. Sets needFull[n] when a class has
 // more than topk scores >= tau (the per-class top-k cap would bite: leave it to the full kernel).
-template <int NW>
-__global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
+template <int NW, int FT>
+__global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
                                                              int A, int Km1, float score_thr, float nms_thr, int topk,
                                                              const unsigned* __restrict__ tauKey, int* __restrict__ needFull,
                                                              float* __restrict__ keptScore, int* __restrict__ keptAnchor,
@@ -512,19 +530,19 @@ __global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __res
     if (tid < 8) removed[tid] = 0ull;
     __syncthreads();
     // the scan is pure latency (13 KB per workgroup for A = 3234): keep 8 independent loads in flight per thread instead of
-    // one dependent round trip per 256 anchors
-    for (int a0 = 0; a0 < A; a0 += 256 * 8) {
+    // one dependent round trip per FT anchors
+    for (int a0 = 0; a0 < A; a0 += FT * 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int a = a0 + u * 256 + tid;
+            const int a = a0 + u * FT + tid;
             v[u] = (a < A) ? col[a] : -1.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const unsigned k = __float_as_uint(v[u]);
             if (v[u] > score_thr && k >= tau) {          // out-of-range lanes are re-checked below (a < A)
-                const int a = a0 + u * 256 + tid;
+                const int a = a0 + u * FT + tid;
                 if (a < A) {
                     const unsigned pos = atomicAdd(&cnt_sh, 1u);
                     if (pos < (unsigned)MC) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
@@ -546,9 +564,9 @@ __global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __res
         return;
     }
     const int M = (int)cnt;
-    rank_sort_desc<256>(cand, tmp, M);          // unique keys: order is the canonical (score desc, anchor asc)
+    rank_sort_desc<FT>(cand, tmp, M);          // unique keys: order is the canonical (score desc, anchor asc)
     PP_STAMP(2);
-    for (int i = tid; i < MC; i += 256) {
+    for (int i = tid; i < MC; i += FT) {
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < M) b = boxes[(size_t)n * A + (0xFFFFFFFFu - (unsigned)(cand[i] & 0xFFFFFFFFull))];
         cbox[i] = b;
@@ -556,7 +574,7 @@ __global__ __launch_bounds__(256) void select_nms_fast_kernel(const float* __res
     }
     __syncthreads();
     PP_STAMP(3);
-    nms_mask_phase<NW>(cbox, carea, mask, M, nms_thr);
+    nms_mask_phase<NW, FT / 64>(cbox, carea, mask, M, nms_thr);
     __syncthreads();
     PP_STAMP(4);
     if (tid < 64) nms_serial_phase<NW>(cand, mask, removed, M, keptScore + obase, keptAnchor + obase, keptCount + (size_t)n * Km1 + cls);
@@ -742,7 +760,9 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
 template <int NW>
 int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes, const unsigned* tauKey, int* needFull,
                    float* keptScore, int* keptAnchor, int* keptCount, hipStream_t s) {
-    hipLaunchKernelGGL((select_nms_fast_kernel<NW>), dim3(a.K - 1, a.n), dim3(256), 0, s, scoresT, boxes, a.A, a.K - 1,
+    // 512 threads: the column scan is one batch of loads for A <= 4096, and a heavy class (up to topk candidates) spreads its
+    // IoU-mask rows over 8 waves instead of 4 -- the kernel's duration is the lifetime of its heaviest workgroups
+    hipLaunchKernelGGL((select_nms_fast_kernel<NW, 512>), dim3(a.K - 1, a.n), dim3(512), 0, s, scoresT, boxes, a.A, a.K - 1,
                        a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps);
     return DN_OK;
 }
