@@ -113,15 +113,17 @@ int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, 
 // expand 1x1 + depthwise kxk in one launch (expdw.hip)
 struct ExpDwArgs {
     const half_t* x; half_t* out; float* pool;     // pool (optional): [n][tiles][cexp] fp32 per-tile channel sums
-    const half_t* w1; const float* b1;             // expand [cexp][cin]
+    const half_t* w1; const float* b1;             // expand [cexp][cin]; null: no expand stage (cexp == cin, the depthwise reads x)
     const half_t* wd; const float* bd;             // depthwise [k*k][cexp]
-    int n, H, W, Ho, Wo, cin, cexp, k, stride, pad, act1, act2;
+    const half_t* w3; const float* b3;             // project [cout][cexp]; null: stop after the depthwise stage (out has cexp channels)
+    int n, H, W, Ho, Wo, cin, cexp, cout, k, stride, pad, act1, act2, has_res;   // has_res: out += x (stride 1, cout == cin)
     int xw, chunks_per_wg;                         // filled by the launcher
     long long* stamps;                             // dev-only
 };
 int launch_expdw(const ExpDwArgs& a, hipStream_t s);
 int expdw_tiles_per_image(int Ho, int Wo, int stride);
 bool expdw_supported(int cin, int cexp, int k, int stride);
+bool expdw_project_supported(int cexp, int cout, int Ho, int Wo, int stride);
 
 
 struct PostArgs {

@@ -35,7 +35,7 @@ struct ExpDwGeom {
     static constexpr int RT = (NPIX + 31) / 32, ROWS = RT * 32;
 };
 
-template <int K, int S, int OH, int OW, int KSM>
+template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ>
 __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
@@ -44,9 +44,11 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     const int XW = a.xw;                                    // halfs per X row: round16(cin) + 8
     half_t* Xs = lds;                                       // [ROWS][XW]
     half_t* Es = Xs + ROWS * XW;                            // [ROWS][EW]
-    half_t* Wd = Es + ROWS * EW;                            // [K*K][64]   depthwise weights of the chunk
+    half_t* Wd = Es + (EXP ? ROWS * EW : 0);                // [K*K][64]   depthwise weights of the chunk
     float* Bd = reinterpret_cast<float*>(Wd + K * K * 64);  // [64]        depthwise bias of the chunk
     float* Ps = Bd + 64;                                    // [NT/64][64] pooled-sum scratch (one row per wave)
+    half_t* Ds = reinterpret_cast<half_t*>(Ps + NT / 64 * 64);   // [DROWS][EW] depthwise output of the chunk (PROJ only)
+    constexpr int DROWS = (OH * OW + 31) / 32 * 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -69,18 +71,20 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     uint4 wdreg = make_uint4(0, 0, 0, 0);
     float bdreg = 0.f;
     auto request_chunk = [&](int c0) {
-        const int ch = c0 + t * 32 + r;
+        if constexpr (EXP) {
+            const int ch = c0 + t * 32 + r;
 #pragma unroll
-        for (int ks = 0; ks < KSM; ++ks) {
-            const int k = ks * 16 + hh * 8;
-            half8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ks < KS && ch < cexp && k < cin) w = *reinterpret_cast<const half8*>(a.w1 + (size_t)ch * cin + k);
-            wf[ks] = w;
-        }
+            for (int ks = 0; ks < KSM; ++ks) {
+                const int k = ks * 16 + hh * 8;
+                half8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ks < KS && ch < cexp && k < cin) w = *reinterpret_cast<const half8*>(a.w1 + (size_t)ch * cin + k);
+                wf[ks] = w;
+            }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = c0 + t * 32 + 8 * g + 4 * hh;
-            bv[g] = (c < cexp) ? *reinterpret_cast<const float4*>(a.b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < 4; ++g) {
+                const int c = c0 + t * 32 + 8 * g + 4 * hh;
+                bv[g] = (c < cexp) ? *reinterpret_cast<const float4*>(a.b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         wdreg = make_uint4(0, 0, 0, 0);
         if (tid < K * K * 8 && c0 + (tid & 7) * 8 < cexp)
@@ -127,6 +131,15 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     XD_STAMP(1);
 
     const int cg = tid & 7;                 // this thread's 8-channel group in the depthwise stage (NT % 8 == 0)
+    // project stage (PROJ): wave = one (32-pixel row tile, 32-channel tile) unit of the [OH*OW][cout] output; its accumulator
+    // lives across the chunk loop (the projection sums over all expanded channels)
+    constexpr int PRT = DROWS / 32;
+    const int pct = PROJ ? (a.cout + 31) >> 5 : 0;
+    const int prt = wave % PRT, pc = wave / PRT;          // launcher guarantees PRT * pct <= NT / 64
+    const bool punit = PROJ && pc < pct;
+    floatx16 pacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
     const int tiles = gridDim.x;
     for (int c0 = c_begin; c0 < c_end; c0 += 64) {
         if (tid < K * K * 8) *reinterpret_cast<uint4*>(&Wd[(tid >> 3) * 64 + (tid & 7) * 8]) = wdreg;
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
         // ---- 2. expand on the matrix cores. A = weight rows (channels), B = pixel rows: the accumulator then holds, per lane,
         //         pixel (lane & 31) and channels 8g + 4*(lane >> 5) .. +3 in registers 4g .. 4g+3.
         //         wave w: channel tile t = w & 1 of the chunk, row tiles (w >> 1), (w >> 1) + 4, ...
-        for (int rt = wave >> 1; rt < RT && c0 + t * 32 < cexp; rt += NT / 128) {
+        for (int rt = wave >> 1; EXP && rt < RT && c0 + t * 32 < cexp; rt += NT / 128) {
             floatx16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -177,18 +190,20 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
                 const float4 b0 = *reinterpret_cast<const float4*>(&Bd[cg * 8]), b1 = *reinterpret_cast<const float4*>(&Bd[cg * 8 + 4]);
                 acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
             }
-            const half_t* ebase = &Es[((oy * S) * IW + ox * S) * EW + cg * 8];
+            // without an expand stage the depthwise reads the staged input itself (zero outside the image = its zero padding)
+            const int SW = EXP ? EW : XW;
+            const half_t* ebase = (EXP ? Es : Xs) + ((oy * S) * IW + ox * S) * SW + cg * 8;
             // one kernel row in flight at a time (fully unrolled, hipcc hoists all K*K tile and weight reads: 350 VGPRs for 5x5)
 #pragma unroll 1
             for (int ky = 0; ky < K; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
-                    const uint4 ev = *reinterpret_cast<const uint4*>(ebase + (ky * IW + kx) * EW);
+                    const uint4 ev = *reinterpret_cast<const uint4*>(ebase + (ky * IW + kx) * SW);
                     const uint4 wv = *reinterpret_cast<const uint4*>(&Wd[(ky * K + kx) * 64 + cg * 8]);
                     fma_mix_h8(acc, ev, wv);
                 }
             const int gy = oy0 + oy, gx = ox0 + ox;
-            if (gy < a.Ho && gx < a.Wo) {
+            if (PROJ || (gy < a.Ho && gx < a.Wo)) {
                 half8 hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -196,7 +211,8 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
                     psum[e] += v;
                     hv[e] = (half_t)v;
                 }
-                *reinterpret_cast<half8*>(a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * cexp + c0 + cg * 8) = hv;
+                if constexpr (PROJ) *reinterpret_cast<half8*>(&Ds[opix * EW + cg * 8]) = hv;     // B operand rows of the projection
+                else *reinterpret_cast<half8*>(a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * cexp + c0 + cg * 8) = hv;
             }
         }
         if (a.pool) {
@@ -221,22 +237,67 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
                 a.pool[((size_t)n * tiles + tile) * cexp + c0 + tid] = s;
             }
         }
-        __syncthreads();        // Es / Wd / Bd / Ps are rewritten by the next chunk
+        if constexpr (PROJ) {
+            // channel groups of a partial last chunk that the depthwise stage skipped must read as zero
+            if (c0 + 64 > cexp)
+                for (int item = tid; item < DROWS * 8; item += NT)
+                    if (c0 + (item & 7) * 8 >= cexp) *reinterpret_cast<uint4*>(&Ds[(item >> 3) * EW + (item & 7) * 8]) = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            if (punit) {
+                const int co = pc * 32 + r;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = c0 + ks * 16 + hh * 8;
+                    half8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (co < a.cout && k < cexp) w = *reinterpret_cast<const half8*>(a.w3 + (size_t)co * cexp + k);
+                    const half8 df = *reinterpret_cast<const half8*>(&Ds[(prt * 32 + r) * EW + ks * 16 + hh * 8]);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, df, pacc, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();        // Es / Wd / Bd / Ps / Ds are rewritten by the next chunk
         if (c0 == c_begin) XD_STAMP(3);
+    }
+    if constexpr (PROJ) {
+        // lane = output pixel (row tile prt, row r), registers 4g..4g+3 = channels pc*32 + 8g + 4hh .. +3
+        const int opix = prt * 32 + r;
+        const int oy = opix / OW, ox = opix - oy * OW;
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        if (punit && opix < OH * OW && gy < a.Ho && gx < a.Wo) {
+            half_t* orow = a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * a.cout;
+            const half_t* xrow = a.x + (((size_t)n * a.H + gy) * a.W + gx) * cin;      // residual (stride 1, cout == cin)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = pc * 32 + 8 * g + 4 * hh;
+                if (c < a.cout) {           // cout % 8 == 0: the 4-channel group is entirely in range
+                    const float4 b = *reinterpret_cast<const float4*>(a.b3 + c);
+                    float v[4] = {pacc[4 * g + 0] + b.x, pacc[4 * g + 1] + b.y, pacc[4 * g + 2] + b.z, pacc[4 * g + 3] + b.w};
+                    if (a.has_res) {
+                        const half4 rr = *reinterpret_cast<const half4*>(xrow + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                    }
+                    half4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
+                    *reinterpret_cast<half4*>(orow + c) = hv;
+                }
+            }
+        }
     }
     XD_STAMP(4);
 }
 
-template <int K, int S, int OH, int OW, int KSM>
+template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ>
 int launch_k(const ExpDwArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM>),
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d>", K, S, OH, OW, KSM);
-    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM>), grid, dim3(NT), lds, s, a);
+    dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
+    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>), grid, dim3(NT), lds, s, a);
     return DN_OK;
 }
 
@@ -244,19 +305,29 @@ template <int K, int S, int OH, int OW>
 int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     using G = ExpDwGeom<K, S, OH, OW>;
     ExpDwArgs a = a0;
-    const size_t lds = ((size_t)G::ROWS * a.xw + (size_t)G::ROWS * EW + K * K * 64) * sizeof(half_t) + (64 + NT / 64 * 64) * sizeof(float);
+    const bool proj = a.w3 != nullptr, exp = a.w1 != nullptr;
+    constexpr int DROWS = (OH * OW + 31) / 32 * 32;
+    const size_t lds = ((size_t)G::ROWS * a.xw + (exp ? (size_t)G::ROWS * EW : 0) + K * K * 64 + (proj ? (size_t)DROWS * EW : 0)) * sizeof(half_t) +
+                       (64 + NT / 64 * 64) * sizeof(float);
     DN_REQUIRE(lds <= 160 * 1024, "expand+depthwise: LDS %zu B exceeds 160 KB", lds);
     // split the 64-channel chunks over grid.z until there are enough workgroups to fill the chip a few times over
+    // (not with a project stage: it sums over all chunks inside the workgroup)
     const int tiles = dn_cdiv(a.Ho, OH) * dn_cdiv(a.Wo, OW), chunks = dn_cdiv(a.cexp, 64);
     static const int want = getenv("DN_EXPDW_WGS") ? atoi(getenv("DN_EXPDW_WGS")) : 1024;
     int cpw = chunks;
-    while (cpw > 1 && (long)tiles * a.n * dn_cdiv(chunks, cpw) < want) --cpw;
+    while (!proj && cpw > 1 && (long)tiles * a.n * dn_cdiv(chunks, cpw) < want) --cpw;
     a.chunks_per_wg = cpw;
     a.stamps = g_xd_stamps;
     const dim3 grid(tiles, a.n, dn_cdiv(chunks, cpw));
+    if (proj) DN_REQUIRE((DROWS / 32) * dn_cdiv(a.cout, 32) <= NT / 64, "expand+depthwise+project: %d output units for %d waves", (DROWS / 32) * dn_cdiv(a.cout, 32), NT / 64);
     // the A fragments of the expand live in registers: 2 K steps cover cin <= 32 (fewer registers -> more waves), else 8
-    if (a.cin <= 32) return launch_k<K, S, OH, OW, 2>(a, grid, lds, s);
-    return launch_k<K, S, OH, OW, XKS>(a, grid, lds, s);
+    if (!exp) return proj ? launch_k<K, S, OH, OW, 2, false, true>(a, grid, lds, s) : DN_E_UNSUPPORTED;
+    if (proj) {
+        if (a.cin <= 32) return launch_k<K, S, OH, OW, 2, true, true>(a, grid, lds, s);
+        return launch_k<K, S, OH, OW, XKS, true, true>(a, grid, lds, s);
+    }
+    if (a.cin <= 32) return launch_k<K, S, OH, OW, 2, true, false>(a, grid, lds, s);
+    return launch_k<K, S, OH, OW, XKS, true, false>(a, grid, lds, s);
 }
 
 template <int K, int S>
@@ -291,10 +362,21 @@ bool expdw_supported(int cin, int cexp, int k, int stride) {
     return cin % 8 == 0 && cin <= 16 * XKS && cexp % 8 == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2);
 }
 
+// the project stage keeps one MFMA accumulator per wave: (pixels of the tile / 32) x (cout / 32) units must fit the 8 waves
+bool expdw_project_supported(int cexp, int cout, int Ho, int Wo, int stride) {
+    int oh, ow;
+    expdw_tile(Ho, Wo, stride, &oh, &ow);
+    return cexp % 8 == 0 && cout % 8 == 0 && ((oh * ow + 31) / 32) * ((cout + 31) / 32) <= NT / 64;
+}
+
 int launch_expdw(const ExpDwArgs& a0, hipStream_t s) {
     ExpDwArgs a = a0;
     DN_REQUIRE(expdw_supported(a.cin, a.cexp, a.k, a.stride), "expand+depthwise: unsupported cin=%d cexp=%d k=%d stride=%d", a.cin, a.cexp,
                a.k, a.stride);
+    DN_REQUIRE(a.w1 || a.cin == a.cexp, "depthwise+project without expand needs cexp == cin");
+    DN_REQUIRE(a.w1 || a.w3, "expand+depthwise: neither an expand nor a project stage (use the depthwise kernel)");
+    DN_REQUIRE(!a.w3 || (!a.pool && expdw_project_supported(a.cexp, a.cout, a.Ho, a.Wo, a.stride)), "expand+depthwise+project: unsupported cout=%d / tile", a.cout);
+    DN_REQUIRE(!a.has_res || (a.w3 && a.stride == 1 && a.cout == a.cin), "expand+depthwise+project: residual needs stride 1 and cout == cin");
     DN_REQUIRE(a.n > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0, "expand+depthwise: empty problem");
     a.xw = ((a.cin + 15) / 16) * 16 + 8;
     int oh, ow;

@@ -79,8 +79,9 @@ struct dn_plan {
     // head ops (dw -> 1x1 / dense 3x3 per level, both heads) run as grouped launches once the backbone is done
     int head_first = -1;                    // index of the first head-chain op (all later ops are head-chain ops), -1: off
     std::vector<int> head_dw, head_cls, head_reg;            // optional extra output of the merge kernel (dn_set_packed_output)
-    // expand 1x1 + depthwise pairs run as one launch (expdw.hip): fused_len = 2 at the 1x1 op of such a pair
-    std::vector<int> fused_len;
+    // inverted-residual stages that run as one launch (expdw.hip): at the first op of a group, fused_len = number of ops and
+    // fused_kind bit0 = has expand (1x1), bit1 = has project (1x1 [+ residual]); the depthwise op is always part of it
+    std::vector<int> fused_len, fused_kind;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -166,6 +167,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     }
     // ---- expand (1x1) -> depthwise pairs whose expanded tensor has no other reader: one launch, the tensor never leaves LDS
     p->fused_len.assign(desc->n_ops, 0);
+    p->fused_kind.assign(desc->n_ops, 0);
     {
         const bool enabled = getenv("DN_EXPDW") ? atoi(getenv("DN_EXPDW")) != 0 : true;
         const int max_hw = getenv("DN_EXPDW_MAXHW") ? atoi(getenv("DN_EXPDW_MAXHW")) : (1 << 30);
@@ -179,15 +181,37 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             if (o.se >= 0) uses[o.se]++;
         }
         for (int l = 0; l < desc->n_levels; ++l) uses[desc->level_tensor[l]] += 100;    // features must be materialised
+        // project stage only where the map is large (one workgroup must own all expanded channels) and the expand's A fragments
+        // fit the small register variant (cin <= 32); measured: wins on the 160^2 / 80^2 blocks
+        const int proj_min_hw = getenv("DN_EXPDW_PROJ_MINHW") ? atoi(getenv("DN_EXPDW_PROJ_MINHW")) : 6400;
+        auto plain_pw = [&](const dn_op_desc& o) { return o.type == DN_OP_PW && !o.head && o.se < 0; };
+        auto dw_ok = [&](const dn_op_desc& o) { return o.type == DN_OP_DW && !o.head && o.dil == 1; };
+        auto proj_ok = [&](const dn_op_desc& pj, const dn_op_desc& d, int block_in) {
+            const dn_tensor_desc& to = p->tensors[d.out];
+            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= 128 &&
+                   to.h * to.w >= proj_min_hw && expdw_project_supported(d.cin, pj.cout, to.h, to.w, d.stride) &&
+                   (pj.residual < 0 || (pj.residual == block_in && d.stride == 1 && pj.cout == p->tensors[block_in].c));
+        };
         for (int i = 0; enabled && i + 1 < desc->n_ops; ++i) {
             const dn_op_desc& a = p->ops[i];
             const dn_op_desc& d = p->ops[i + 1];
-            const dn_tensor_desc& to = p->tensors[d.out];
-            if (a.type == DN_OP_PW && !a.head && a.se < 0 && a.residual < 0 && uses[a.out] == 1 && d.type == DN_OP_DW && !d.head &&
-                d.in == a.out && d.dil == 1 && p->tensors[a.in].kind == DN_T_ACT && expdw_supported(a.cin, a.cout, d.k, d.stride) &&
-                to.h * to.w <= max_hw && to.h * to.w >= min_hw) {
-                p->fused_len[i] = 2;
-                ++i;
+            if (plain_pw(a) && a.residual < 0 && uses[a.out] == 1 && dw_ok(d) && d.in == a.out && p->tensors[a.in].kind == DN_T_ACT &&
+                expdw_supported(a.cin, a.cout, d.k, d.stride)) {
+                const dn_tensor_desc& to = p->tensors[d.out];
+                if (to.h * to.w > max_hw || to.h * to.w < min_hw) continue;
+                if (i + 2 < desc->n_ops && a.cin <= 32 && proj_ok(p->ops[i + 2], d, a.in)) {
+                    p->fused_len[i] = 3; p->fused_kind[i] = 3; i += 2;
+                } else {
+                    p->fused_len[i] = 2; p->fused_kind[i] = 1; i += 1;
+                }
+                continue;
+            }
+            // depthwise -> project without an expand (first block of the MobileNets): correct but measured slower than the two
+            // launches (16 channels leave half of the workgroup idle in the depthwise stage) -- opt-in
+            static const bool noexp = getenv("DN_EXPDW_NOEXP") ? atoi(getenv("DN_EXPDW_NOEXP")) != 0 : false;
+            if (noexp && dw_ok(a) && p->tensors[a.in].kind == DN_T_ACT && expdw_supported(a.cin, a.cin, a.k, a.stride) && a.cin <= 32 &&
+                proj_ok(d, a, a.in)) {
+                p->fused_len[i] = 2; p->fused_kind[i] = 2; i += 1;
             }
         }
     }
@@ -195,7 +219,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     p->pool_blocks.assign(desc->n_tensors, 0);
     for (int i = 0; i < desc->n_ops; ++i) {
         const dn_op_desc& o = p->ops[i];
-        if (o.type == DN_OP_DW && o.pool >= 0 && i > 0 && p->fused_len[i - 1] == 2) {
+        if (o.type == DN_OP_DW && o.pool >= 0 && i > 0 && p->fused_len[i - 1] >= 2 && (p->fused_kind[i - 1] & 1)) {
             const dn_tensor_desc& to = p->tensors[o.out];
             p->pool_blocks[o.pool] = expdw_tiles_per_image(to.h, to.w, o.stride);
             continue;
@@ -480,24 +504,29 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             break;
         }
         if (p->fused_len[i] > 0) {
-            const dn_op_desc& e = p->ops[i];
-            const dn_op_desc& dwo = p->ops[i + 1];
-            const dn_tensor_desc& tin = p->tensors[e.in];
+            const int kind = p->fused_kind[i], len = p->fused_len[i];
+            const dn_op_desc* e = (kind & 1) ? &p->ops[i] : nullptr;
+            const dn_op_desc& dwo = p->ops[i + ((kind & 1) ? 1 : 0)];
+            const dn_op_desc* pj = (kind & 2) ? &p->ops[i + len - 1] : nullptr;
+            const dn_tensor_desc& tin = p->tensors[p->ops[i].in];
             const dn_tensor_desc& tdo = p->tensors[dwo.out];
             ExpDwArgs a{};
-            a.x = reinterpret_cast<const half_t*>(tptr(e.in));
-            a.out = reinterpret_cast<half_t*>(tptr(dwo.out));
+            a.x = reinterpret_cast<const half_t*>(tptr(p->ops[i].in));
+            a.out = reinterpret_cast<half_t*>(tptr(pj ? pj->out : dwo.out));
             a.pool = dwo.pool >= 0 ? reinterpret_cast<float*>(tptr(dwo.pool)) : nullptr;
-            a.w1 = reinterpret_cast<const half_t*>(W + e.w_off); a.b1 = reinterpret_cast<const float*>(W + e.b_off); a.act1 = e.act;
+            if (e) { a.w1 = reinterpret_cast<const half_t*>(W + e->w_off); a.b1 = reinterpret_cast<const float*>(W + e->b_off); a.act1 = e->act; }
             a.wd = reinterpret_cast<const half_t*>(W + dwo.w_off); a.bd = reinterpret_cast<const float*>(W + dwo.b_off); a.act2 = dwo.act;
+            if (pj) { a.w3 = reinterpret_cast<const half_t*>(W + pj->w_off); a.b3 = reinterpret_cast<const float*>(W + pj->b_off); }
             a.n = n; a.H = tin.h; a.W = tin.w; a.Ho = tdo.h; a.Wo = tdo.w;
-            a.cin = e.cin; a.cexp = e.cout; a.k = dwo.k; a.stride = dwo.stride; a.pad = dwo.pad;
+            a.cin = tin.c; a.cexp = dwo.cin; a.cout = pj ? pj->cout : dwo.cin;
+            a.k = dwo.k; a.stride = dwo.stride; a.pad = dwo.pad;
+            a.has_res = (pj && pj->residual >= 0) ? 1 : 0;
             rc = launch_expdw(a, s);
             if (rc != DN_OK) return rc;
-            note(i, i);
-            note(i + 1, i);
-            if (record) (void)hipEventRecord(p->events[ev++], s);
-            ++i;
+            for (int q = 0; q < len; ++q) note(i + q, i);
+            for (int q = 1; q < len; ++q)
+                if (record) (void)hipEventRecord(p->events[ev++], s);
+            i += len - 1;
             continue;
         }
         switch (o.type) {
@@ -776,16 +805,18 @@ extern "C" int dn_pointwise_conv(const void* x, const void* w, const float* bias
     return DN_OK;
 }
 
-extern "C" int dn_expand_depthwise(const void* x, const void* w1, const float* b1, const void* wd, const float* bd, void* out,
-                                   float* pool_partial, int n, int h, int w, int cin, int cexp, int k, int stride, int act1,
-                                   int act2, void* stream) {
-    DN_REQUIRE(x && w1 && b1 && wd && bd && out, "dn_expand_depthwise: null argument");
+extern "C" int dn_expand_depthwise(const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w3,
+                                   const float* b3, void* out, float* pool_partial, int n, int h, int w, int cin, int cexp, int cout,
+                                   int k, int stride, int act1, int act2, int has_res, void* stream) {
+    DN_REQUIRE(x && wd && bd && out, "dn_expand_depthwise: null argument");
+    DN_REQUIRE((w1 == nullptr) == (b1 == nullptr) && (w3 == nullptr) == (b3 == nullptr), "dn_expand_depthwise: weight without bias");
     ExpDwArgs a{};
     a.x = reinterpret_cast<const half_t*>(x); a.out = reinterpret_cast<half_t*>(out); a.pool = pool_partial;
     a.w1 = reinterpret_cast<const half_t*>(w1); a.b1 = b1; a.wd = reinterpret_cast<const half_t*>(wd); a.bd = bd;
+    a.w3 = reinterpret_cast<const half_t*>(w3); a.b3 = b3;
     a.n = n; a.H = h; a.W = w; a.k = k; a.stride = stride; a.pad = (k - 1) / 2;
     a.Ho = (h + 2 * a.pad - k) / stride + 1; a.Wo = (w + 2 * a.pad - k) / stride + 1;
-    a.cin = cin; a.cexp = cexp; a.act1 = act1; a.act2 = act2;
+    a.cin = cin; a.cexp = cexp; a.cout = w3 ? cout : cexp; a.act1 = act1; a.act2 = act2; a.has_res = has_res;
     int rc = launch_expdw(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     DN_HIP_CHECK(hipGetLastError());

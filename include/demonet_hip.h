@@ -123,14 +123,17 @@ DN_API int dn_pointwise_conv(const void* x_dev, const void* w_dev, const float* 
 DN_API int dn_depthwise_conv(const void* x_dev, const void* w_dev, const float* bias_dev, void* out_dev,
                       int n, int h, int w, int c, int k, int stride, int pad, int act, void* stream);
 
-/* 1x1 expand + depthwise kxk in one launch (expdw.hip): out = act2(dw_kxk(act1(x . w1 + b1)) + bd), BN folded, padding
- * (k-1)/2; replaces the expand and depthwise ConvBNActivation pair of InvertedResidual.forward (mobilenetv3.py:72-84) /
- * _extra_block (ssd_mobilenetv3.py:39-50). x: [n][h][w][cin] fp16, w1 [cexp][cin] fp16, wd [k*k][cexp] fp16, out
- * [n][ho][wo][cexp] fp16; pool_partial (optional) receives [n][tiles][cexp] fp32 channel sums, tiles =
- * dn_expand_depthwise_tiles(ho, wo, stride). cin <= 128, k in {3,5}, stride in {1,2}. */
+/* Fused inverted-residual stages (expdw.hip): [1x1 expand w1/b1 + act1] -> depthwise kxk wd/bd + act2 -> [1x1 project w3/b3
+ * (+ residual = x)], BN folded, padding (k-1)/2; replaces the ConvBNActivation chain of InvertedResidual.forward
+ * (mobilenetv3.py:72-99) / _extra_block (ssd_mobilenetv3.py:39-54). The expanded / depthwise activations stay on chip.
+ * w1 may be NULL (no expand: cexp == cin), w3 may be NULL (stop after the depthwise stage: out is [n][ho][wo][cexp] and
+ * pool_partial (optional) receives [n][tiles][cexp] fp32 channel sums, tiles = dn_expand_depthwise_tiles(ho, wo, stride));
+ * not both. x: [n][h][w][cin] fp16, w1 [cexp][cin], wd [k*k][cexp], w3 [cout][cexp] fp16. cin <= 128, k in {3,5}, stride in
+ * {1,2}; with w3: (tile pixels / 32) * (cout / 32) <= 8 and no pooling. */
 DN_API int dn_expand_depthwise(const void* x_dev, const void* w1_dev, const float* b1_dev, const void* wd_dev, const float* bd_dev,
-                        void* out_dev, float* pool_partial_dev, int n, int h, int w, int cin, int cexp, int k, int stride,
-                        int act1, int act2, void* stream);
+                        const void* w3_dev, const float* b3_dev, void* out_dev, float* pool_partial_dev,
+                        int n, int h, int w, int cin, int cexp, int cout, int k, int stride, int act1, int act2, int has_res,
+                        void* stream);
 DN_API int dn_expand_depthwise_tiles(int ho, int wo, int stride);
 
 /* 1 = replay the launch sequence from a cached hipGraph keyed by (n, pointers) [default], 0 = eager launches */

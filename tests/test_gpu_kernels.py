@@ -130,48 +130,64 @@ def test_bad_arguments_report_errors():
 
 
 EXPDW_CASES = [
-    # n, h, w, cin, cexp, k, s, pool, act1, act2
-    (2, 36, 44, 16, 64, 3, 2, False, 1, 1),      # b2-like (8x8 tiles), ragged tile edges
-    (1, 40, 40, 24, 72, 3, 1, False, 1, 1),      # b3-like (8x16 tiles), cin padded 24 -> 32, channel tail 72 = 64 + 8
-    (2, 40, 40, 24, 72, 5, 2, True, 1, 1),       # b4-like: 5x5 stride 2 + pooled sums
-    (2, 20, 20, 40, 120, 5, 1, True, 1, 1),      # 5x5 stride 1, pooled
-    (1, 20, 20, 80, 200, 3, 1, False, 3, 3),     # b8-like, hardswish, 4 chunks
-    (2, 20, 20, 112, 672, 3, 1, True, 3, 3),     # widest expand of the backbone, 7 K steps, 11 chunks
-    (2, 10, 10, 80, 480, 5, 1, True, 3, 3),      # 5x10 tiles
-    (3, 5, 5, 40, 104, 3, 2, False, 2, 2),       # tiny map (5x5 tile), channel tail
-    (2, 19, 19, 64, 384, 3, 1, False, 2, 2),     # MobileNetV2-like odd map, relu6
-    (2, 3, 3, 128, 256, 3, 2, False, 1, 1),      # extras-like: 3x3 -> 2x2, cin = 128
+    # n, h, w, cin, cexp, cout, k, s, expand, project, pool, res, act1, act2
+    (2, 36, 44, 16, 64, 0, 3, 2, True, False, False, False, 1, 1),      # b2-like (8x8 tiles), ragged tile edges
+    (1, 40, 40, 24, 72, 0, 3, 1, True, False, False, False, 1, 1),      # b3-like (8x16 tiles), cin padded 24 -> 32, tail 72 = 64 + 8
+    (2, 40, 40, 24, 72, 0, 5, 2, True, False, True, False, 1, 1),       # b4-like: 5x5 stride 2 + pooled sums
+    (2, 20, 20, 40, 120, 0, 5, 1, True, False, True, False, 1, 1),      # 5x5 stride 1, pooled
+    (1, 20, 20, 80, 200, 0, 3, 1, True, False, False, False, 3, 3),     # b8-like, hardswish, 4 chunks
+    (2, 20, 20, 112, 672, 0, 3, 1, True, False, True, False, 3, 3),     # widest expand of the backbone, 7 K steps, 11 chunks
+    (2, 10, 10, 80, 480, 0, 5, 1, True, False, True, False, 3, 3),      # 5x10 tiles
+    (3, 5, 5, 40, 104, 0, 3, 2, True, False, False, False, 2, 2),       # tiny map (5x5 tile), channel tail
+    (2, 19, 19, 64, 384, 0, 3, 1, True, False, False, False, 2, 2),     # MobileNetV2-like odd map, relu6
+    (2, 3, 3, 128, 256, 0, 3, 2, True, False, False, False, 1, 1),      # extras-like: 3x3 -> 2x2, cin = 128
+    (2, 40, 48, 16, 16, 16, 3, 1, False, True, False, True, 0, 1),      # b1-like: depthwise -> project + residual, no expand
+    (2, 36, 44, 16, 64, 24, 3, 2, True, True, False, False, 1, 1),      # b2-like: expand -> dw s2 -> project, ragged tiles
+    (1, 40, 40, 24, 72, 24, 3, 1, True, True, False, True, 1, 1),       # b3-like: full block with residual, two chunks (64 + 8)
+    (2, 38, 38, 32, 96, 40, 3, 1, True, True, False, False, 2, 2),      # V2-like: 2 output channel tiles
 ]
 
 
-@pytest.mark.parametrize("n,h,w,cin,cexp,k,s,pool,act1,act2", EXPDW_CASES)
-def test_expand_depthwise(n, h, w, cin, cexp, k, s, pool, act1, act2):
-    """The fused expand + depthwise kernel against the same chain of fp32 CPU ops with the expanded activation rounded to
-    fp16 where the unfused path stores it."""
+@pytest.mark.parametrize("n,h,w,cin,cexp,cout,k,s,expand,project,pool,res,act1,act2", EXPDW_CASES)
+def test_expand_depthwise(n, h, w, cin, cexp, cout, k, s, expand, project, pool, res, act1, act2):
+    """The fused inverted-residual stages against the same chain of fp32 CPU ops with the expanded and depthwise activations
+    rounded to fp16 where the unfused path stores them."""
     L, lib = _lib()
     g = torch.Generator().manual_seed(h * 7 + cexp)
     x = torch.randn(n, cin, h, w, generator=g).half()
-    w1 = (torch.randn(cexp, cin, generator=g) / cin ** 0.5).half()
-    b1 = torch.randn(cexp, generator=g) * 0.1
+    w1 = (torch.randn(cexp, cin, generator=g) / cin ** 0.5).half() if expand else None
+    b1 = torch.randn(cexp, generator=g) * 0.1 if expand else None
     wd = (torch.randn(cexp, 1, k, k, generator=g) / k).half()
     bd = torch.randn(cexp, generator=g) * 0.1
+    w3 = (torch.randn(cout, cexp, generator=g) / cexp ** 0.5).half() if project else None
+    b3 = torch.randn(cout, generator=g) * 0.1 if project else None
     pad = (k - 1) // 2
-    y = _act(F.conv2d(x.float(), w1.float()[:, :, None, None], b1), act1).half().float()
+    y = x.float()
+    if expand:
+        y = _act(F.conv2d(y, w1.float()[:, :, None, None], b1), act1).half().float()
     y32 = _act(F.conv2d(y, wd.float(), bd, s, pad, 1, cexp), act2)
     pooled_ref = y32.sum(dim=(2, 3))
+    ref = y32.half().float()
+    if project:
+        ref = F.conv2d(ref, w3.float()[:, :, None, None], b3)
+        if res:
+            ref = ref + x.float()
     ho, wo = y32.shape[-2:]
     xd = x.permute(0, 2, 3, 1).contiguous().cuda()
     wdd = wd.view(cexp, k * k).t().contiguous().cuda()
-    out = torch.zeros(n, ho, wo, cexp, dtype=torch.half, device="cuda")
+    out = torch.zeros(n, ho, wo, cout if project else cexp, dtype=torch.half, device="cuda")
     tiles = lib.dn_expand_depthwise_tiles(ho, wo, s)
     pp = torch.zeros(n, tiles, cexp, device="cuda") if pool else None
-    w1d, b1d, bdd = w1.cuda(), b1.cuda(), bd.cuda()
-    rc = lib.dn_expand_depthwise(_ptr(xd), _ptr(w1d), _ptr(b1d), _ptr(wdd), _ptr(bdd), _ptr(out), _ptr(pp),
-                                 n, h, w, cin, cexp, k, s, act1, act2, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    dev = lambda t: t.cuda() if t is not None else None
+    w1d, b1d, w3d, b3d, bdd = dev(w1), dev(b1), dev(w3), dev(b3), dev(bd)
+    rc = lib.dn_expand_depthwise(_ptr(xd), _ptr(w1d), _ptr(b1d), _ptr(wdd), _ptr(bdd), _ptr(w3d), _ptr(b3d), _ptr(out), _ptr(pp),
+                                 n, h, w, cin, cexp, cout, k, s, act1, act2, int(res),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.check(rc, "dn_expand_depthwise")
     torch.cuda.synchronize()
     got = out.cpu().float().permute(0, 3, 1, 2)
-    torch.testing.assert_close(got, y32.half().float(), rtol=4e-3, atol=4e-3)
+    tol = dict(rtol=1e-2, atol=2e-2) if project else dict(rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(got, ref.half().float(), **tol)
     if pool:
         torch.testing.assert_close(pp.cpu().sum(1), pooled_ref, rtol=2e-3, atol=2e-2)
 
@@ -180,5 +196,5 @@ def test_expand_depthwise_rejects_unsupported_shapes():
     L, lib = _lib()
     x = torch.zeros(4096, dtype=torch.half, device="cuda")
     f = torch.zeros(4096, device="cuda")
-    rc = lib.dn_expand_depthwise(_ptr(x), _ptr(x), _ptr(f), _ptr(x), _ptr(f), _ptr(x), None, 1, 4, 4, 136, 64, 3, 1, 0, 0, None)
+    rc = lib.dn_expand_depthwise(_ptr(x), _ptr(x), _ptr(f), _ptr(x), _ptr(f), None, None, _ptr(x), None, 1, 4, 4, 136, 64, 0, 3, 1, 0, 0, 0, None)
     assert rc < 0 and b"unsupported" in lib.dn_last_error()

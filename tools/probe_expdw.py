@@ -19,7 +19,7 @@ for (h, cin, cexp, k, s) in SHAPES:
     outs = [torch.empty(N, ho, ho, cexp, device="cuda", dtype=torch.half) for _ in range(R)]
     w1 = (torch.randn(cexp, cin, device="cuda") / cin ** 0.5).half(); b1 = torch.randn(cexp, device="cuda")
     wd = (torch.randn(k * k, cexp, device="cuda") / k).half(); bd = torch.randn(cexp, device="cuda")
-    call = lambda i: _lib.check(L.dn_expand_depthwise(P(xs[i % R]), P(w1), P(b1), P(wd), P(bd), P(outs[i % R]), None, N, h, h, cin, cexp, k, s, 1, 1, stream))
+    call = lambda i: _lib.check(L.dn_expand_depthwise(P(xs[i % R]), P(w1), P(b1), P(wd), P(bd), None, None, P(outs[i % R]), None, N, h, h, cin, cexp, 0, k, s, 1, 1, 0, stream))
     call(0); call(1)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
