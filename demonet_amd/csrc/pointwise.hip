@@ -155,8 +155,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
         }
     };
     if constexpr (PF > 1) {
-        // short K (KT <= PF stages, launcher-checked): every stage's global loads are requested up front, so the workgroup pays
-        // ONE exposed memory round trip instead of one per 32-deep stage; the LDS double buffer and its barriers stay as they are.
+        // Register ring of PF stages: every stage's global loads are requested PF stages before their use. For short K
+        // (KT <= PF) that is everything up front -- ONE exposed memory round trip per workgroup instead of one per 32-deep
+        // stage; for long K the latency hides behind PF stages of MFMA work. The LDS double buffer and its barriers stay.
         uint4 px[PF][NX], pwt[PF][NWc];
 #pragma unroll
         for (int st = 0; st < PF; ++st)
@@ -164,12 +165,17 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
         store_from(px[0], pwt[0], 0);
         __syncthreads();
         PW_STAMP(1);
+        for (int kt0 = 0; kt0 < KT; kt0 += PF) {
 #pragma unroll
-        for (int kt = 0; kt < PF; ++kt) {
-            if (kt < KT) {
-                mfma_stage(kt & 1, kt);
-                if (kt + 1 < KT) store_from(px[(kt + 1) % PF], pwt[(kt + 1) % PF], (kt + 1) & 1);
-                __syncthreads();
+            for (int j = 0; j < PF; ++j) {
+                const int kt = kt0 + j;
+                if (kt < KT) {
+                    mfma_stage(kt & 1, kt);
+                    // slot (j+1)%PF holds stage kt+1; slot j (stage kt, already in LDS) is free for stage kt+PF
+                    if (kt + 1 < KT) store_from(px[(j + 1) % PF], pwt[(j + 1) % PF], (kt + 1) & 1);
+                    if (kt + PF < KT) load_into(px[j], pwt[j], (kt + PF) * BK);
+                    __syncthreads();
+                }
             }
         }
     } else {
@@ -378,7 +384,7 @@ struct PwGroup {
     PwArgs a[8];
 };
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(256) void pw_group_kernel(PwGroup g) {
     int p = 0;
 #pragma unroll
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void pw_group_kernel(PwGroup g) {
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
     const int local = blockIdx.x - g.start[p];
     const int gx = g.gx[p];
-    pw_body<BP, BC, WP, WC, CONV, BK>(g.a[p], local % gx, local / gx);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF>(g.a[p], local % gx, local / gx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -639,6 +645,11 @@ int launch_select(const PwArgs& a, hipStream_t s) {
                 if (a.cout <= 32) return launch_bk<128, 32, 4, 1, CONV, 32, 4>(a, s, 2);
                 return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
             }
+            if (shortk && a.cin > 128) {                      // long K on a thin layer: loads 4 stages ahead
+                const_cast<PwArgs&>(a).stamps = g_pw_stamps;
+                if (a.cout <= 32) return launch_bk<128, 32, 4, 1, CONV, 32, 4>(a, s, 2);
+                return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
+            }
             if (a.cout <= 32) return launch_cfg<128, 32, 4, 1, CONV>(a, s);
             return launch_cfg<64, 64, 2, 2, CONV>(a, s);
         }
@@ -661,6 +672,9 @@ int launch_select(const PwArgs& a, hipStream_t s) {
 namespace {
 template <int BP, int BC, int WP, int WC, bool CONV>
 int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
+    // head 1x1 convs have long K (21 stages at level 0): loads run 3 stages ahead (the dense-conv heads of the VGG models are
+    // MFMA-bound at 184 VGPRs and keep the plain double buffer)
+    constexpr int GPF = CONV ? 1 : 3;
     PwGroup g{};
     g.count = count;
     int acc = 0;
@@ -680,12 +694,12 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, 32>),
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, 32, GPF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    dn_note_kernel("pw_group_kernel<%d,%d,%d,%d,%s,32>", BP, BC, WP, WC, CONV ? "true" : "false");
-    hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, 32>), dim3(acc), dim3(256), lds, s, g);
+    dn_note_kernel(GPF > 1 ? "pw_group_kernel<%d,%d,%d,%d,%s,32,%d>" : "pw_group_kernel<%d,%d,%d,%d,%s,32>", BP, BC, WP, WC, CONV ? "true" : "false", GPF);
+    hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, 32, GPF>), dim3(acc), dim3(256), lds, s, g);
     return DN_OK;
 }
 }  // namespace
