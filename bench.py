@@ -42,16 +42,17 @@ def op_costs(graph, n):
             m = n * to.h * to.w
             kk = nd.k * nd.k * nd.cin
             ob = 4 if nd.head else 2
-            b = 2 * m * (nd.cin if nd.op == "pw" else nd.cin * (ti.h * ti.w) / (to.h * to.w)) + ob * m * nd.cout \
-                + 2 * kk * nd.cout + 4 * nd.cout
-            if nd.residual >= 0:
-                b += 2 * m * nd.cout
+            bi = 2 * m * (nd.cin if nd.op == "pw" else nd.cin * (ti.h * ti.w) / (to.h * to.w))
+            bo = ob * m * nd.cout
+            bw = 2 * kk * nd.cout + 4 * nd.cout + (2 * m * nd.cout if nd.residual >= 0 else 0)
+            b = bi + bo + bw
             f = 2 * m * kk * nd.cout
             kern = "pw_kernel"
         elif nd.op == "dw":
-            b = 2 * n * (ti.h * ti.w + to.h * to.w) * nd.cin + 2 * nd.k * nd.k * nd.cin + 4 * nd.cin
-            if nd.pool >= 0:
-                b += 2 * n * to.h * to.w * nd.cin          # v1: separate pooling pass re-reads the output
+            bi = 2 * n * ti.h * ti.w * nd.cin
+            bo = 2 * n * to.h * to.w * nd.cin
+            bw = 2 * nd.k * nd.k * nd.cin + 4 * nd.cin
+            b = bi + bo + bw
             f = 2 * n * to.h * to.w * nd.cin * nd.k * nd.k
             kern = f"dw_kernel<{nd.k},{nd.stride}>"
         elif nd.op == "se":
@@ -66,7 +67,10 @@ def op_costs(graph, n):
             b = 4 * n * ti.h * ti.w * nd.cin
             f = 3 * n * ti.h * ti.w * nd.cin
             kern = "l2norm_kernel"
-        out.append(dict(kernel=kern, bytes=float(b), flops=float(f)))
+        c = dict(kernel=kern, bytes=float(b), flops=float(f))
+        if nd.op in ("pw", "dw"):
+            c.update(b_in=float(bi), b_out=float(bo), b_w=float(bw))
+        out.append(c)
     A, K = graph.num_anchors(), graph.num_classes
     topk, D = graph.post["topk_candidates"], graph.post["detections_per_img"]
     out.append(dict(kernel="softmax_decode_kernel", bytes=float(n * A * (4 * K + 16 + 4 * (K - 1) + 16)), flops=float(5 * n * A * K)))
@@ -207,6 +211,16 @@ def main():
                 c["kernel"], c["owner"] = name.value.decode(), owner.value
             else:
                 c["kernel"], c["owner"] = post[i - len(g.nodes)], i
+        # fused inverted-residual launches: the intermediate activations never reach HBM -> external bytes only
+        fused = {}
+        for i, c in enumerate(costs):
+            if c["kernel"].startswith("expdw_kernel"):
+                fused.setdefault(c["owner"], []).append(i)
+        for mem in fused.values():
+            first, last = costs[mem[0]], costs[mem[-1]]
+            ext = first["b_in"] + last["b_out"] + sum(costs[i]["b_w"] for i in mem)
+            for i in mem:
+                costs[i]["bytes"] = ext / len(mem)
         owners = {}
         for i, c in enumerate(costs):
             a = agg.setdefault(c["kernel"], dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
