@@ -107,6 +107,7 @@ int launch_maxpool(const half_t* x, half_t* out, int n, int h, int w, int c, int
                    hipStream_t s);
 int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels, int c, hipStream_t s);
 // bilinear (align_corners=False) resize of NCHW fp32 planes; also writes scale_xy[n][2] = (w/ow, h/oh) in fp32
+int launch_u8hwc_to_planar(const unsigned char* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s);
 int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s);
 
 // fused inverted-residual block (fused.hip): [expand 1x1] -> depthwise -> [project 1x1 (+residual)]

@@ -63,6 +63,15 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const half_t* __restrict__ 
     }
 }
 
+// one rounding per operation, no FMA contraction: the float and the uint8 input paths must produce the same resized image
+__device__ __forceinline__ float bilerp(float a, float b, float c, float d, float hx, float lx, float hy, float ly) {
+#pragma clang fp contract(off)
+    const float t0 = hx * a, t1 = lx * b, b0 = hx * c, b1 = lx * d;
+    const float top = t0 + t1, bot = b0 + b1;
+    const float u = hy * top, v = ly * bot;
+    return u + v;
+}
+
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                     float* __restrict__ scale_xy, int planes, int h, int w, int oh, int ow) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -85,9 +94,43 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
     const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
     const float hy = 1.f - ly, hx = 1.f - lx;
     const float* p = in + (size_t)pl * h * w;
-    const float v = hy * (hx * p[(size_t)y0 * w + x0] + lx * p[(size_t)y0 * w + x1]) +
-                    ly * (hx * p[(size_t)y1 * w + x0] + lx * p[(size_t)y1 * w + x1]);
-    out[((size_t)pl * oh + oy) * ow + ox] = v;
+    out[((size_t)pl * oh + oy) * ow + ox] = bilerp(p[(size_t)y0 * w + x0], p[(size_t)y0 * w + x1], p[(size_t)y1 * w + x0],
+                                                   p[(size_t)y1 * w + x1], hx, lx, hy, ly);
+}
+
+
+// Decoder output straight into the network input: [n][h][w][3] uint8 (HWC, RGB) -> x/255 (ToTensor) -> bilinear resize to the
+// network size (transform.py:27-53, align_corners=False; same arithmetic as resize_kernel) -> [n][3][oh][ow] fp32 planes.
+// With (h, w) == (oh, ow) the interpolation weights are exactly (1, 0): a plain conversion.
+__global__ __launch_bounds__(256) void u8hwc_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
+                                                    float* __restrict__ scale_xy, int n, int h, int w, int oh, int ow) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n && scale_xy) {
+        scale_xy[2 * idx] = (float)w / (float)ow;
+        scale_xy[2 * idx + 1] = (float)h / (float)oh;
+    }
+    const int ox = (int)(idx % ow);
+    idx /= ow;
+    const int oy = (int)(idx % oh);
+    const long img = idx / oh;
+    if (img >= n) return;
+    const float rh = (float)h / (float)oh, rw = (float)w / (float)ow;
+    const float sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const float sx = fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fminf(fmaxf(sy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const unsigned char* p = in + (size_t)img * h * w * 3;
+    const unsigned char* p00 = p + ((size_t)y0 * w + x0) * 3;
+    const unsigned char* p01 = p + ((size_t)y0 * w + x1) * 3;
+    const unsigned char* p10 = p + ((size_t)y1 * w + x0) * 3;
+    const unsigned char* p11 = p + ((size_t)y1 * w + x1) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = (float)p00[c] / 255.f, b = (float)p01[c] / 255.f, cc = (float)p10[c] / 255.f, d = (float)p11[c] / 255.f;
+        out[(((size_t)img * 3 + c) * oh + oy) * ow + ox] = bilerp(a, b, cc, d, hx, lx, hy, ly);
+    }
 }
 
 }  // namespace
@@ -111,5 +154,12 @@ int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels,
 int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s) {
     const long threads = (long)n * 3 * oh * ow;
     hipLaunchKernelGGL(resize_kernel, dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, in, out, scale_xy, n * 3, h, w, oh, ow);
+    return DN_OK;
+}
+
+int launch_u8hwc_to_planar(const unsigned char* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s) {
+    const long threads = (long)n * oh * ow;
+    dn_note_kernel("u8hwc_kernel");
+    hipLaunchKernelGGL(u8hwc_kernel, dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, in, out, scale_xy, n, h, w, oh, ow);
     return DN_OK;
 }

@@ -76,6 +76,7 @@ struct dn_plan {
     hipEvent_t ev_fork = nullptr, ev_branch[3] = {nullptr, nullptr, nullptr};
     std::map<std::pair<int, int>, Layout> sub_layouts;
     float* packed_out = nullptr;
+    bool input_u8 = false;                  // the current call's images are [n][h][w][3] uint8 (dn_forward_u8)
     // head ops (dw -> 1x1 / dense 3x3 per level, both heads) run as grouped launches once the backbone is done
     int head_first = -1;                    // index of the first head-chain op (all later ops are head-chain ops), -1: off
     std::vector<int> head_dw, head_cls, head_reg;            // optional extra output of the merge kernel (dn_set_packed_output)
@@ -381,7 +382,14 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     const float* net_in = images;
     const bool resize = (h != d.image_h || w != d.image_w);
     float* scale_xy = nullptr;
-    if (resize) {
+    if (p->input_u8) {
+        // uint8 HWC decoder output: /255, bilinear resize and HWC -> planar in one pass (the stem then normalises on load)
+        float* rz = reinterpret_cast<float*>(ws + L.resized_off);
+        if (resize) scale_xy = reinterpret_cast<float*>(ws + L.scale_off);
+        int rc = launch_u8hwc_to_planar(reinterpret_cast<const unsigned char*>(images), rz, scale_xy, n, h, w, d.image_h, d.image_w, s);
+        if (rc) return rc;
+        net_in = rz;
+    } else if (resize) {
         // normalisation commutes with bilinear interpolation (affine per channel), so resizing the raw image first and
         // normalising on load in the stem equals transform.py:113-114 (normalize then resize) up to fp32 rounding.
         float* rz = reinterpret_cast<float*>(ws + L.resized_off);
@@ -622,7 +630,9 @@ static int enqueue_all(dn_plan* p, const float* images, int n, int h, int w, flo
             bs = p->branch_stream[k - 1];
             DN_HIP_CHECK(hipStreamWaitEvent(bs, p->ev_fork, 0));
         }
-        int rc = enqueue(p, images + n0 * 3 * (size_t)h * w, ns, h, w, boxes ? boxes + n0 * D * 4 : nullptr, scores ? scores + n0 * D : nullptr,
+        const float* sub_images = p->input_u8 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(images) + n0 * 3 * (size_t)h * w)
+                                              : images + n0 * 3 * (size_t)h * w;
+        int rc = enqueue(p, sub_images, ns, h, w, boxes ? boxes + n0 * D * 4 : nullptr, scores ? scores + n0 * D : nullptr,
                          labels ? labels + n0 * D : nullptr, counts ? counts + n0 : nullptr, ws, V, heads_only, bs, record,
                          p->packed_out ? p->packed_out + n0 * (D + 1) * 6 : nullptr, k * ev_stride);
         if (rc) return rc;
@@ -673,7 +683,7 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     }
     if (!p->graph_mode) return enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, false);
 
-    GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, heads_only ? 1 : 0, p->packed_out};
+    GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, (heads_only ? 1 : 0) | (p->input_u8 ? 2 : 0), p->packed_out};
     auto it = p->graphs.find(key);
     if (it == p->graphs.end()) {
         // first call with this signature: run once eagerly (sets function attributes, validates), then capture
@@ -706,6 +716,16 @@ extern "C" int dn_forward(dn_plan* plan, const float* images_dev, int n, int h, 
                           int64_t* labels_dev, int32_t* counts_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
     return forward_impl(plan, images_dev, n, h, w, boxes_dev, scores_dev, labels_dev, counts_dev, workspace_dev,
                         workspace_bytes, stream, false);
+}
+
+extern "C" int dn_forward_u8(dn_plan* plan, const uint8_t* images_dev, int n, int h, int w, float* boxes_dev, float* scores_dev,
+                             int64_t* labels_dev, int32_t* counts_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    DN_REQUIRE(plan, "dn_forward_u8: null plan");
+    plan->input_u8 = true;
+    const int rc = forward_impl(plan, reinterpret_cast<const float*>(images_dev), n, h, w, boxes_dev, scores_dev, labels_dev, counts_dev,
+                                workspace_dev, workspace_bytes, stream, false);
+    plan->input_u8 = false;
+    return rc;
 }
 
 extern "C" int dn_forward_heads(dn_plan* plan, const float* images_dev, int n, int h, int w, void* workspace_dev,

@@ -170,6 +170,27 @@ class SSD(nn.Module):
                                              C.c_void_p(b["ws"].data_ptr()), b["ws"].numel(), C.c_void_p(stream)), "dn_forward")
         return b["boxes"], b["scores"], b["labels"], b["counts"]
 
+    def forward_uint8(self, images: Tensor, packed: Optional[Tensor] = None):
+        """images: [N,H,W,3] uint8 on the GPU -- a decoder's output (HWC, RGB). ToTensor (/255), the bilinear resize to the network
+        size and the HWC -> planar conversion run on the device ahead of the stem (transform.py:27-53,129-138); results equal
+        forward_batch(images.permute(0,3,1,2).float() / 255). `images` must keep its address between calls for the graph replay.
+        Returns the padded device tensors of forward_batch."""
+        if images.dim() != 4 or images.shape[3] != 3 or images.dtype != torch.uint8:
+            raise ValueError("expected a [N,H,W,3] uint8 batch, got {} {}".format(tuple(images.shape), images.dtype))
+        if not images.is_contiguous():
+            raise ValueError("forward_uint8 needs a contiguous [N,H,W,3] tensor")
+        handle = self._plan(images.device)
+        n, h, w, _ = images.shape
+        b = self._buffers_for(n, h, w, images.device)
+        stream = torch.cuda.current_stream(images.device).cuda_stream
+        _lib.check(_lib.lib().dn_set_packed_output(C.c_void_p(handle), C.c_void_p(packed.data_ptr()) if packed is not None else None))
+        with torch.cuda.device(images.device):
+            _lib.check(_lib.lib().dn_forward_u8(C.c_void_p(handle), C.c_void_p(images.data_ptr()), n, h, w,
+                                                C.c_void_p(b["boxes"].data_ptr()), C.c_void_p(b["scores"].data_ptr()),
+                                                C.c_void_p(b["labels"].data_ptr()), C.c_void_p(b["counts"].data_ptr()),
+                                                C.c_void_p(b["ws"].data_ptr()), b["ws"].numel(), C.c_void_p(stream)), "dn_forward_u8")
+        return b["boxes"], b["scores"], b["labels"], b["counts"]
+
     def batch_split(self, n: int) -> int:
         """Number of parallel sub-batch launch chains a forward of n images is issued as (1 = a single chain)."""
         if self._handle is None:

@@ -84,6 +84,30 @@ def test_state_dict_keys_and_lowering(name, ncls, nparams):
     np.testing.assert_allclose(bias, b - mu * sc, rtol=1e-6, atol=1e-6)
 
 
+def test_checkpoint_ingestion_by_reference_key_names(tmp_path):
+    """a torchvision-format checkpoint (a pickled state_dict with the reference's key names, BN buffers and
+    num_batches_tracked included; ssd_mobilenetv3.py:20-23,222-224) loads through the factory's load_state_dict, strictly, and
+    lowers to exactly the blob the same weights give when injected directly."""
+    m = models.ssdlite320_mobilenet_v3_large(num_classes=91)
+    src = {k: torch.from_numpy(np.asarray(v).copy()) for k, v in synth.state_dict(m.graph, 2).items()}
+    assert any(k.endswith("num_batches_tracked") for k in src)
+    path = tmp_path / "ssdlite320_mobilenet_v3_large_coco-synthetic.pth"
+    torch.save(src, path)
+    ck = torch.load(path, map_location="cpu")
+    res = m.load_state_dict(ck)                                    # strict=True: any key mismatch raises
+    assert not res.missing_keys and not res.unexpected_keys
+    a = LoweredModel(m.graph, m.state_dict())
+    b = LoweredModel(m.graph, {k: v.numpy() for k, v in src.items()})
+    assert bytes(a.blob) == bytes(b.blob)
+    # a checkpoint of another architecture / class count is refused, as nn.Module.load_state_dict does for the reference
+    bad = dict(ck)
+    bad.pop("head.classification_head.module_list.0.1.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    with pytest.raises(RuntimeError):
+        models.ssdlite320_mobilenet_v3_large(num_classes=21).load_state_dict(ck)      # 6*21 != 6*91 output channels
+
+
 def test_factory_api_mirrors_reference():
     with pytest.warns(UserWarning):
         m = models.ssdlite320_mobilenet_v3_large(num_classes=5, size=(300, 300), score_thresh=0.3)     # ssd_mobilenetv3.py:183-184

@@ -258,6 +258,27 @@ def test_sub_batch_branches_equal_separate_forwards(n, hw):
     assert d.max().item() < 2e-2 and d.mean().item() < 2e-3
 
 
+@pytest.mark.parametrize("n,h,w", [(3, 320, 320), (2, 500, 400), (33, 240, 320)])
+def test_uint8_hwc_input_equals_float_path(n, h, w):
+    """decoder output (uint8 HWC) -> /255 -> bilinear resize -> planar, on the device ahead of the stem.
+    Must equal the float path fed to_tensor(images) bit for bit (same resize arithmetic), incl. the box back-mapping
+    (transform.py:278-292) and the sub-batch branches (n >= 32)."""
+    m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    u8 = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, generator=g).cuda()
+    # ToTensor divides on the CPU (true division); torch's GPU kernel multiplies by 1/255 instead, which differs in the last ulp
+    ref_in = (u8.cpu().permute(0, 3, 1, 2).float() / 255).contiguous().cuda()
+    ref = [t.clone() for t in m.forward_batch(ref_in, persistent_input=True)]
+    for _ in range(2):          # eager capture pass, then graph replay
+        got = [t.clone() for t in m.forward_uint8(u8)]
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert int(ref[3].sum()) > 0
+    with pytest.raises(ValueError):
+        m.forward_uint8(u8.permute(0, 3, 1, 2))          # not HWC
+
+
 def test_error_behaviour_matches_reference():
     m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
     with pytest.raises(ValueError):

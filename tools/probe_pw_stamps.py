@@ -7,7 +7,7 @@ from demonet_amd import _lib
 L = _lib.lib()
 L.dn_debug_pw_stamps.argtypes = [C.c_void_p]
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-for (m, ci, co, act) in [(25600, 112, 672, 3), (25600, 672, 112, 0), (25600, 80, 200, 3), (102400, 40, 120, 1), (409600, 24, 72, 1), (1638400, 16, 64, 1)]:
+for (m, ci, co, act) in [(12800, 80, 184, 3), (12800, 112, 672, 3), (51200, 40, 120, 1), (51200, 72, 40, 0), (204800, 24, 72, 1), (3200, 80, 480, 3), (12800, 80, 480, 3)]:
     x = torch.randn(m, ci, device="cuda").half(); w = torch.randn(co, ci, device="cuda").half(); b = torch.randn(co, device="cuda")
     o = torch.empty(m, co, device="cuda", dtype=torch.half)
     st = torch.zeros(8 * 40000, dtype=torch.int64, device="cuda")
