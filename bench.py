@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
+    ap.add_argument("--input", choices=["f32", "u8"], default="f32",
+                    help="f32: NCHW float images in [0,1] (the headline window, engine.py:86); u8: the decoder's [N,H,W,3] uint8 output")
     ap.add_argument("--per-op", default="", help="write a per-op table (time, GB/s, TFLOP/s) to this file")
     args = ap.parse_args()
 
@@ -138,6 +140,7 @@ def main():
     images = torch.from_numpy(synth.images(1002 + rank, B, H, W)).to(dev)      # device-resident input (engine.py:86)
     if args.eager:
         model.set_graph_mode(False)
+    images_u8 = (images * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous() if args.input == "u8" else None
 
     gatherer = DetectionGatherer(B, g.post["detections_per_img"], dev) if distributed else None
 
@@ -146,6 +149,8 @@ def main():
             # the merge kernel writes the gather payload itself; ONE packed all_gather on a side stream, overlapped with the next step
             boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True, packed=gatherer.next_buffer())
             gatherer.submit()
+        elif images_u8 is not None:
+            boxes, scores, labels, counts = model.forward_uint8(images_u8)
         else:
             boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True)
         return counts
@@ -184,6 +189,7 @@ def main():
                                f"synthetic weights seed 0, post-process incl. per-class top-{g.post['topk_candidates']} + hard NMS",
                    "global_batch": B * world, "launch": ("eager" if args.eager else "hipGraph replay") + f", {model.batch_split(B)} sub-batch branch(es)",
                    "parallelism": f"image-sharded x{world}, RCCL all_gather of detections" if distributed else "single GPU",
+                   "input": "NCHW fp32 in [0,1], device-resident" if args.input == "f32" else "NHWC uint8 (decoder output), device-resident",
                    "mean_detections": float(counts.float().mean().item())},
     }
 
