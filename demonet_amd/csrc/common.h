@@ -111,6 +111,25 @@ int launch_u8hwc_to_planar(const unsigned char* in, float* out, float* scale_xy,
 int launch_resize_bilinear(const float* in, float* out, float* scale_xy, int n, int h, int w, int oh, int ow, hipStream_t s);
 
 // fused inverted-residual block (fused.hip): [expand 1x1] -> depthwise -> [project 1x1 (+residual)]
+// run of tiny layers (<= 32 output pixels each) executed by one workgroup per image with the activations in LDS (tail.hip)
+constexpr int TAIL_MAX_OPS = 16;
+struct TailOp {
+    int type, cin, cout, k, stride, pad, hin, win, hout, wout, act;
+    long w_off;             // halfs from TailArgs::weights
+    long b_off;             // bytes from TailArgs::weights
+    half_t* out;            // non-null: the output is also written to HBM (per-image stride out_stride halfs)
+    long out_stride;
+};
+struct TailArgs {
+    int count, buf_halfs, buf2_halfs;
+    const half_t* in0; long in0_stride;     // first op's input [n][pixels][cin], per-image stride in halfs
+    const half_t* weights;
+    long long* stamps;                      // dev-only
+    TailOp op[TAIL_MAX_OPS];
+};
+int launch_tail(const TailArgs& a, int n, hipStream_t s);
+bool tail_op_supported(const dn_op_desc& o, int hin, int win, int hout, int wout);
+
 // expand 1x1 + depthwise kxk in one launch (expdw.hip)
 struct ExpDwArgs {
     const half_t* x; half_t* out; float* pool;     // pool (optional): [n][tiles][cexp] fp32 per-tile channel sums

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <tuple>
@@ -79,7 +80,10 @@ struct dn_plan {
     bool input_u8 = false;                  // the current call's images are [n][h][w][3] uint8 (dn_forward_u8)
     // head ops (dw -> 1x1 / dense 3x3 per level, both heads) run as grouped launches once the backbone is done
     int head_first = -1;                    // index of the first head-chain op (all later ops are head-chain ops), -1: off
-    std::vector<int> head_dw, head_cls, head_reg;            // optional extra output of the merge kernel (dn_set_packed_output)
+    std::vector<int> head_dw, head_cls, head_reg;
+    // run of tiny backbone layers [tail_first, tail_end) executed by one per-image workgroup (tail.hip); -1: none
+    int tail_first = -1, tail_end = -1;
+    std::vector<char> tail_materialise;     // per op of the run: its output is read outside the run (pyramid feature) -> also to HBM            // optional extra output of the merge kernel (dn_set_packed_output)
     // inverted-residual stages that run as one launch (expdw.hip): at the first op of a group, fused_len = number of ops and
     // fused_kind bit0 = has expand (1x1), bit1 = has project (1x1 [+ residual]); the depthwise op is always part of it
     std::vector<int> fused_len, fused_kind;
@@ -272,6 +276,39 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (ok && (kinds == 3 || p->head_dw.size() > 12 || p->head_cls.size() > 8 || p->head_reg.size() > 8 || p->head_cls.empty())) ok = false;
         if (ok) p->head_first = first;
         else { p->head_dw.clear(); p->head_cls.clear(); p->head_reg.clear(); }
+    }
+    // ---- tail run: the longest suffix of the backbone (ops before the heads) that is a linear chain of tiny layers
+    if ((getenv("DN_TAIL") ? atoi(getenv("DN_TAIL")) : 1) != 0) {
+        const int end = p->head_first >= 0 ? p->head_first : desc->n_ops;
+        int first = end;
+        while (first > 0) {
+            const int i = first - 1;
+            const dn_op_desc& o = p->ops[i];
+            const dn_tensor_desc& ti = p->tensors[o.in];
+            const dn_tensor_desc& to = p->tensors[o.out];
+            bool fused = p->fused_len[i] > 0;
+            for (int q = 1; q <= 2 && i - q >= 0; ++q) fused |= p->fused_len[i - q] > q;
+            if (fused || ti.kind != DN_T_ACT || !tail_op_supported(o, ti.h, ti.w, to.h, to.w)) break;
+            if (first < end && p->ops[first].in != o.out) break;         // must feed the next op of the run
+            --first;
+        }
+        if (end - first > TAIL_MAX_OPS) first = end - TAIL_MAX_OPS;
+        if (end - first >= 2) {
+            p->tail_first = first;
+            p->tail_end = end;
+            p->tail_materialise.assign(end - first, 0);
+            for (int i = first; i < end; ++i) {
+                const int t = p->ops[i].out;
+                bool outside = false;
+                for (int l = 0; l < desc->n_levels; ++l) outside |= desc->level_tensor[l] == t;
+                for (int j = 0; j < desc->n_ops; ++j) {
+                    if (j >= first && j < end) continue;
+                    const dn_op_desc& u = p->ops[j];
+                    outside |= (u.in == t || u.residual == t || u.se == t);
+                }
+                p->tail_materialise[i - first] = outside ? 1 : 0;
+            }
+        }
     }
     p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
     p->split = getenv("DN_SPLIT") ? atoi(getenv("DN_SPLIT")) : 2;
@@ -510,6 +547,32 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             for (size_t q = seg + 1; q < p->ops.size(); ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             break;
+        }
+        if ((int)i == p->tail_first) {
+            TailArgs ta{};
+            ta.count = p->tail_end - p->tail_first;
+            ta.weights = reinterpret_cast<const half_t*>(W);
+            const dn_op_desc& o0 = p->ops[i];
+            ta.in0 = reinterpret_cast<const half_t*>(tptr(o0.in));
+            ta.in0_stride = (long)(L.tbytes[o0.in] / (size_t)L.n / 2);
+            for (int q = 0; q < ta.count; ++q) {
+                const dn_op_desc& oq = p->ops[i + q];
+                const dn_tensor_desc& tq = p->tensors[oq.in];
+                const dn_tensor_desc& uq = p->tensors[oq.out];
+                TailOp& t = ta.op[q];
+                t.type = oq.type; t.cin = oq.cin; t.cout = oq.type == DN_OP_DW ? oq.cin : oq.cout; t.k = oq.k; t.stride = oq.stride; t.pad = oq.pad;
+                t.hin = tq.h; t.win = tq.w; t.hout = uq.h; t.wout = uq.w; t.act = oq.act;
+                t.w_off = (long)((oq.type == DN_OP_PW ? oq.w2_off : oq.w_off) / 2); t.b_off = (long)oq.b_off;
+                t.out = p->tail_materialise[q] ? reinterpret_cast<half_t*>(tptr(oq.out)) : nullptr;
+                t.out_stride = (long)(L.tbytes[oq.out] / (size_t)L.n / 2);
+            }
+            rc = launch_tail(ta, n, s);
+            if (rc != DN_OK) return rc;
+            for (int q = 0; q < ta.count; ++q) note(i + q, i);
+            for (int q = 1; q < ta.count; ++q)
+                if (record) (void)hipEventRecord(p->events[ev++], s);
+            i += ta.count - 1;
+            continue;
         }
         if (p->fused_len[i] > 0) {
             const int kind = p->fused_kind[i], len = p->fused_len[i];

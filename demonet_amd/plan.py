@@ -79,8 +79,18 @@ class LoweredModel:
             elif nd.op == "pw":
                 w = _np(state_dict, nd.conv_key + ".weight").reshape(nd.cout, nd.cin)
                 s, b = _fold(state_dict, nd, nd.cout)
-                o.w_off = blob.add((w * s[:, None]).astype(np.float16))
+                wf = (w * s[:, None]).astype(np.float16)
+                o.w_off = blob.add(wf)
                 o.b_off = blob.add(b.astype(np.float32))
+                if nd.cin % 16 == 0 and not nd.head:
+                    # second copy in MFMA-fragment order for the kernels that stream weights straight from L2 into A fragments
+                    # (tail.hip): [cout tile of 32][16-deep K step][lane = (k half, channel)][8 halfs] -> each wave-wide load is
+                    # 1 KB contiguous instead of 32 row pieces of 32 B
+                    nt, ks = (nd.cout + 31) // 32, nd.cin // 16
+                    padded = np.zeros((nt * 32, nd.cin), dtype=np.float16)
+                    padded[:nd.cout] = wf
+                    frag = padded.reshape(nt, 32, ks, 2, 8).transpose(0, 2, 3, 1, 4)
+                    o.w2_off = blob.add(np.ascontiguousarray(frag))
             elif nd.op == "dw":
                 w = _np(state_dict, nd.conv_key + ".weight").reshape(nd.cin, nd.k * nd.k)
                 s, b = _fold(state_dict, nd, nd.cin)

@@ -52,6 +52,8 @@ typedef struct dn_op_desc {
     int32_t reserved[2];
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob; -1 none.
                                                PW/CONV: w = fp16 [cout][k*k*cin] (tap-major, channel-minor), b = fp32 [cout]
+                                               PW (optional, cin % 16 == 0): w2 = the same weights in MFMA-fragment order
+                                                 [ceil(cout/32)][cin/16][2 k-halves][32 channels][8] fp16, zero rows beyond cout; -1: none
                                                DW/STEM: w = fp16 [k*k][c] / fp32 [k*k*3][cout], b = fp32 [c]
                                                SE: w = fp16 fc1 weight TRANSPOSED [c][squeeze], b = fp32 fc1 bias, w2 = fp16 fc2 weight TRANSPOSED [squeeze][c], b2 = fp32 fc2 bias (c, squeeze even)
                                                L2NORM: w = fp32 scale [c] */
