@@ -60,6 +60,7 @@ static inline int dn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 struct PwArgs {
     // implicit-GEMM geometry (dense kxk conv); pointwise uses k=1: x rows are then simply [m][cin]
     int cv_k = 1, cv_stride = 1, cv_pad = 0, cv_dil = 1, cv_h = 0, cv_w = 0, cv_ho = 0, cv_wo = 0, cv_cin = 0;
+    const half_t* wfrag = nullptr;   // optional: the weights in MFMA-fragment order (dn_op_desc::w2_off), used by the strip kernel
     const half_t* x;        // [m][cin]
     const half_t* w;        // [cout][cin]
     const float* bias;      // [cout]

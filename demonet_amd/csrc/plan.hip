@@ -443,6 +443,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         PwArgs a;
         a.x = reinterpret_cast<const half_t*>(tptr(o.in));
         a.w = reinterpret_cast<const half_t*>(Wb + o.w_off);
+        a.wfrag = (o.type == DN_OP_PW && o.w2_off >= 0) ? reinterpret_cast<const half_t*>(Wb + o.w2_off) : nullptr;
         a.bias = reinterpret_cast<const float*>(Wb + o.b_off);
         a.residual = o.residual >= 0 ? reinterpret_cast<const half_t*>(tptr(o.residual)) : nullptr;
         a.se = o.se >= 0 ? reinterpret_cast<const float*>(tptr(o.se)) : nullptr;
@@ -873,12 +874,13 @@ extern "C" int dn_postprocess(const float* logits, const float* reg, const float
     return launch_postprocess(a, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
-extern "C" int dn_pointwise_conv(const void* x, const void* w, const float* bias, const void* residual, const float* se,
-                                 void* out, int m, int cin, int cout, int hw, int act, int out_fp32, int64_t out_img_stride,
-                                 void* stream) {
+extern "C" int dn_pointwise_conv(const void* x, const void* w, const void* w_frag, const float* bias, const void* residual,
+                                 const float* se, void* out, int m, int cin, int cout, int hw, int act, int out_fp32,
+                                 int64_t out_img_stride, void* stream) {
     DN_REQUIRE(x && w && bias && out, "dn_pointwise_conv: null argument");
     PwArgs a;
     a.x = reinterpret_cast<const half_t*>(x); a.w = reinterpret_cast<const half_t*>(w); a.bias = bias;
+    a.wfrag = reinterpret_cast<const half_t*>(w_frag);
     a.residual = reinterpret_cast<const half_t*>(residual); a.se = se; a.out = out;
     a.m = m; a.cin = cin; a.cout = cout; a.hw = hw; a.act = act; a.out_fp32 = out_fp32;
     a.out_img_stride = out_fp32 ? (long)out_img_stride : 0; a.out_base = 0;

@@ -465,14 +465,14 @@ __global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a) {
         }
     }
 
+    // weights come from the fragment-major copy (plan.py): [channel tile][K step][lane][8 halfs], zero rows beyond cout -- every
+    // wave-wide load is 1 KB contiguous and needs no per-lane predicate (K % 16 == 0 for these layers)
     auto load_w = [&](half8 (&wf)[KC], int nt, int ks0) {
-        const int n = nt * 32 + r;
-        const half_t* wr = a.w + (size_t)n * K + hh * 8;
+        const half_t* wr = a.wfrag + (size_t)nt * KS * 512 + lane * 8;
 #pragma unroll
         for (int u = 0; u < KC; ++u) {
-            const int k = (ks0 + u) * 16 + hh * 8;
             half8 t = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (n < NC && k < K) t = *reinterpret_cast<const half8*>(wr + (ks0 + u) * 16);
+            if (ks0 + u < KS) t = *reinterpret_cast<const half8*>(wr + (size_t)(ks0 + u) * 512);
             wf[u] = t;
         }
     };
@@ -731,8 +731,8 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
     static const int xs_mode = getenv("DN_PW_XS") ? atoi(getenv("DN_PW_XS")) : 1;
-    if (g_pw_tile == 8) return launch_xs<32>(a, s);
-    if (xs_mode && !g_pw_tile && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&
+    if (g_pw_tile == 8 && a.wfrag) return launch_xs<32>(a, s);
+    if (xs_mode && !g_pw_tile && a.wfrag && a.cin % 16 == 0 && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&
         ((a.cin >= 64 && a.m <= 8192) || (a.cin >= 160 && a.m <= 16384))) {
         // measured (tools/tune_pw.py): the strip kernel wins where the tiled kernel cannot fill the chip -- M <= ~8k rows, or
         // M <= ~16k rows when K is long (the tiled kernel pays one exposed round trip per 32-deep K stage)

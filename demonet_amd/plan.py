@@ -14,6 +14,16 @@ from .anchors import default_boxes
 from .spec import Graph
 
 
+def fragment_major(w16: np.ndarray) -> np.ndarray:
+    """[cout][cin] fp16 (cin % 16 == 0) -> MFMA-fragment order [ceil(cout/32)][cin/16][2][32][8], zero rows beyond cout: the layout
+    of dn_op_desc.w2_off for PW ops (each wave-wide weight load of the streaming kernels is then 1 KB contiguous)."""
+    cout, cin = w16.shape
+    nt, ks = (cout + 31) // 32, cin // 16
+    padded = np.zeros((nt * 32, cin), dtype=np.float16)
+    padded[:cout] = w16
+    return np.ascontiguousarray(padded.reshape(nt, 32, ks, 2, 8).transpose(0, 2, 3, 1, 4))
+
+
 class _Blob:
     def __init__(self):
         self.parts = []
@@ -86,11 +96,7 @@ class LoweredModel:
                     # second copy in MFMA-fragment order for the kernels that stream weights straight from L2 into A fragments
                     # (tail.hip): [cout tile of 32][16-deep K step][lane = (k half, channel)][8 halfs] -> each wave-wide load is
                     # 1 KB contiguous instead of 32 row pieces of 32 B
-                    nt, ks = (nd.cout + 31) // 32, nd.cin // 16
-                    padded = np.zeros((nt * 32, nd.cin), dtype=np.float16)
-                    padded[:nd.cout] = wf
-                    frag = padded.reshape(nt, 32, ks, 2, 8).transpose(0, 2, 3, 1, 4)
-                    o.w2_off = blob.add(np.ascontiguousarray(frag))
+                    o.w2_off = blob.add(fragment_major(wf))
             elif nd.op == "dw":
                 w = _np(state_dict, nd.conv_key + ".weight").reshape(nd.cin, nd.k * nd.k)
                 s, b = _fold(state_dict, nd, nd.cin)

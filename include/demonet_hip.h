@@ -123,11 +123,12 @@ DN_API int dn_postprocess(const float* cls_logits_dev, const float* bbox_regress
 
 /* Single-kernel entry points (unit parity tests, micro-benchmarks, roofline measurement).
  * x: [m][cin] fp16 (NHWC rows), w: [cout][cin] fp16, bias fp32 [cout], residual [m][cout] fp16 or NULL,
+ * w_frag (optional, cin % 16 == 0): the same weights in MFMA-fragment order (dn_op_desc PW w2) -- enables the strip kernel,
  * se_scale fp32 [m/hw][cin] or NULL, out fp16 [m][cout] (out_fp32 != 0: fp32, addressed
  * (row/hw)*out_img_stride + (row%hw)*cout + c). */
-DN_API int dn_pointwise_conv(const void* x_dev, const void* w_dev, const float* bias_dev, const void* residual_dev,
-                      const float* se_scale_dev, void* out_dev, int m, int cin, int cout, int hw, int act,
-                      int out_fp32, int64_t out_img_stride, void* stream);
+DN_API int dn_pointwise_conv(const void* x_dev, const void* w_dev, const void* w_frag_dev, const float* bias_dev,
+                      const void* residual_dev, const float* se_scale_dev, void* out_dev, int m, int cin, int cout, int hw,
+                      int act, int out_fp32, int64_t out_img_stride, void* stream);
 /* x: [n][h][w][c] fp16, w: [k*k][c] fp16, bias fp32 [c], out [n][ho][wo][c] fp16 */
 DN_API int dn_depthwise_conv(const void* x_dev, const void* w_dev, const float* bias_dev, void* out_dev,
                       int n, int h, int w, int c, int k, int stride, int pad, int act, void* stream);

@@ -35,7 +35,7 @@ def pw(m, cin, cout, hw, act=0, res=False, fp32=False, nbuf=4, dbg=0):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def fn(i):
-        _lib.check(L.dn_pointwise_conv(P(xs[i % nbuf]), P(w), P(b), P(r), None, P(outs[i % nbuf]), m, cin, cout, hw,
+        _lib.check(L.dn_pointwise_conv(P(xs[i % nbuf]), P(w), None, P(b), P(r), None, P(outs[i % nbuf]), m, cin, cout, hw,
                                        act | (dbg << 8), int(fp32), hw * cout, st))
     us = time_fn(fn)
     by = 2 * m * cin + (4 if fp32 else 2) * m * cout + 2 * cin * cout + (2 * m * cout if res else 0)

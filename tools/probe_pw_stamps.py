@@ -11,7 +11,7 @@ for (m, ci, co, act) in [(12800, 80, 184, 3), (12800, 112, 672, 3), (51200, 40, 
     x = torch.randn(m, ci, device="cuda").half(); w = torch.randn(co, ci, device="cuda").half(); b = torch.randn(co, device="cuda")
     o = torch.empty(m, co, device="cuda", dtype=torch.half)
     st = torch.zeros(8 * 40000, dtype=torch.int64, device="cuda")
-    call = lambda: _lib.check(L.dn_pointwise_conv(P(x), P(w), P(b), None, None, P(o), m, ci, co, m, act, 0, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    call = lambda: _lib.check(L.dn_pointwise_conv(P(x), P(w), None, P(b), None, None, P(o), m, ci, co, m, act, 0, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     for _ in range(3): call()
     torch.cuda.synchronize()
     L.dn_debug_pw_stamps(C.c_void_p(st.data_ptr())); call(); torch.cuda.synchronize(); L.dn_debug_pw_stamps(None)

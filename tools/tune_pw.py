@@ -42,7 +42,7 @@ for (m, ci, co, res, se, hw) in shapes:
             row.append(float("nan")); continue
         L.dn_debug_pw_tile(t)
         def call(i):
-            _lib.check(L.dn_pointwise_conv(P(xs[i % R]), P(w), P(b), P(rs[i % R]), P(sev), P(os_[i % R]), m, ci, co, hw, 3, 0, 0, stream))
+            _lib.check(L.dn_pointwise_conv(P(xs[i % R]), P(w), None, P(b), P(rs[i % R]), P(sev), P(os_[i % R]), m, ci, co, hw, 3, 0, 0, stream))
         call(0); call(1)
         tot = 0.0
         for i in range(10):
