@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a) {
     }
 
     // weights come from the fragment-major copy (plan.py): [channel tile][K step][lane][8 halfs], zero rows beyond cout -- every
-    // wave-wide load is 1 KB contiguous and needs no per-lane predicate (K % 16 == 0 for these layers)
+    // wave-wide load is 1 KB contiguous and needs no per-lane predicate (K is zero-padded to a multiple of 16 in the copy, as in the strip)
     auto load_w = [&](half8 (&wf)[KC], int nt, int ks0) {
         const half_t* wr = a.wfrag + (size_t)nt * KS * 512 + lane * 8;
 #pragma unroll
@@ -732,7 +732,7 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
     static const int xs_mode = getenv("DN_PW_XS") ? atoi(getenv("DN_PW_XS")) : 1;
     if (g_pw_tile == 8 && a.wfrag) return launch_xs<32>(a, s);
-    if (xs_mode && !g_pw_tile && a.wfrag && a.cin % 16 == 0 && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&
+    if (xs_mode && !g_pw_tile && a.wfrag && a.cin % 16 == 0 && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&      // (K % 16 == 8: measured slower than the tiled kernel)
         ((a.cin >= 64 && a.m <= 8192) || (a.cin >= 160 && a.m <= 16384))) {
         // measured (tools/tune_pw.py): the strip kernel wins where the tiled kernel cannot fill the chip -- M <= ~8k rows, or
         // M <= ~16k rows when K is long (the tiled kernel pays one exposed round trip per 32-deep K stage)

@@ -15,12 +15,12 @@ from .spec import Graph
 
 
 def fragment_major(w16: np.ndarray) -> np.ndarray:
-    """[cout][cin] fp16 (cin % 16 == 0) -> MFMA-fragment order [ceil(cout/32)][cin/16][2][32][8], zero rows beyond cout: the layout
+    """[cout][cin] fp16 -> MFMA-fragment order [ceil(cout/32)][ceil(cin/16)][2][32][8], zero rows / columns beyond cout / cin: the layout
     of dn_op_desc.w2_off for PW ops (each wave-wide weight load of the streaming kernels is then 1 KB contiguous)."""
     cout, cin = w16.shape
-    nt, ks = (cout + 31) // 32, cin // 16
-    padded = np.zeros((nt * 32, cin), dtype=np.float16)
-    padded[:cout] = w16
+    nt, ks = (cout + 31) // 32, (cin + 15) // 16
+    padded = np.zeros((nt * 32, ks * 16), dtype=np.float16)
+    padded[:cout, :cin] = w16
     return np.ascontiguousarray(padded.reshape(nt, 32, ks, 2, 8).transpose(0, 2, 3, 1, 4))
 
 
@@ -92,7 +92,7 @@ class LoweredModel:
                 wf = (w * s[:, None]).astype(np.float16)
                 o.w_off = blob.add(wf)
                 o.b_off = blob.add(b.astype(np.float32))
-                if nd.cin % 16 == 0 and not nd.head:
+                if nd.cin % 8 == 0 and not nd.head:
                     # second copy in MFMA-fragment order for the kernels that stream weights straight from L2 into A fragments
                     # (tail.hip): [cout tile of 32][16-deep K step][lane = (k half, channel)][8 halfs] -> each wave-wide load is
                     # 1 KB contiguous instead of 32 row pieces of 32 B

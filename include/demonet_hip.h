@@ -52,8 +52,8 @@ typedef struct dn_op_desc {
     int32_t reserved[2];
     int64_t w_off, b_off, w2_off, b2_off;   /* byte offsets into the weight blob; -1 none.
                                                PW/CONV: w = fp16 [cout][k*k*cin] (tap-major, channel-minor), b = fp32 [cout]
-                                               PW (optional, cin % 16 == 0): w2 = the same weights in MFMA-fragment order
-                                                 [ceil(cout/32)][cin/16][2 k-halves][32 channels][8] fp16, zero rows beyond cout; -1: none
+                                               PW (optional): w2 = the same weights in MFMA-fragment order
+                                                 [ceil(cout/32)][ceil(cin/16)][2 k-halves][32 channels][8] fp16, zero beyond cout / cin; -1: none
                                                DW/STEM: w = fp16 [k*k][c] / fp32 [k*k*3][cout], b = fp32 [c]
                                                SE: w = fp16 fc1 weight TRANSPOSED [c][squeeze], b = fp32 fc1 bias, w2 = fp16 fc2 weight TRANSPOSED [squeeze][c], b2 = fp32 fc2 bias (c, squeeze even)
                                                L2NORM: w = fp32 scale [c] */
@@ -123,7 +123,7 @@ DN_API int dn_postprocess(const float* cls_logits_dev, const float* bbox_regress
 
 /* Single-kernel entry points (unit parity tests, micro-benchmarks, roofline measurement).
  * x: [m][cin] fp16 (NHWC rows), w: [cout][cin] fp16, bias fp32 [cout], residual [m][cout] fp16 or NULL,
- * w_frag (optional, cin % 16 == 0): the same weights in MFMA-fragment order (dn_op_desc PW w2) -- enables the strip kernel,
+ * w_frag (optional): the same weights in MFMA-fragment order (dn_op_desc PW w2) -- enables the strip kernel,
  * se_scale fp32 [m/hw][cin] or NULL, out fp16 [m][cout] (out_fp32 != 0: fp32, addressed
  * (row/hw)*out_img_stride + (row%hw)*cout + c). */
 DN_API int dn_pointwise_conv(const void* x_dev, const void* w_dev, const void* w_frag_dev, const float* bias_dev,

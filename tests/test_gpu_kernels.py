@@ -75,7 +75,7 @@ def test_pointwise_conv(m, cin, cout, hw, act, res, se, fp32):
     else:
         stride = 0
         out = torch.zeros(m, cout, dtype=torch.half, device=dev)
-    wfd = torch.from_numpy(fragment_major(w.numpy())).to(dev) if cin % 16 == 0 else None     # lets the strip kernel be chosen
+    wfd = torch.from_numpy(fragment_major(w.numpy())).to(dev)     # lets the strip kernel be chosen
     rc = lib.dn_pointwise_conv(_ptr(xd), _ptr(wd), _ptr(wfd), _ptr(bd), _ptr(rd), _ptr(sd), _ptr(out), m, cin, cout, hw, act,
                                int(fp32), stride, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     L.check(rc, "dn_pointwise_conv")

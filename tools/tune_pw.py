@@ -9,6 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from demonet_amd import _lib, spec
+from demonet_amd.plan import fragment_major
 L = _lib.lib()
 L.dn_debug_pw_tile.argtypes = [C.c_int]
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
@@ -36,13 +37,14 @@ for (m, ci, co, res, se, hw) in shapes:
     rs = [torch.randn(m, co, device="cuda").half() for _ in range(R)] if res else [None] * R
     sev = torch.rand(m // hw, ci, device="cuda") if se else None
     w = torch.randn(co, ci, device="cuda").half(); b = torch.randn(co, device="cuda")
+    wf = torch.from_numpy(fragment_major(w.cpu().numpy())).cuda() if ci % 16 == 0 else None
     row = []
     for t in [0] + list(TILES):
-        if t == 8 and (ci < 64 or ci > 1024 or m > 30000):
+        if t == 8 and (ci % 16 or ci > 1024 or m > 60000):
             row.append(float("nan")); continue
         L.dn_debug_pw_tile(t)
         def call(i):
-            _lib.check(L.dn_pointwise_conv(P(xs[i % R]), P(w), None, P(b), P(rs[i % R]), P(sev), P(os_[i % R]), m, ci, co, hw, 3, 0, 0, stream))
+            _lib.check(L.dn_pointwise_conv(P(xs[i % R]), P(w), P(wf), P(b), P(rs[i % R]), P(sev), P(os_[i % R]), m, ci, co, hw, 3, 0, 0, stream))
         call(0); call(1)
         tot = 0.0
         for i in range(10):
