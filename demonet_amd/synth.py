@@ -17,7 +17,7 @@ CALIBRATED_SEEDS = (0, 1, 2)
 
 
 def calibration(model_name: str, seed: int = 0):
-    """Per-conv weight multipliers measured once at authoring time (tools/calibrate_synth.py): they play the
+    """Per-conv weight multipliers measured once at authoring time (tests/golden/calibrate_synth.py): they play the
     role training plays for real checkpoints -- keeping every layer's output near unit variance under the
     fixed synthetic BN statistics. Pure data; identical on every machine. Tables exist for the weight seeds
     in CALIBRATED_SEEDS; other seeds get uncalibrated weights (still valid, but activations drift)."""

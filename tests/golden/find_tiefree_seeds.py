@@ -1,6 +1,6 @@
 """Authoring-time helper: scan image seeds with the ORACLE for post-process instances that are far from any\norder/threshold flip (see oracle.selection_margins). usage: find_tiefree_seeds.py <model> <num_classes> <lo> <hi>"""
 import sys, numpy as np, torch
-import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'oracle'))
+import os; R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,'oracle'))
 from demonet_amd import spec, synth
 import ssd_oracle as so
 torch.set_num_threads(8)

@@ -23,7 +23,7 @@ import run_reference as rr  # noqa: E402
 import ssd_oracle as so  # noqa: E402
 
 CASES = [
-    # name, num_classes, weight seed, per-image seeds (chosen tie-free by tools/find_tiefree_seeds.py), full-logits images
+    # name, num_classes, weight seed, per-image seeds (chosen tie-free by tests/golden/find_tiefree_seeds.py), full-logits images
     ("ssdlite320_mobilenet_v3_large", 91, 0, [1008, 1021], 1),
     ("ssd_lite_mobilenet_v2", 21, 0, [1005], 1),
     ("ssd300_vgg16", 91, 0, [1005], 0),
