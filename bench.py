@@ -6,8 +6,9 @@
 A step = one pass of the whole hot path (stem .. heads .. softmax/decode/top-k/NMS/merge) over one device-resident
 batch of synthetic 320x320 images (BASELINE.json configs[1]: ssdlite320_mobilenet_v3_large fp16, batch 64 per GPU).
 Timing window = engine.evaluate's (engine.py:86-94): inputs already on the device, synchronize, forward incl.
-post-process, outputs complete on the stream. N > 1: every rank runs its own 64-image shard (weak scaling) and the
-fixed-shape detections are all-gathered over RCCL each step.
+post-process, outputs complete on the stream. N > 1: every rank runs its own 64-image shard (weak scaling); the fixed-shape
+detections of every step are staged on the device and all-gathered over RCCL one window (8 steps) at a time, the last window
+flushed inside the timed region (the reference gathers once, after the loop: engine.py:105).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -146,7 +147,7 @@ def main():
 
     def step():
         if distributed:
-            # the merge kernel writes the gather payload itself; ONE packed all_gather on a side stream, overlapped with the next step
+            # the merge kernel writes the gather payload itself; it is staged per step and all-gathered per window of steps
             boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True, packed=gatherer.next_buffer())
             gatherer.submit()
         elif images_u8 is not None:
@@ -188,7 +189,7 @@ def main():
         "config": {"workload": f"{args.model} fp16, batch {B} per GPU, {H}x{W} synthetic images, K={ncls}, "
                                f"synthetic weights seed 0, post-process incl. per-class top-{g.post['topk_candidates']} + hard NMS",
                    "global_batch": B * world, "launch": ("eager" if args.eager else "hipGraph replay") + f", {model.batch_split(B)} sub-batch branch(es)",
-                   "parallelism": f"image-sharded x{world}, RCCL all_gather of detections" if distributed else "single GPU",
+                   "parallelism": f"image-sharded x{world}, RCCL all_gather of detections (windows of {gatherer.K} steps)" if distributed else "single GPU",
                    "input": "NCHW fp32 in [0,1], device-resident" if args.input == "f32" else "NHWC uint8 (decoder output), device-resident",
                    "mean_detections": float(counts.float().mean().item())},
     }

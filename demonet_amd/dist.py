@@ -40,67 +40,70 @@ def shard_range(global_batch: int, rank: int, world: int):
 
 
 class DetectionGatherer:
-    """Overlapped gather for a steady stream of batches: one packed [B, D+1, 6] fp32 buffer per step (row D carries the
-    count), ONE all_gather_into_tensor per step on a side stream, double-buffered so the collective of step i runs under
-    the compute of step i+1 (payload is KBs, only latency matters -> hide it)."""
+    """Gather for a steady stream of batches. Every step the forward's packed payload [B, D+1, 6] fp32 (row D carries the
+    count) is copied into a slot of a device ring; every `every` steps ONE all_gather_into_tensor moves the whole window.
 
-    def __init__(self, batch: int, dets: int, device, group=None):
+    Why a window: the reference gathers once, after the evaluation loop (engine.py:105 `synchronize_between_processes`);
+    gathering every step is stricter than needed and costs a fixed ~45 us of collective launch per step on the compute
+    stream (measured at world 1) -- more from a side stream, because a hipGraph launch does not overlap kernels of other
+    streams on this runtime -- and two alternating packed buffers would mean two alternating graph executables (~35 us per
+    launch). One buffer, one graph, a 0.5 MB device copy per step and one collective per window amortise all of that.
+    """
+
+    def __init__(self, batch: int, dets: int, device, group=None, every: int = 8):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.B, self.D = batch, dets
-        self.stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        self.packed = [torch.zeros(batch, dets + 1, 6, dtype=torch.float32, device=device) for _ in range(2)]
-        self.out = [torch.zeros(self.world * batch, dets + 1, 6, dtype=torch.float32, device=device) for _ in range(2)]
-        self.work = [None, None]
-        self.i = 0
+        self.B, self.D, self.K = batch, dets, max(1, int(every))
+        self.packed = torch.zeros(batch, dets + 1, 6, dtype=torch.float32, device=device)     # the forward writes here
+        self.acc = torch.zeros(self.K, batch, dets + 1, 6, dtype=torch.float32, device=device)
+        # gathered windows, two deep: out[w][rank][slot] = payload of step (window w, slot)
+        self.out = [torch.zeros(self.world, self.K, batch, dets + 1, 6, dtype=torch.float32, device=device) for _ in range(2)]
+        self.n = 0                  # steps submitted
+        self.gathered = 0           # steps covered by completed collectives
 
     def next_buffer(self):
-        """The packed buffer the NEXT forward should write into (SSD.forward_batch(packed=...): the merge kernel fills it,
-        no torch-side packing -- a strided torch copy of the boxes alone costs more than the whole forward)."""
-        i = self.i
-        if self.work[i] is not None:
-            self.work[i].wait()                       # the collective that last used this buffer pair
-            self.work[i] = None
-        return self.packed[i]
+        """The packed buffer the forward should write into (SSD.forward_batch(packed=...): the merge kernel fills it, no
+        torch-side packing -- a strided torch copy of the boxes alone costs more than the whole forward)."""
+        return self.packed
+
+    def _gather_window(self):
+        w = (self.gathered // self.K) & 1
+        if self.world == 1 and not dist.is_initialized():
+            self.out[w][0].copy_(self.acc)
+        else:
+            dist.all_gather_into_tensor(self.out[w].view(self.world, -1), self.acc.view(1, -1), group=self.group)
+        self.gathered = (self.gathered // self.K + 1) * self.K
 
     def submit(self, boxes=None, scores=None, labels=None, counts=None):
-        """Call on the compute stream right after the forward; returns immediately. With arguments the payload is packed
-        here (CPU tests / callers without the packed output); without, packed[i] was filled by the forward."""
-        i = self.i
-        self.i ^= 1
-        if self.work[i] is not None:
-            self.work[i].wait()
-            self.work[i] = None
-        p = self.packed[i]
+        """Call on the compute stream right after the forward; returns the step's ticket. With arguments the payload is
+        packed here (CPU tests / callers without the packed output); without, `packed` was filled by the forward."""
+        slot = self.n % self.K
+        p = self.acc[slot]
         D = self.D
         if boxes is not None:
             p[:, :D, :4].copy_(boxes)
             p[:, :D, 4].copy_(scores)
             p[:, :D, 5].copy_(labels)
             p[:, D, 0].copy_(counts)
-        if self.world == 1 and not dist.is_initialized():
-            self.out[i].copy_(p)
-            return i
-        if self.stream is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self.stream):
-                self.stream.wait_event(ev)
-                self.work[i] = dist.all_gather_into_tensor(self.out[i], p, group=self.group, async_op=True)
         else:
-            self.work[i] = dist.all_gather_into_tensor(self.out[i], p, group=self.group, async_op=True)
-        return i
-
-    def result(self, i):
-        """Detections of the global batch of submission i: (packed [W*B, D, 6], counts [W*B] int32)."""
-        if self.work[i] is not None:
-            self.work[i].wait()
-            self.work[i] = None
-        o = self.out[i]
-        return o[:, :self.D, :], o[:, self.D, 0].to(torch.int32)
+            p.copy_(self.packed)            # 0.5 MB device copy on the compute stream; frees `packed` for the next forward
+        ticket = self.n
+        self.n += 1
+        if slot == self.K - 1:
+            self._gather_window()
+        return ticket
 
     def flush(self):
-        for i in (0, 1):
-            if self.work[i] is not None:
-                self.work[i].wait()
-                self.work[i] = None
+        """Gather the last, partial window (collective: every rank calls it after the same number of steps)."""
+        if self.gathered < self.n:
+            self._gather_window()
+
+    def result(self, ticket: int):
+        """Detections of the global batch of step `ticket`, rank-major: (packed [W*B, D, 6], counts [W*B] int32). Available
+        once its window is gathered (every `every` steps or after flush()) and until two windows later."""
+        if ticket >= self.gathered:
+            raise RuntimeError("step %d is not gathered yet: call flush() (collectively) first" % ticket)
+        if ticket < self.gathered - 2 * self.K:
+            raise RuntimeError("step %d was overwritten by later windows" % ticket)
+        o = self.out[(ticket // self.K) & 1][:, ticket % self.K].reshape(self.world * self.B, self.D + 1, 6)
+        return o[:, :self.D, :], o[:, self.D, 0].to(torch.int32)

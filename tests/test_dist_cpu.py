@@ -26,17 +26,20 @@ def _worker(rank, world, port, ret):
         c = int(counts[i])
         assert torch.equal(mine[i]["boxes"], boxes[i, :c]) and torch.equal(mine[i]["labels"], labels[i, :c])
         assert torch.equal(mine[i]["scores"], scores[i, :c])
-    # overlapped, double-buffered gatherer (the form bench.py uses), three consecutive steps
-    G = DetectionGatherer(B, D, "cpu")
-    idx = []
-    for step in range(3):
-        idx.append(G.submit(boxes + step, scores, labels, counts))
-    for step in (1, 2):                       # buffers of step 0 were recycled by step 2
+    # windowed gatherer (the form bench.py uses): five steps with a window of two -> two full windows + a flushed partial one
+    G = DetectionGatherer(B, D, "cpu", every=2)
+    idx = [G.submit(boxes + step, scores, labels, counts) for step in range(5)]
+    try:
+        G.result(idx[4])                      # the last window is not gathered before flush()
+        raise AssertionError("expected RuntimeError")
+    except RuntimeError:
+        pass
+    G.flush()
+    for step in (2, 3, 4):                    # steps 0, 1 were overwritten by the third window
         pk, cn = G.result(idx[step])
         assert pk.shape == (world * B, D, 6) and cn.tolist() == [D, 2, 0, 1, D, 3]
         assert torch.equal(pk[rank * B:(rank + 1) * B, :, :4], boxes + step)
         assert torch.equal(pk[rank * B:(rank + 1) * B, :, 5].to(torch.int64), labels)
-    G.flush()
     ret[rank] = float(gp.sum())
     dist.destroy_process_group()
 
