@@ -7,7 +7,7 @@ A step = one pass of the whole hot path (stem .. heads .. softmax/decode/top-k/N
 batch of synthetic 320x320 images (BASELINE.json configs[1]: ssdlite320_mobilenet_v3_large fp16, batch 64 per GPU).
 Timing window = engine.evaluate's (engine.py:86-94): inputs already on the device, synchronize, forward incl.
 post-process, outputs complete on the stream. N > 1: every rank runs its own 64-image shard (weak scaling); the fixed-shape
-detections of every step are staged on the device and all-gathered over RCCL one window (8 steps) at a time, the last window
+detections of every step are staged on the device and all-gathered over RCCL one window (16 steps) at a time, the last window
 flushed inside the timed region (the reference gathers once, after the loop: engine.py:105).
 Prints ONE JSON line (rank 0).
 """

@@ -50,7 +50,7 @@ class DetectionGatherer:
     launch). One buffer, one graph, a 0.5 MB device copy per step and one collective per window amortise all of that.
     """
 
-    def __init__(self, batch: int, dets: int, device, group=None, every: int = 8):
+    def __init__(self, batch: int, dets: int, device, group=None, every: int = 16):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.B, self.D, self.K = batch, dets, max(1, int(every))
