@@ -613,6 +613,12 @@ int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
 template <int BP, int BC, int WP, int WC, bool CONV>
 int launch_cfg(const PwArgs& a, hipStream_t s) {
     const_cast<PwArgs&>(a).stamps = g_pw_stamps;
+    if constexpr (CONV && BP == 128 && BC == 128) {
+        // MFMA-bound dense convolutions (VGG): 64-deep stages halve the barriers per MFMA; the tile is register-limited to two
+        // workgroups per CU either way, and 2 x 74 KB of LDS fit
+        static const int bk64 = getenv("DN_CONV_BK64") ? atoi(getenv("DN_CONV_BK64")) : 1;
+        if (bk64 && a.cv_cin % 64 == 0) return launch_bk<BP, BC, WP, WC, CONV, 64>(a, s, 2);
+    }
     return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 2);
 }
 
