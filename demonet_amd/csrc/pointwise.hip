@@ -668,7 +668,8 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         if (wgs(128, 64) >= 1500) return launch_cfg<128, 64, 4, 1, CONV>(a, s);
         return launch_cfg<64, 64, 2, 2, CONV>(a, s);
     }
-    if (wgs(128, 128) >= 1500) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
+    static const int t128 = getenv("DN_CONV_T128") ? atoi(getenv("DN_CONV_T128")) : 300;      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
+    if (wgs(128, 128) >= (CONV ? t128 : 1500)) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
     if (wgs(128, 64) >= 1500 || a.cout % 128 > 64 || a.cout % 128 == 0) {
         if (wgs(64, 128) >= 600) return launch_cfg<64, 128, 2, 2, CONV>(a, s);
     }
