@@ -532,10 +532,19 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 ++seg;
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             }
+            // box and class heads of all levels in ONE launch when they fit (a dependent launch costs ~4.5 us even when empty, and
+            // the narrow box heads then share the class heads' tile instead of running as a launch of their own)
+            static const bool merge_heads = getenv("DN_HEAD_MERGE") ? atoi(getenv("DN_HEAD_MERGE")) != 0 : true;
+            const bool one = merge_heads && !p->head_reg.empty() && !p->head_cls.empty() && p->head_reg.size() + p->head_cls.size() <= 12 &&
+                             p->ops[p->head_reg[0]].type == p->ops[p->head_cls[0]].type;
             for (int kind = 0; kind < 2; ++kind) {
-                const std::vector<int>& lst = kind ? p->head_cls : p->head_reg;
+                std::vector<int> lst = kind ? p->head_cls : p->head_reg;
+                if (one) {
+                    if (kind == 1) break;
+                    lst.insert(lst.end(), p->head_cls.begin(), p->head_cls.end());
+                }
                 if (lst.empty()) continue;
-                PwArgs arr[8];
+                PwArgs arr[12];
                 const bool conv = p->ops[lst[0]].type == DN_OP_CONV;
                 for (size_t q = 0; q < lst.size(); ++q)
                     arr[q] = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);

@@ -374,21 +374,21 @@ __global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
     pw_body<BP, BC, WP, WC, CONV, BK, PF>(a, blockIdx.x, blockIdx.y);
 }
 
-// Grouped launch: up to 8 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
+// Grouped launch: up to 12 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
 // The fixed cost of a launch chain (~9 us per dependent launch at any batch size) dominates the small levels; here
 // their workgroups simply ride along with level 0's. blockIdx.x is flat; start[] are prefix sums of workgroup counts.
 struct PwGroup {
     int count;
-    int start[9];
-    int gx[8];
-    PwArgs a[8];
+    int start[13];
+    int gx[12];
+    PwArgs a[12];
 };
 
 template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(256) void pw_group_kernel(PwGroup g) {
     int p = 0;
 #pragma unroll
-    for (int i = 1; i < 8; ++i)
+    for (int i = 1; i < 12; ++i)
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
     const int local = blockIdx.x - g.start[p];
     const int gx = g.gx[p];
@@ -713,7 +713,7 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
 
 // All problems must be of the same kind (pointwise or implicit-GEMM conv); the tile is chosen for the widest one.
 int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t s) {
-    DN_REQUIRE(count >= 1 && count <= 8, "pointwise group: %d problems", count);
+    DN_REQUIRE(count >= 1 && count <= 12, "pointwise group: %d problems", count);
     int maxc = 0;
     long wg128 = 0;
     for (int i = 0; i < count; ++i) {
