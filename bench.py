@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
     ap.add_argument("--input", choices=["f32", "u8"], default="f32",
                     help="f32: NCHW float images in [0,1] (the headline window, engine.py:86); u8: the decoder's [N,H,W,3] uint8 output")
+    ap.add_argument("--weights", choices=["calibrated", "worstcase"], default="calibrated",
+                    help="worstcase: class-head weights shrunk so every score passes score_thresh (all K-1 x topk candidates reach NMS; SURVEY 8d)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the per-step latency percentiles / D2H-inclusive step time (extra passes after the timed region)")
     ap.add_argument("--per-op", default="", help="write a per-op table (time, GB/s, TFLOP/s) to this file")
     args = ap.parse_args()
 
@@ -134,7 +137,15 @@ def main():
     from demonet_amd import models, synth
     from demonet_amd.dist import DetectionGatherer
     ncls = 21 if args.model == "ssd_lite_mobilenet_v2" else 91
-    model = models.load_synthetic(getattr(models, args.model)(num_classes=ncls), 0).to(dev)
+    model = models.load_synthetic(getattr(models, args.model)(num_classes=ncls), 0)
+    if args.weights == "worstcase":
+        sd = {k: torch.from_numpy(v.copy()) for k, v in synth.state_dict(model.graph, 0).items()}
+        for k in sd:
+            last = (sd[k].dim() == 4 and sd[k].shape[1] > 1) or (sd[k].dim() == 1 and sd[k].shape[0] % ncls == 0 and k.endswith("bias"))
+            if "classification_head" in k and last:
+                sd[k] = sd[k] * 0.01          # near-uniform softmax: 1/K > score_thresh for every (anchor, class)
+        model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
     g = model.graph
     W, H = g.size
     B = args.batch
@@ -193,6 +204,33 @@ def main():
                    "input": "NCHW fp32 in [0,1], device-resident" if args.input == "f32" else "NHWC uint8 (decoder output), device-resident",
                    "mean_detections": float(counts.float().mean().item())},
     }
+    if args.weights != "calibrated":
+        result["config"]["workload"] += f", {args.weights} class-head weights"
+
+    if rank == 0 and not args.no_latency and not distributed:
+        # per-step distribution (one forward in flight at a time) and the window of engine.py:86-94 with the
+        # detections copied to the host inside it. Extra passes after the timed region; `value` is unaffected.
+        lat = []
+        for _ in range(max(args.steps, 50)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            e1.synchronize()
+            lat.append(e0.elapsed_time(e1))
+        lat.sort()
+        pick = lambda q: round(lat[min(len(lat) - 1, int(q * len(lat)))], 4)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            if images_u8 is not None:
+                out = model.forward_uint8(images_u8)
+            else:
+                out = model.forward_batch(images, persistent_input=True)
+            host = [t.cpu() for t in out]
+        d2h_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        result["latency"] = {"p10_ms": pick(0.10), "median_ms": pick(0.50), "p90_ms": pick(0.90), "samples": len(lat),
+                             "ms_per_step_with_d2h": round(d2h_ms, 4),
+                             "d2h_bytes": int(sum(t.numel() * t.element_size() for t in host))}
 
     if rank == 0 and not args.no_roofline:
         # per-kernel device time: HIP events around every launch on the forward stream (eager pass, same inputs)
