@@ -349,3 +349,44 @@ def test_packed_gather_payload_matches_outputs():
     assert torch.equal(packed[:, :D, 5].to(torch.int64), l) and torch.equal(packed[:, D, 0].to(torch.int32), c)
     b2 = m.forward_batch(imgs, persistent_input=True)[0]            # and it can be switched off again
     assert torch.equal(b2, b)
+
+
+@pytest.mark.parametrize("ncls,post", [
+    (2, {}),                                                                                   # one foreground class: N = 12 / 6 head channels
+    (21, dict(score_thresh=0.2, nms_thresh=0.3, detections_per_img=10, topk_candidates=50)),   # kwargs override the defaults (ssd_mobilenetv3.py:217)
+    (81, dict(detections_per_img=400, topk_candidates=400)),                                   # more detections than the default buffers
+])
+def test_num_classes_and_postprocess_kwargs(ncls, post):
+    """Factory kwargs of the reference (num_classes, score_thresh, nms_thresh, detections_per_img, topk_candidates): the head
+    logits follow the fp32 CPU path within the logit tolerance, and the detections equal the oracle's post-process applied to
+    the device's own head outputs (labels exact, scores / boxes to float tolerance)."""
+    name = "ssdlite320_mobilenet_v3_large"
+    m = getattr(models, name)(num_classes=ncls, **post)
+    g = m.graph
+    for k, v in post.items():
+        assert g.post[k] == v
+    sd = synth.state_dict(g, 0)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.cuda()
+    imgs = torch.stack(_images(g, [501, 502, 503]))
+    o = so.OracleSSD(name, sd, ncls, **post)
+    raw = o.forward_raw([i.cpu() for i in imgs])
+    logits, reg = m.forward_heads(imgs)
+    logits, reg = logits.cpu(), reg.cpu()
+    assert logits.shape == raw["cls_logits"].shape and reg.shape == raw["bbox_regression"].shape
+    tol = LOGIT_ATOL + LOGIT_RTOL * raw["cls_logits"].abs()
+    assert bool(((logits - raw["cls_logits"]).abs() <= tol).all())
+    boxes, scores, labels, counts = [t.cpu().numpy() for t in m.forward_batch(imgs)]
+    p = g.post
+    ref = so.postprocess_detections(logits, reg, raw["anchors"], (g.size[1], g.size[0]), p["score_thresh"], p["nms_thresh"], p["detections_per_img"],
+                                    p["topk_candidates"], return_intermediates=True)
+    assert boxes.shape[1] == p["detections_per_img"]
+    for i, d in enumerate(ref):
+        cnt = int(counts[i])
+        assert cnt == d["labels"].shape[0] <= p["detections_per_img"]
+        mg = so.selection_margins(d["softmax"], d["decoded"], p["score_thresh"], p["nms_thresh"], p["topk_candidates"], p["detections_per_img"])
+        risky = min(mg["thresh_gap"], mg["iou_gap"]) < 1e-5 or any(0 < mg[k] < 1e-5 for k in ("topk_gap", "final_gap", "order_gap"))
+        if not risky:
+            assert np.array_equal(labels[i, :cnt], d["labels"])
+            np.testing.assert_allclose(boxes[i, :cnt], d["boxes"], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(np.sort(scores[i, :cnt])[::-1], np.sort(d["scores"])[::-1], rtol=1e-5, atol=1e-7)
