@@ -677,7 +677,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
 }
 
 namespace {
-template <int BP, int BC, int WP, int WC, bool CONV>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
 int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     // head 1x1 convs have long K (21 stages at level 0): loads run 3 stages ahead (the dense-conv heads of the VGG models are
     // MFMA-bound at 184 VGPRs and keep the plain double buffer)
@@ -693,7 +693,7 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
         acc += g.gx[i] * dn_cdiv(arr[i].cout, BC);
     }
     g.start[count] = acc;
-    size_t halfs = (size_t)2 * (BP + BC) * 40;
+    size_t halfs = (size_t)2 * (BP + BC) * (BK + 8);
     bool any_fp32 = false;
     for (int i = 0; i < count; ++i) any_fp32 |= arr[i].out_fp32 != 0;
     const size_t otile = any_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);
@@ -701,12 +701,12 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, 32, GPF>),
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    dn_note_kernel(GPF > 1 ? "pw_group_kernel<%d,%d,%d,%d,%s,32,%d>" : "pw_group_kernel<%d,%d,%d,%d,%s,32>", BP, BC, WP, WC, CONV ? "true" : "false", GPF);
-    hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, 32, GPF>), dim3(acc), dim3(256), lds, s, g);
+    dn_note_kernel(GPF > 1 ? "pw_group_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_group_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK, GPF);
+    hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>), dim3(acc), dim3(256), lds, s, g);
     return DN_OK;
 }
 }  // namespace
@@ -729,6 +729,13 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     if (!conv && maxc > 64 && gt == 7) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
+    if (wg128 >= 1500 && conv) {
+        // MFMA-bound dense-conv heads: 64-deep stages as in launch_cfg (half the barriers per MFMA)
+        static const int bk64 = getenv("DN_CONV_GROUP_BK64") ? atoi(getenv("DN_CONV_GROUP_BK64")) : 1;
+        bool all64 = bk64 != 0;
+        for (int i = 0; i < count; ++i) all64 &= arr[i].cv_cin % 64 == 0;
+        if (all64) return launch_group_cfg<128, 128, 2, 2, true, 64>(arr, count, s);
+    }
     if (wg128 >= 1500) return conv ? launch_group_cfg<128, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
     return conv ? launch_group_cfg<64, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
 }
