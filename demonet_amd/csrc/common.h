@@ -60,6 +60,7 @@ static inline int dn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 struct PwArgs {
     // implicit-GEMM geometry (dense kxk conv); pointwise uses k=1: x rows are then simply [m][cin]
     int cv_k = 1, cv_stride = 1, cv_pad = 0, cv_dil = 1, cv_h = 0, cv_w = 0, cv_ho = 0, cv_wo = 0, cv_cin = 0;
+    const half_t* zeros = nullptr;   // optional: >= 16 zero bytes on the device (dense convs)
     const half_t* wfrag = nullptr;   // optional: the weights in MFMA-fragment order (dn_op_desc::w2_off), used by the strip kernel
     const half_t* x;        // [m][cin]
     const half_t* w;        // [cout][cin]
@@ -74,6 +75,9 @@ struct PwArgs {
 };
 int launch_pointwise(const PwArgs& a, hipStream_t s);
 int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t s);
+// 256x256-tile implicit GEMM for the MFMA-bound dense convs (convbig.hip)
+bool conv_big_supported(const PwArgs& a);
+int launch_conv_big(const PwArgs& a, hipStream_t s);
 
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;
@@ -99,6 +103,7 @@ int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b
 
 struct ConvArgs {
     const half_t* x; const half_t* w; const float* bias; void* out;
+    const half_t* zeros = nullptr;      // >= 16 zero bytes on the device (optional; enables convbig.hip)
     int n, h, w_, cin, cout, k, stride, pad, dil, act, ho, wo, out_fp32;
     long out_img_stride, out_base;
 };

@@ -58,6 +58,7 @@ struct dn_plan {
     std::vector<int> level_off;         // anchor offset per level
     std::vector<int> pool_blocks;       // per DN_T_POOL tensor: partial-sum rows per image (= dw workgroups per image)
     unsigned char* weights_dev = nullptr;
+    size_t zeros_off = 0;
     size_t weight_bytes = 0;
     float* anchors_dev = nullptr;
     std::map<int, Layout> layouts;
@@ -325,7 +326,10 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         dn_set_error("dn_create: anchors per level sum to %d, desc says %d", acc, desc->num_anchors);
         return fail(DN_E_INVALID);
     }
-    hipError_t e = hipMalloc((void**)&p->weights_dev, weight_bytes);
+    // the arena ends with 256 zero bytes: the source of out-of-image taps in convbig.hip
+    p->zeros_off = (weight_bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc((void**)&p->weights_dev, p->zeros_off + 256);
+    if (e == hipSuccess) e = hipMemset(p->weights_dev + p->zeros_off, 0, 256);
     if (e == hipSuccess) e = hipMemcpy(p->weights_dev, weights, weight_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&p->anchors_dev, (size_t)desc->num_anchors * 16);
     if (e == hipSuccess) e = hipMemcpy(p->anchors_dev, desc->anchors, (size_t)desc->num_anchors * 16, hipMemcpyHostToDevice);
@@ -482,6 +486,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.x = reinterpret_cast<const half_t*>(tptr(o.in));
         a.w = reinterpret_cast<const half_t*>(Wb + o.w_off);
         a.bias = reinterpret_cast<const float*>(Wb + o.b_off);
+        a.zeros = reinterpret_cast<const half_t*>(Wb + p->zeros_off);
         a.n = n; a.h = ti.h; a.w_ = ti.w; a.cin = o.cin; a.cout = o.cout; a.k = o.k; a.stride = o.stride;
         a.pad = o.pad; a.dil = o.dil; a.act = o.act; a.ho = to.h; a.wo = to.w;
         if (o.head) {

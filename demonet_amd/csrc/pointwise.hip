@@ -668,6 +668,11 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         if (wgs(128, 64) >= 1500) return launch_cfg<128, 64, 4, 1, CONV>(a, s);
         return launch_cfg<64, 64, 2, 2, CONV>(a, s);
     }
+    if constexpr (CONV) {
+        static const int big = getenv("DN_CONV_BIG") ? atoi(getenv("DN_CONV_BIG")) : 1;
+        static const int bigmin = getenv("DN_CONV_BIG_MIN") ? atoi(getenv("DN_CONV_BIG_MIN")) : 200;
+        if (big && conv_big_supported(a) && wgs(256, 256) >= bigmin) return launch_conv_big(a, s);
+    }
     static const int t128 = getenv("DN_CONV_T128") ? atoi(getenv("DN_CONV_T128")) : 300;      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
     if (wgs(128, 128) >= (CONV ? t128 : 1500)) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
     if (wgs(128, 64) >= 1500 || a.cout % 128 > 64 || a.cout % 128 == 0) {
@@ -759,7 +764,7 @@ PwArgs conv_to_pw(const ConvArgs& c) {
     PwArgs a;
     a.cv_k = c.k; a.cv_stride = c.stride; a.cv_pad = c.pad; a.cv_dil = c.dil; a.cv_h = c.h; a.cv_w = c.w_;
     a.cv_ho = c.ho; a.cv_wo = c.wo; a.cv_cin = c.cin;
-    a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out;
+    a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out; a.zeros = c.zeros;
     a.hw = c.ho * c.wo;
     a.m = c.n * a.hw;
     a.cin = c.k * c.k * c.cin;
@@ -773,7 +778,7 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     PwArgs a;
     a.cv_k = c.k; a.cv_stride = c.stride; a.cv_pad = c.pad; a.cv_dil = c.dil; a.cv_h = c.h; a.cv_w = c.w_;
     a.cv_ho = c.ho; a.cv_wo = c.wo; a.cv_cin = c.cin;
-    a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out;
+    a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out; a.zeros = c.zeros;
     a.hw = c.ho * c.wo;
     a.m = c.n * a.hw;
     a.cin = c.k * c.k * c.cin;
