@@ -57,6 +57,7 @@ _SIGNATURES = {
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "dn_depthwise_conv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dn_dense_conv": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 10 + [C.c_void_p]),
     "dn_expand_depthwise": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 11 + [C.c_void_p]),
     "dn_expand_depthwise_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dn_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),

@@ -924,6 +924,24 @@ extern "C" int dn_expand_depthwise(const void* x, const void* w1, const float* b
 
 extern "C" int dn_expand_depthwise_tiles(int ho, int wo, int stride) { return expdw_tiles_per_image(ho, wo, stride); }
 
+extern "C" int dn_dense_conv(const void* x, const void* w, const float* bias, const void* zeros, void* out, int n, int h, int wd,
+                             int cin, int cout, int k, int stride, int pad, int dil, int act, void* stream) {
+    DN_REQUIRE(x && w && bias && out, "dn_dense_conv: null argument");
+    DN_REQUIRE(n > 0 && h > 0 && wd > 0 && k >= 1 && stride >= 1 && dil >= 1 && pad >= 0, "dn_dense_conv: bad geometry");
+    ConvArgs a;
+    a.x = reinterpret_cast<const half_t*>(x); a.w = reinterpret_cast<const half_t*>(w); a.bias = bias; a.out = out;
+    a.zeros = reinterpret_cast<const half_t*>(zeros);
+    a.n = n; a.h = h; a.w_ = wd; a.cin = cin; a.cout = cout; a.k = k; a.stride = stride; a.pad = pad; a.dil = dil; a.act = act;
+    a.ho = (h + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+    a.wo = (wd + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+    DN_REQUIRE(a.ho > 0 && a.wo > 0, "dn_dense_conv: empty output");
+    a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
+    int rc = launch_conv(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    DN_HIP_CHECK(hipGetLastError());
+    return DN_OK;
+}
+
 extern "C" int dn_depthwise_conv(const void* x, const void* w, const float* bias, void* out, int n, int h, int wd, int c, int k,
                                  int stride, int pad, int act, void* stream) {
     DN_REQUIRE(x && w && bias && out, "dn_depthwise_conv: null argument");

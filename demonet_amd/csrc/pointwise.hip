@@ -670,7 +670,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
     }
     if constexpr (CONV) {
         static const int big = getenv("DN_CONV_BIG") ? atoi(getenv("DN_CONV_BIG")) : 1;
-        static const int bigmin = getenv("DN_CONV_BIG_MIN") ? atoi(getenv("DN_CONV_BIG_MIN")) : 200;
+        static const int bigmin = getenv("DN_CONV_BIG_MIN") ? atoi(getenv("DN_CONV_BIG_MIN")) : 40;       // measured on both VGG models: 40 < 90 < 200; the sub-batch chains fill the chip together
         if (big && conv_big_supported(a) && wgs(256, 256) >= bigmin) return launch_conv_big(a, s);
     }
     static const int t128 = getenv("DN_CONV_T128") ? atoi(getenv("DN_CONV_T128")) : 300;      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)

@@ -129,6 +129,12 @@ DN_API int dn_postprocess(const float* cls_logits_dev, const float* bbox_regress
 DN_API int dn_pointwise_conv(const void* x_dev, const void* w_dev, const void* w_frag_dev, const float* bias_dev,
                       const void* residual_dev, const float* se_scale_dev, void* out_dev, int m, int cin, int cout, int hw,
                       int act, int out_fp32, int64_t out_img_stride, void* stream);
+/* Dense kxk convolution + bias + activation (the VGG path: vgg16 "D" convs, fc6 dilated 3x3, fc7 1x1, extras, ssd_vgg16.py:30-109).
+ * x: [n][h][w][cin] fp16, w: [cout][k][k][cin] fp16, bias fp32 [cout], out [n][ho][wo][cout] fp16; cin % 32 == 0, cout % 4 == 0.
+ * zeros (optional): >= 16 zero bytes on the device; with it, layers with cin % 64 == 0 and cout % 256 == 0 run on the
+ * 256x256-tile kernel (taps outside the image are read from there). */
+DN_API int dn_dense_conv(const void* x_dev, const void* w_dev, const float* bias_dev, const void* zeros_dev, void* out_dev,
+                  int n, int h, int w, int cin, int cout, int k, int stride, int pad, int dil, int act, void* stream);
 /* x: [n][h][w][c] fp16, w: [k*k][c] fp16, bias fp32 [c], out [n][ho][wo][c] fp16 */
 DN_API int dn_depthwise_conv(const void* x_dev, const void* w_dev, const float* bias_dev, void* out_dev,
                       int n, int h, int w, int c, int k, int stride, int pad, int act, void* stream);

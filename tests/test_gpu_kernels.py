@@ -125,6 +125,41 @@ def test_depthwise_conv(n, h, w, c, k, s, act):
     torch.testing.assert_close(got, ref.half().float(), rtol=4e-3, atol=4e-3)
 
 
+DENSE_CASES = [
+    # n, h, w, cin, cout, k, s, pad, dil, act, zeros
+    (2, 19, 19, 64, 256, 3, 1, 1, 1, 1, True),       # 256x256-tile kernel: M = 722 (3 tiles, ragged last), borders on every side
+    (1, 38, 38, 128, 512, 3, 1, 1, 1, 1, True),      # two channel tiles, 18 K stages
+    (3, 19, 19, 128, 256, 3, 1, 6, 6, 1, True),      # fc6-like: dilation 6, padding 6 (ssd_vgg16.py:86)
+    (2, 19, 19, 256, 512, 3, 2, 1, 1, 1, True),      # extras-like: stride 2 (ssd_vgg16.py:60-72)
+    (2, 10, 10, 256, 256, 1, 1, 0, 1, 1, True),      # fc7-like 1x1 through the conv entry
+    (2, 5, 5, 128, 256, 3, 1, 0, 1, 1, True),        # valid 3x3 (extras tail): 5x5 -> 3x3
+    (2, 19, 19, 64, 256, 3, 1, 1, 1, 1, False),      # same problem without the zero block -> the 128x128 / 64x64 tiles
+    (2, 21, 17, 32, 96, 3, 1, 1, 1, 0, True),        # cin % 64 != 0, cout not a multiple of 256 -> general path, no activation
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,s,pad,dil,act,zeros", DENSE_CASES)
+def test_dense_conv(n, h, w, cin, cout, k, s, pad, dil, act, zeros):
+    """Dense kxk convolution (VGG path) against fp32 F.conv2d on the fp16-rounded operands; result rounded to fp16 once."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(h * 17 + cin + cout + k)
+    x = torch.randn(n, cin, h, w, generator=g).half()
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (k * cin ** 0.5)).half()
+    b = torch.randn(cout, generator=g)
+    ref = _act(F.conv2d(x.float(), wt.float(), b, s, pad, dil), act)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = wt.permute(0, 2, 3, 1).contiguous().cuda()                 # [cout][ky][kx][cin]
+    z = torch.zeros(64, dtype=torch.uint8, device="cuda") if zeros else None
+    ho, wo = ref.shape[-2:]
+    out = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.half, device="cuda")
+    rc = lib.dn_dense_conv(_ptr(xd), _ptr(wd), _ptr(b.cuda()), _ptr(z) if zeros else None, _ptr(out), n, h, w, cin, cout, k, s, pad, dil, act,
+                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    L.check(rc, "dn_dense_conv")
+    torch.cuda.synchronize()
+    got = out.cpu().float().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref.half().float(), rtol=4e-3, atol=4e-3)
+
+
 def test_bad_arguments_report_errors():
     L, lib = _lib()
     x = torch.zeros(8, 12, dtype=torch.half, device="cuda")
