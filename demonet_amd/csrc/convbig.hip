@@ -19,12 +19,50 @@
 // re-read every input row from L2, which a spatially tiled input patch in LDS would remove (next step).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
 constexpr int BP = 256, BC = 256;
 constexpr int OROW = BC + 8;
+
+// bias + activation, tile -> LDS [BP][BC+8] halfs (over the stage buffers; the caller has passed a barrier), then 16-B
+// row-contiguous stores
+__device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[4][4], const PwArgs& a, half_t* lds, const float* bsh, int m0, int n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int M = a.m, NC = a.cout;
+    half_t* ot = lds;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int prow = (wp * 4 + j) * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = (wc * 4 + i) * 32 + 8 * g + 4 * hh;
+                const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
+                half4 hv;
+                hv[0] = (half_t)dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
+                hv[1] = (half_t)dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
+                hv[2] = (half_t)dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
+                hv[3] = (half_t)dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                *reinterpret_cast<half4*>(&ot[prow * OROW + cl]) = hv;
+            }
+        }
+    }
+    __syncthreads();
+    half_t* outp = reinterpret_cast<half_t*>(a.out);
+#pragma unroll 4
+    for (int c = tid; c < BP * (BC / 8); c += 256) {
+        const int row = c >> 5, ch = c & 31;
+        const int m = m0 + row;
+        if (m < M) *reinterpret_cast<uint4*>(outp + (size_t)m * NC + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&ot[row * OROW + ch * 8]);
+    }
+}
 
 // An LDS-DMA wave-instruction writes 1 KB linearly (lane l -> base + 16 l): the stage image is rows of 128 B without padding, 8 rows
 // per instruction, and the bank-conflict swizzle goes on the SOURCE: position p of row r holds K-chunk p ^ ((r >> 1) & 7); the
@@ -198,34 +236,210 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
 
-    // epilogue: bias + activation, tile -> LDS [BP][BC+8] halfs (over the stage buffers), then 16-B row-contiguous stores
-    half_t* ot = lds;
+    conv_epilogue(acc, a, lds, bsh, m0, n0);
+}
+
+
+// ---- 3x3-style convs with stride 1 and "same" padding: the pixel tile of all k*k taps from ONE staged run of input rows ---------
+// The 256 output pixels of a tile are consecutive in the flattened (image, y, x) order, and with stride 1 / pad = dil (k-1)/2 tap
+// (ky, kx) of output pixel p reads input pixel p + (ky dil - pad) W + (kx dil - pad): the k*k pixel tiles are the same run of
+// 256 + 2 (pad W + pad) input rows read at k*k row shifts. conv_glds_kernel fetches every shifted copy from L2 (9 x 32 KB of pixels
+// beside 9 x 32 KB of weights per 64 channels); here the run is staged once per 32-channel slice (26 KB at W = 75) and the taps
+// shift the fragment reads instead -- 40 % less L2 -> LDS traffic, which is what bounds that kernel. Rows that a tap must not see
+// (image borders: the neighbour in the flattened order is another row's or image's pixel) are zeroed in the pixel fragment
+// registers (lane = pixel) by a per-pixel tap mask.
+//   K order: 32-channel slice outer, tap inner; a stage = two consecutive (slice, tap) half-stages = 64 deep. 9 stages = 18
+//   half-stages = two slices = 64 input channels form the loop body, unrolled so that every buffer index, tap shift and DMA
+//   piece is static. Pixel runs are double-buffered per slice parity, the weight stages double-buffered per stage.
+constexpr int HK = 32;                      // K per half-stage
+constexpr int A_ROWS = 512;                 // rows of a staged run (256 + halo on both sides), upper bound
+constexpr int A_BUF = A_ROWS * HK;          // halfs (32 KB)
+constexpr int B_HALF = BC * HK;             // halfs (16 KB)
+constexpr int B_STAGE = 2 * B_HALF;
+
+template <int KSZ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_halo_kernel(PwArgs a) {
+    constexpr int NT = KSZ * KSZ;           // taps; the unrolled body below is written for NT == 9
+    static_assert(NT == 9, "3x3 only");
+    extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];
+    float* bsh = reinterpret_cast<float*>(lds_raw);
+    half_t* lds = lds_raw + 2 * BC;
+    half_t* Abuf = lds;                     // [2][A_BUF]
+    half_t* Bbuf = lds + 2 * A_BUF;         // [2][B_STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * BP, n0 = blockIdx.y * BC;
+    const int M = a.m, K = a.cin, NC = a.cout, CIN = a.cv_cin;
+    const int W = a.cv_w, pad = a.cv_pad, dil = a.cv_dil;
+    const int HALO = pad * W + pad;
+    const int NPIECE = (BP + 2 * HALO + 15) >> 4;       // 16-row DMA pieces of a run (<= 32)
+    const int NIT = CIN / 64;
+
+    floatx16 acc[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int prow = (wp * 4 + j) * 32 + r;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = (wc * 4 + i) * 32 + 8 * g + 4 * hh;
-                const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
-                half4 hv;
-                hv[0] = (half_t)dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
-                hv[1] = (half_t)dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
-                hv[2] = (half_t)dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
-                hv[3] = (half_t)dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
-                *reinterpret_cast<half4*>(&ot[prow * OROW + cl]) = hv;
-            }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- loader geometry: a DMA piece = 16 rows of 64 B; lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 2) & 3)
+    const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const char* xbase = reinterpret_cast<const char*>(a.x);
+    int axoff[8], apiece[8];               // this wave's pieces of a run: piece index (uniform) and per-lane source offset
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pc = min(wave + 4 * i, NPIECE - 1);            // beyond the run: the last piece again (same bytes, same place)
+        const int q = pc * 16 + lrow;
+        const int pix = min(max(m0 - HALO + q, 0), M - 1);      // rows outside the tensor are masked below: any valid address
+        apiece[i] = pc;
+        axoff[i] = (pix * CIN + lchunk * 8) * 2;
+    }
+    const char* wbase = reinterpret_cast<const char*>(a.w) + ((size_t)(n0 + wave * 64) * K) * 2;
+    const unsigned wlo = (unsigned)((lrow * K + lchunk * 8) * 2);
+
+    auto issue_a = [&](int ab, int slice, int i) {               // piece i of this wave, 32-channel slice `slice` -> run buffer ab
+        const char* p = xbase + (long)(axoff[i] + slice * 64);
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Abuf + ab * A_BUF + apiece[i] * 16 * HK), 16, 0, 0);
+    };
+    auto issue_b = [&](int bb, int hf, int slice, int tap, int j) {      // 16 weight rows j of this wave's 64, half-stage (slice, tap)
+        const char* p = wbase + (size_t)(j * 16) * K * 2 + (wlo + (unsigned)((tap * CIN + slice * 32) * 2));
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Bbuf + bb * B_STAGE + hf * B_HALF + (wave * 64 + j * 16) * HK), 16, 0, 0);
+    };
+
+    bsh[tid] = a.bias[n0 + tid];
+
+    // ---- fragment geometry
+    unsigned vm[4];                         // tap-validity mask of this lane's 4 pixels (pixel tiles jt = 0..3)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const int m = m0 + (wp * 4 + jt) * 32 + r;
+        unsigned mk = 0;
+        if (m < M) {
+            const int rem = m % a.hw;
+            const int oy = rem / W, ox = rem - oy * W;
+            for (int ky = 0; ky < KSZ; ++ky)
+                for (int kx = 0; kx < KSZ; ++kx) {
+                    const int iy = oy + ky * dil - pad, ix = ox + kx * dil - pad;
+                    if (iy >= 0 && iy < a.cv_h && ix >= 0 && ix < W) mk |= 1u << (ky * KSZ + kx);
+                }
         }
+        vm[jt] = mk;
+    }
+    const int kbw0 = ((wc * 4) * 32 + r) * HK + ((hh ^ ((r >> 2) & 3)) * 8);             // weight fragment, K step 0 / 1 of a half-stage
+    const int kbw1 = ((wc * 4) * 32 + r) * HK + (((2 + hh) ^ ((r >> 2) & 3)) * 8);
+    half8 xf0[4], wf0[4], xf1[4], wf1[4];
+    // fragments of half-stage (run buffer ab, tap, weight buffer bb / half hf), K step ks
+    auto read_frags = [&](half8 (&xf)[4], half8 (&wf)[4], int ab, int tap, int bb, int hf, int ks) {
+        const int ky = tap / KSZ, kx = tap - ky * KSZ;
+        const int rs = r + HALO + (ky * dil - pad) * W + (kx * dil - pad);             // run row of pixel tile 0, wave row 0
+        const int sw = (rs >> 2) & 3;
+        const half_t* xa = Abuf + ab * A_BUF + (wp * 128 + rs) * HK + (((2 * ks + hh) ^ sw) * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const half8*>(xa + j * 32 * HK);
+        const half_t* wb = Bbuf + bb * B_STAGE + hf * B_HALF + (ks ? kbw1 : kbw0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + i * 32 * HK);
+    };
+    auto mask_frags = [&](half8 (&xf)[4], int tap) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned mk = 0u - ((vm[j] >> tap) & 1u);
+            uint4 v = *reinterpret_cast<uint4*>(&xf[j]);
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            xf[j] = *reinterpret_cast<half8*>(&v);
+        }
+    };
+    auto mfma16 = [&](const half8 (&xf)[4], const half8 (&wf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    };
+
+#define CH_PHASE(nvm)                                                  \
+    do {                                                               \
+        for (int u_ = 0; u_ < 8; ++u_) {                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
+        }                                                              \
+        for (int u_ = 0; u_ < 8; ++u_) {                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
+            if (u_ < (nvm)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        }                                                              \
+        __builtin_amdgcn_sched_barrier(0);                             \
+    } while (0)
+
+    // ---- prologue: run of slice 0, weights of stage 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_a(0, 0, i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { issue_b(0, 0, 0, 0, j); issue_b(0, 1, 0, 1, j); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_frags(xf0, wf0, 0, 0, 0, 0, 0);
+    mask_frags(xf0, 0);
+
+    // One loop iteration = slices 2 it (run buffer 0) and 2 it + 1 (run buffer 1) = 18 half-stages h = 0..17 = 9 stages.
+    // Stage s: half-stages h0 = 2 s, h1 = 2 s + 1; phases P0 (h0, K step 0) P1 (h0, 1) P2 (h1, 0) P3 (h1, 1); every phase reads
+    // the fragments of the next one. The DMA of the next stage's weights goes out in P0..P2, two pieces of a pixel run per stage
+    // (stages 0-3: slice 2 it + 1 -> buffer 1; stages 5-8: slice 2 it + 2 -> buffer 0), the stage's barrier sits before P3's MFMAs.
+    for (int it = 0; it < NIT; ++it) {
+        const int sA = 2 * it, sB = 2 * it + 1;
+        const int sNext = min(sA + 2, 2 * NIT - 2);         // last iteration: reload its own even slice into the dead buffer
+        const int itn = min(it + 1, NIT - 1);
+        auto stage = [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            constexpr int H0 = 2 * S, H1 = 2 * S + 1;
+            constexpr int T0 = H0 % NT, T1 = H1 % NT, AB0 = H0 / NT, AB1 = H1 / NT;
+            constexpr int SN = (S + 1) % 9;                                  // next stage
+            constexpr int NH0 = 2 * SN, NH1 = 2 * SN + 1;
+            constexpr int NT0 = NH0 % NT, NT1 = NH1 % NT, NAB0 = NH0 / NT, NAB1 = NH1 / NT;
+            const int bb = (it + S) & 1, nb = bb ^ 1;                        // weight buffer of this / the next stage (9 stages per iteration)
+            const int itx = (S == 8) ? itn : it;                             // iteration of the next stage (the very last stage reloads its own)
+            const int nsl0 = 2 * itx + NAB0, nsl1 = 2 * itx + NAB1;
+            // P0
+            read_frags(xf1, wf1, AB0, T0, bb, 0, 1);
+            issue_b(nb, 0, nsl0, NT0, 0); issue_b(nb, 0, nsl0, NT0, 1); issue_b(nb, 0, nsl0, NT0, 2); issue_b(nb, 0, nsl0, NT0, 3);
+            mfma16(xf0, wf0);
+            mask_frags(xf1, T0);
+            CH_PHASE(4);
+            // P1
+            read_frags(xf0, wf0, AB1, T1, bb, 1, 0);
+            issue_b(nb, 1, nsl1, NT1, 0); issue_b(nb, 1, nsl1, NT1, 1); issue_b(nb, 1, nsl1, NT1, 2); issue_b(nb, 1, nsl1, NT1, 3);
+            mfma16(xf1, wf1);
+            mask_frags(xf0, T1);
+            CH_PHASE(4);
+            // P2
+            read_frags(xf1, wf1, AB1, T1, bb, 1, 1);
+            if constexpr (S <= 3) { issue_a(1, sB, 2 * S); issue_a(1, sB, 2 * S + 1); }
+            if constexpr (S >= 5) { issue_a(0, sNext, 2 * (S - 5)); issue_a(0, sNext, 2 * (S - 5) + 1); }
+            mfma16(xf0, wf0);
+            mask_frags(xf1, T1);
+            CH_PHASE(2);
+            // P3: the barrier, then the next stage's first fragments
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            read_frags(xf0, wf0, NAB0, NT0, nb, 0, 0);
+            mfma16(xf1, wf1);
+            mask_frags(xf0, NT0);
+            CH_PHASE(0);
+        };
+        stage(std::integral_constant<int, 0>{});
+        stage(std::integral_constant<int, 1>{});
+        stage(std::integral_constant<int, 2>{});
+        stage(std::integral_constant<int, 3>{});
+        stage(std::integral_constant<int, 4>{});
+        stage(std::integral_constant<int, 5>{});
+        stage(std::integral_constant<int, 6>{});
+        stage(std::integral_constant<int, 7>{});
+        stage(std::integral_constant<int, 8>{});
     }
     __syncthreads();
-    half_t* outp = reinterpret_cast<half_t*>(a.out);
-#pragma unroll 4
-    for (int c = tid; c < BP * (BC / 8); c += 256) {
-        const int row = c >> 5, ch = c & 31;
-        const int m = m0 + row;
-        if (m < M) *reinterpret_cast<uint4*>(outp + (size_t)m * NC + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&ot[row * OROW + ch * 8]);
-    }
+    conv_epilogue(acc, a, lds, bsh, m0, n0);
 }
 
 }  // namespace
@@ -242,6 +456,21 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
     if (!attr) {
         DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
+    }
+    static const int halo = getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1;
+    const int run_rows = BP + 2 * (a.cv_pad * a.cv_w + a.cv_pad);
+    if (halo && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w && run_rows <= A_ROWS &&
+        (long)a.m * a.cv_cin * 2 < (1L << 31)) {
+        const size_t st2 = (size_t)2 * A_BUF + 2 * B_STAGE;
+        const size_t lds2 = (st2 > otile ? st2 : otile) * sizeof(half_t) + BC * sizeof(float);
+        static bool attr2 = false;
+        if (!attr2) {
+            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        dn_note_kernel("conv_halo_kernel<3>");
+        hipLaunchKernelGGL(conv_halo_kernel<3>, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds2, s, a);
+        return DN_OK;
     }
     dn_note_kernel("conv_glds_kernel");
     hipLaunchKernelGGL(conv_glds_kernel, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds, s, a);
