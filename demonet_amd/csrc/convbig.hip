@@ -14,9 +14,9 @@
 // Staging is LDS-DMA (global_load_lds_dwordx4): a register-staged version of the same loop (global_load -> ds_write_b128, 32-deep
 // stages) spent a quarter of its time in the ds_write_b128 issue (~13 cycles per wave-instruction) and ran level with this one;
 // the DMA form needs no staging registers, which is what makes the 64-deep stage (half the barriers) fit.
-// Measured ablations of the loop (conv3_2 of ssd300_vgg16, TFLOP/s): as is 830; without the staging traffic 1330 -- the
-// 256x256x64 stage moves 64 KB from L2 for 8.4 MFLOP (128 FLOP/B), so at 830 TFLOP/s the CUs pull 6.5 TB/s out of L2; the 9 taps
-// re-read every input row from L2, which a spatially tiled input patch in LDS would remove (next step).
+// Measured ablations of conv_glds_kernel's loop (conv3_2 of ssd300_vgg16, TFLOP/s): as is 830; without the staging traffic 1330 --
+// the 256x256x64 stage moves 64 KB from L2 for 8.4 MFLOP (128 FLOP/B), so at 830 TFLOP/s the CUs pull 6.5 TB/s out of L2, and the 9
+// taps re-read every input row. conv_halo_kernel (below) stages each input row once per channel slice instead: 940 TFLOP/s.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -30,37 +30,39 @@ constexpr int OROW = BC + 8;
 
 // bias + activation, tile -> LDS [BP][BC+8] halfs (over the stage buffers; the caller has passed a barrier), then 16-B
 // row-contiguous stores
-__device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[4][4], const PwArgs& a, half_t* lds, const float* bsh, int m0, int n0) {
+template <int TP, int TC>
+__device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[TC][TP], const PwArgs& a, half_t* lds, const float* bsh, int m0, int n0) {
+    constexpr int BPt = 64 * TP, BCt = 64 * TC, ORW = BCt + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wc = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
     const int M = a.m, NC = a.cout;
     half_t* ot = lds;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int prow = (wp * 4 + j) * 32 + r;
+    for (int j = 0; j < TP; ++j) {
+        const int prow = (wp * TP + j) * 32 + r;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TC; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cl = (wc * 4 + i) * 32 + 8 * g + 4 * hh;
+                const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
                 const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                 half4 hv;
                 hv[0] = (half_t)dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
                 hv[1] = (half_t)dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
                 hv[2] = (half_t)dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
                 hv[3] = (half_t)dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
-                *reinterpret_cast<half4*>(&ot[prow * OROW + cl]) = hv;
+                *reinterpret_cast<half4*>(&ot[prow * ORW + cl]) = hv;
             }
         }
     }
     __syncthreads();
     half_t* outp = reinterpret_cast<half_t*>(a.out);
 #pragma unroll 4
-    for (int c = tid; c < BP * (BC / 8); c += 256) {
-        const int row = c >> 5, ch = c & 31;
+    for (int c = tid; c < BPt * (BCt / 8); c += 256) {
+        const int row = c / (BCt / 8), ch = c % (BCt / 8);
         const int m = m0 + row;
-        if (m < M) *reinterpret_cast<uint4*>(outp + (size_t)m * NC + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&ot[row * OROW + ch * 8]);
+        if (m < M) *reinterpret_cast<uint4*>(outp + (size_t)m * NC + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&ot[row * ORW + ch * 8]);
     }
 }
 
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
 
-    conv_epilogue(acc, a, lds, bsh, m0, n0);
+    conv_epilogue<4, 4>(acc, a, lds, bsh, m0, n0);
 }
 
 
@@ -251,71 +253,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   K order: 32-channel slice outer, tap inner; a stage = two consecutive (slice, tap) half-stages = 64 deep. 9 stages = 18
 //   half-stages = two slices = 64 input channels form the loop body, unrolled so that every buffer index, tap shift and DMA
 //   piece is static. Pixel runs are double-buffered per slice parity, the weight stages double-buffered per stage.
+// The weights are then most of the traffic, and their bytes per flop fall with the PIXEL tile only: a wave tile of TP pixel tiles x
+// TC channel tiles (workgroup 64 TP pixels x 64 TC channels) is instantiated as 4 x 4 (256 x 256) and 8 x 2 (512 x 128).
 constexpr int HK = 32;                      // K per half-stage
-constexpr int A_ROWS = 512;                 // rows of a staged run (256 + halo on both sides), upper bound
-constexpr int A_BUF = A_ROWS * HK;          // halfs (32 KB)
-constexpr int B_HALF = BC * HK;             // halfs (16 KB)
-constexpr int B_STAGE = 2 * B_HALF;
+constexpr int halo_run_rows(int tp) { return tp == 4 ? 544 : 832; }      // 256 + 288 (W <= 143 at pad 1), 512 + 320 (W <= 159)
 
-template <int KSZ>
+template <int KSZ, int TP, int TC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_halo_kernel(PwArgs a) {
     constexpr int NT = KSZ * KSZ;           // taps; the unrolled body below is written for NT == 9
     static_assert(NT == 9, "3x3 only");
+    constexpr int BPt = 64 * TP, BCt = 64 * TC;
+    constexpr int A_ROWS = halo_run_rows(TP);       // rows of a staged run (pixel tile + halo on both sides), upper bound
+    constexpr int A_BUF = A_ROWS * HK;      // halfs
+    constexpr int B_HALF = BCt * HK;
+    constexpr int B_STAGE = 2 * B_HALF;
+    constexpr int APW = (A_ROWS / 16 + 3) / 4;      // DMA pieces of a run per wave, APS per stage over a 4-stage window
+    constexpr int APS = (APW + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];
     float* bsh = reinterpret_cast<float*>(lds_raw);
-    half_t* lds = lds_raw + 2 * BC;
+    half_t* lds = lds_raw + 2 * BCt;
     half_t* Abuf = lds;                     // [2][A_BUF]
     half_t* Bbuf = lds + 2 * A_BUF;         // [2][B_STAGE]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wc = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * BP, n0 = blockIdx.y * BC;
+    const int m0 = blockIdx.x * BPt, n0 = blockIdx.y * BCt;
     const int M = a.m, K = a.cin, NC = a.cout, CIN = a.cv_cin;
     const int W = a.cv_w, pad = a.cv_pad, dil = a.cv_dil;
     const int HALO = pad * W + pad;
-    const int NPIECE = (BP + 2 * HALO + 15) >> 4;       // 16-row DMA pieces of a run (<= 32)
+    const int NPIECE = (BPt + 2 * HALO + 15) >> 4;      // 16-row DMA pieces of a run (<= 4 APW)
     const int NIT = CIN / 64;
 
-    floatx16 acc[4][4];
+    floatx16 acc[TC][TP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TP; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // ---- loader geometry: a DMA piece = 16 rows of 64 B; lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 2) & 3)
     const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
     const char* xbase = reinterpret_cast<const char*>(a.x);
-    int axoff[8], apiece[8];               // this wave's pieces of a run: piece index (uniform) and per-lane source offset
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int pc = min(wave + 4 * i, NPIECE - 1);            // beyond the run: the last piece again (same bytes, same place)
-        const int q = pc * 16 + lrow;
-        const int pix = min(max(m0 - HALO + q, 0), M - 1);      // rows outside the tensor are masked below: any valid address
-        apiece[i] = pc;
-        axoff[i] = (pix * CIN + lchunk * 8) * 2;
-    }
-    const char* wbase = reinterpret_cast<const char*>(a.w) + ((size_t)(n0 + wave * 64) * K) * 2;
+    const int arow0 = m0 - HALO + lrow;      // input pixel of run row lrow
+    const char* wbase = reinterpret_cast<const char*>(a.w) + ((size_t)(n0 + wave * (BCt / 4)) * K) * 2;
     const unsigned wlo = (unsigned)((lrow * K + lchunk * 8) * 2);
 
     auto issue_a = [&](int ab, int slice, int i) {               // piece i of this wave, 32-channel slice `slice` -> run buffer ab
-        const char* p = xbase + (long)(axoff[i] + slice * 64);
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Abuf + ab * A_BUF + apiece[i] * 16 * HK), 16, 0, 0);
+        const int pc = min(wave + 4 * i, NPIECE - 1);            // beyond the run: the last piece again (same bytes, same place)
+        const int pix = min(max(arow0 + pc * 16, 0), M - 1);    // rows outside the tensor are masked in the fragments: any valid address
+        const char* p = xbase + (long)((pix * CIN + lchunk * 8) * 2 + slice * 64);
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Abuf + ab * A_BUF + pc * 16 * HK), 16, 0, 0);
     };
-    auto issue_b = [&](int bb, int hf, int slice, int tap, int j) {      // 16 weight rows j of this wave's 64, half-stage (slice, tap)
+    auto issue_b = [&](int bb, int hf, int slice, int tap, int j) {      // 16 weight rows j of this wave's BCt / 4, half-stage (slice, tap)
         const char* p = wbase + (size_t)(j * 16) * K * 2 + (wlo + (unsigned)((tap * CIN + slice * 32) * 2));
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Bbuf + bb * B_STAGE + hf * B_HALF + (wave * 64 + j * 16) * HK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Bbuf + bb * B_STAGE + hf * B_HALF + (wave * (BCt / 4) + j * 16) * HK), 16, 0, 0);
     };
 
-    bsh[tid] = a.bias[n0 + tid];
+    if (tid < BCt) bsh[tid] = a.bias[n0 + tid];
 
     // ---- fragment geometry
-    unsigned vm[4];                         // tap-validity mask of this lane's 4 pixels (pixel tiles jt = 0..3)
+    unsigned vm[TP];                        // tap-validity mask of this lane's TP pixels (pixel tiles jt)
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-        const int m = m0 + (wp * 4 + jt) * 32 + r;
+    for (int jt = 0; jt < TP; ++jt) {
+        const int m = m0 + (wp * TP + jt) * 32 + r;
         unsigned mk = 0;
         if (m < M) {
             const int rem = m % a.hw;
@@ -328,56 +330,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         vm[jt] = mk;
     }
-    const int kbw0 = ((wc * 4) * 32 + r) * HK + ((hh ^ ((r >> 2) & 3)) * 8);             // weight fragment, K step 0 / 1 of a half-stage
-    const int kbw1 = ((wc * 4) * 32 + r) * HK + (((2 + hh) ^ ((r >> 2) & 3)) * 8);
-    half8 xf0[4], wf0[4], xf1[4], wf1[4];
+    const int kbw0 = ((wc * TC) * 32 + r) * HK + ((hh ^ ((r >> 2) & 3)) * 8);             // weight fragment, K step 0 / 1 of a half-stage
+    const int kbw1 = ((wc * TC) * 32 + r) * HK + (((2 + hh) ^ ((r >> 2) & 3)) * 8);
+    half8 xf0[TP], wf0[TC], xf1[TP], wf1[TC];
     // fragments of half-stage (run buffer ab, tap, weight buffer bb / half hf), K step ks
-    auto read_frags = [&](half8 (&xf)[4], half8 (&wf)[4], int ab, int tap, int bb, int hf, int ks) {
+    auto read_frags = [&](half8 (&xf)[TP], half8 (&wf)[TC], int ab, int tap, int bb, int hf, int ks) {
         const int ky = tap / KSZ, kx = tap - ky * KSZ;
         const int rs = r + HALO + (ky * dil - pad) * W + (kx * dil - pad);             // run row of pixel tile 0, wave row 0
         const int sw = (rs >> 2) & 3;
-        const half_t* xa = Abuf + ab * A_BUF + (wp * 128 + rs) * HK + (((2 * ks + hh) ^ sw) * 8);
+        const half_t* xa = Abuf + ab * A_BUF + (wp * (BPt / 2) + rs) * HK + (((2 * ks + hh) ^ sw) * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const half8*>(xa + j * 32 * HK);
+        for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const half8*>(xa + j * 32 * HK);
         const half_t* wb = Bbuf + bb * B_STAGE + hf * B_HALF + (ks ? kbw1 : kbw0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + i * 32 * HK);
+        for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + i * 32 * HK);
     };
-    auto mask_frags = [&](half8 (&xf)[4], int tap) {
+    auto mask_frags = [&](half8 (&xf)[TP], int tap) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TP; ++j) {
             const unsigned mk = 0u - ((vm[j] >> tap) & 1u);
             uint4 v = *reinterpret_cast<uint4*>(&xf[j]);
             v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
             xf[j] = *reinterpret_cast<half8*>(&v);
         }
     };
-    auto mfma16 = [&](const half8 (&xf)[4], const half8 (&wf)[4]) {
+    auto mfma16 = [&](const half8 (&xf)[TP], const half8 (&wf)[TC]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     };
 
 #define CH_PHASE(nvm)                                                  \
     do {                                                               \
-        for (int u_ = 0; u_ < 8; ++u_) {                               \
+        for (int u_ = 0; u_ < 16; ++u_) {                              \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
-        }                                                              \
-        for (int u_ = 0; u_ < 8; ++u_) {                               \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         \
-            if (u_ < (nvm)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+            if (u_ < TP + TC) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+            else {                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x002, (4 * TP + 15 - TP - TC) / (16 - TP - TC), 0); \
+                if (u_ - TP - TC < (nvm)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+            }                                                          \
         }                                                              \
         __builtin_amdgcn_sched_barrier(0);                             \
     } while (0)
 
     // ---- prologue: run of slice 0, weights of stage 0
 #pragma unroll
-    for (int i = 0; i < 8; ++i) issue_a(0, 0, i);
+    for (int i = 0; i < APW; ++i) issue_a(0, 0, i);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { issue_b(0, 0, 0, 0, j); issue_b(0, 1, 0, 1, j); }
+    for (int j = 0; j < TC; ++j) { issue_b(0, 0, 0, 0, j); issue_b(0, 1, 0, 1, j); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     read_frags(xf0, wf0, 0, 0, 0, 0, 0);
@@ -403,23 +404,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int nsl0 = 2 * itx + NAB0, nsl1 = 2 * itx + NAB1;
             // P0
             read_frags(xf1, wf1, AB0, T0, bb, 0, 1);
-            issue_b(nb, 0, nsl0, NT0, 0); issue_b(nb, 0, nsl0, NT0, 1); issue_b(nb, 0, nsl0, NT0, 2); issue_b(nb, 0, nsl0, NT0, 3);
+#pragma unroll
+            for (int j = 0; j < TC; ++j) issue_b(nb, 0, nsl0, NT0, j);
             mfma16(xf0, wf0);
             mask_frags(xf1, T0);
-            CH_PHASE(4);
+            CH_PHASE(TC);
             // P1
             read_frags(xf0, wf0, AB1, T1, bb, 1, 0);
-            issue_b(nb, 1, nsl1, NT1, 0); issue_b(nb, 1, nsl1, NT1, 1); issue_b(nb, 1, nsl1, NT1, 2); issue_b(nb, 1, nsl1, NT1, 3);
+#pragma unroll
+            for (int j = 0; j < TC; ++j) issue_b(nb, 1, nsl1, NT1, j);
             mfma16(xf1, wf1);
             mask_frags(xf0, T1);
-            CH_PHASE(4);
+            CH_PHASE(TC);
             // P2
             read_frags(xf1, wf1, AB1, T1, bb, 1, 1);
-            if constexpr (S <= 3) { issue_a(1, sB, 2 * S); issue_a(1, sB, 2 * S + 1); }
-            if constexpr (S >= 5) { issue_a(0, sNext, 2 * (S - 5)); issue_a(0, sNext, 2 * (S - 5) + 1); }
+            if constexpr (S <= 3) {
+#pragma unroll
+                for (int u = 0; u < APS; ++u)
+                    if (APS * S + u < APW) issue_a(1, sB, APS * S + u);
+            }
+            if constexpr (S >= 5) {
+#pragma unroll
+                for (int u = 0; u < APS; ++u)
+                    if (APS * (S - 5) + u < APW) issue_a(0, sNext, APS * (S - 5) + u);
+            }
             mfma16(xf0, wf0);
             mask_frags(xf1, T1);
-            CH_PHASE(2);
+            CH_PHASE(APS);
             // P3: the barrier, then the next stage's first fragments
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -439,14 +450,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stage(std::integral_constant<int, 8>{});
     }
     __syncthreads();
-    conv_epilogue(acc, a, lds, bsh, m0, n0);
+    conv_epilogue<TP, TC>(acc, a, lds, bsh, m0, n0);
 }
 
 }  // namespace
 
 bool conv_big_supported(const PwArgs& a) {
-    return a.zeros && a.cv_cin % GK == 0 && a.cout % BC == 0 && !a.out_fp32 && !a.residual && !a.se && a.cv_k * a.cv_k <= 32 &&
-           a.cin >= 2 * GK && (long)a.m / a.hw * a.cv_h * a.cv_w * a.cv_cin * 2 < (1L << 31) && (long)a.cout * a.cin * 2 < (1L << 32);
+    if (!(a.zeros && a.cv_cin % GK == 0 && !a.out_fp32 && !a.residual && !a.se && a.cv_k * a.cv_k <= 32 && a.cin >= 2 * GK &&
+          (long)a.m / a.hw * a.cv_h * a.cv_w * a.cv_cin * 2 < (1L << 31) && (long)a.cout * a.cin * 2 < (1L << 32)))
+        return false;
+    if (a.cout % BC == 0) return true;
+    // 128-channel layers: only on the 512 x 128 run kernel
+    return a.cout % 128 == 0 && a.cv_cin >= 128 && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w &&
+           512 + 2 * (a.cv_pad * a.cv_w + a.cv_pad) <= halo_run_rows(8) && (getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1) != 0;
 }
 
 int launch_conv_big(const PwArgs& a, hipStream_t s) {
@@ -458,20 +474,34 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
         attr = true;
     }
     static const int halo = getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1;
-    const int run_rows = BP + 2 * (a.cv_pad * a.cv_w + a.cv_pad);
-    if (halo && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w && run_rows <= A_ROWS &&
-        (long)a.m * a.cv_cin * 2 < (1L << 31)) {
-        const size_t st2 = (size_t)2 * A_BUF + 2 * B_STAGE;
-        const size_t lds2 = (st2 > otile ? st2 : otile) * sizeof(half_t) + BC * sizeof(float);
+    const int halo_rows = 2 * (a.cv_pad * a.cv_w + a.cv_pad);
+    const bool halo_ok = halo && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w &&
+                         (long)a.m * a.cv_cin * 2 < (1L << 31);
+    if (halo_ok && a.cout % 256 == 0 && halo != 2 && 256 + halo_rows <= halo_run_rows(4)) {
+        const size_t st2 = (size_t)2 * halo_run_rows(4) * HK + 2 * 2 * 256 * HK;
+        const size_t lds2 = (st2 > otile ? st2 : otile) * sizeof(half_t) + 256 * sizeof(float);
         static bool attr2 = false;
         if (!attr2) {
-            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2 = true;
         }
-        dn_note_kernel("conv_halo_kernel<3>");
-        hipLaunchKernelGGL(conv_halo_kernel<3>, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds2, s, a);
+        dn_note_kernel("conv_halo_kernel<3,4,4>");
+        hipLaunchKernelGGL((conv_halo_kernel<3, 4, 4>), dim3(dn_cdiv(a.m, 256), a.cout / 256), dim3(256), lds2, s, a);
         return DN_OK;
     }
+    if (halo_ok && a.cv_cin >= 128 && 512 + halo_rows <= halo_run_rows(8)) {        // 512 pixels x 128 channels: the 128-channel layers
+        const size_t st2 = (size_t)2 * halo_run_rows(8) * HK + 2 * 2 * 128 * HK, ot2 = (size_t)512 * 136;
+        const size_t lds2 = (st2 > ot2 ? st2 : ot2) * sizeof(half_t) + 128 * sizeof(float);
+        static bool attr3 = false;
+        if (!attr3) {
+            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr3 = true;
+        }
+        dn_note_kernel("conv_halo_kernel<3,8,2>");
+        hipLaunchKernelGGL((conv_halo_kernel<3, 8, 2>), dim3(dn_cdiv(a.m, 512), a.cout / 128), dim3(256), lds2, s, a);
+        return DN_OK;
+    }
+    DN_REQUIRE(a.cout % BC == 0, "conv: cout=%d not a multiple of 256 on the 256x256 tile", a.cout);
     dn_note_kernel("conv_glds_kernel");
     hipLaunchKernelGGL(conv_glds_kernel, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds, s, a);
     return DN_OK;
