@@ -287,7 +287,7 @@ def main():
                     if len(members[c["owner"]]) > 1:      # member of a grouped launch: timed as a whole below
                         f.write(f"{i:3d} {nm:58s} {shp:34s}  (slot {c['owner']:3d}) {c['bytes'] / 1e6:8.1f} MB {'':26s}  {c['kernel']}\n")
                         continue
-                    ms = buf[i]
+                    ms = buf[c["owner"]]          # a launch's time sits in its segment slot, which need not be the op's own index
                     f.write(f"{i:3d} {nm:58s} {shp:34s} {ms * 1e3:8.1f} us {c['bytes'] / 1e6:8.1f} MB {c['bytes'] / max(ms, 1e-9) / 1e6:8.0f} GB/s {c['flops'] / max(ms, 1e-9) / 1e9:7.1f} TF/s  {c['kernel']}\n")
                 for slot, mem in sorted(members.items()):
                     if len(mem) < 2:

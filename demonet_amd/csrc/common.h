@@ -61,6 +61,9 @@ struct PwArgs {
     // implicit-GEMM geometry (dense kxk conv); pointwise uses k=1: x rows are then simply [m][cin]
     int cv_k = 1, cv_stride = 1, cv_pad = 0, cv_dil = 1, cv_h = 0, cv_w = 0, cv_ho = 0, cv_wo = 0, cv_cin = 0;
     const half_t* zeros = nullptr;   // optional: >= 16 zero bytes on the device (dense convs)
+    // optional second head on the same input (convbig.hip, head kernel): output channels [cout, cout + cout2) use these
+    const half_t* w_b = nullptr; const float* bias_b = nullptr; void* out_b = nullptr;
+    int cout_b = 0; long out_b_img_stride = 0, out_b_base = 0;
     const half_t* wfrag = nullptr;   // optional: the weights in MFMA-fragment order (dn_op_desc::w2_off), used by the strip kernel
     const half_t* x;        // [m][cin]
     const half_t* w;        // [cout][cin]
@@ -78,6 +81,8 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
 // 256x256-tile implicit GEMM for the MFMA-bound dense convs (convbig.hip)
 bool conv_big_supported(const PwArgs& a);
 int launch_conv_big(const PwArgs& a, hipStream_t s);
+bool conv_head_big_supported(const PwArgs& a);
+int launch_conv_head_big(const PwArgs& a, hipStream_t s);
 
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;

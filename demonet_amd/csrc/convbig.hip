@@ -66,6 +66,69 @@ __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[TC][TP], const PwA
     }
 }
 
+// Head outputs (generalized_ssd.py:60-74): fp32 rows of the [anchor][class] / [anchor][4] arrays, addressed
+// out_base + image * out_img_stride + (pixel in image) * cout + channel. The accumulator layout has every lane on a different row:
+// the tile goes through LDS in two halves of BPt / 2 pixel rows ([rows][BCt + 4] floats) and leaves as row-contiguous float2 runs.
+template <int TP, int TC>
+__device__ __forceinline__ void conv_epilogue_fp32(floatx16 (&acc)[TC][TP], const PwArgs& a, half_t* lds, const float* bsh, int m0, int n0) {
+    constexpr int BPt = 64 * TP, BCt = 64 * TC, FROW = BCt + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int M = a.m, NC1 = a.cout, NCT = a.cout + a.cout_b;
+    float* ot = reinterpret_cast<float*>(lds);
+    auto pair_aligned = [](const void* p, int nc, long base, long stride) {
+        return ((nc | (int)(base & 1) | (int)(stride & 1)) & 1) == 0 && (reinterpret_cast<size_t>(p) & 7) == 0;
+    };
+    const bool pair1 = pair_aligned(a.out, a.cout, a.out_base, a.out_img_stride);
+    const bool pair2 = a.cout_b > 0 && pair_aligned(a.out_b, a.cout_b, a.out_b_base, a.out_b_img_stride);
+    for (int half = 0; half < 2; ++half) {
+        if (wp == half) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int prow = j * 32 + r;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                        const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
+                        float4 v;
+                        v.x = dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
+                        v.y = dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
+                        v.z = dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
+                        v.w = dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                        *reinterpret_cast<float4*>(&ot[prow * FROW + cl]) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int PPR = BCt / 2;
+#pragma unroll 4
+        for (int c = tid; c < (BPt / 2) * PPR; c += 256) {
+            const int row = c / PPR, cp = (c - row * PPR) * 2;
+            const int m = m0 + half * (BPt / 2) + row, n = n0 + cp;
+            if (m >= M || n >= NCT) continue;
+            const int img = m / a.hw;
+            const float2 v = *reinterpret_cast<const float2*>(&ot[row * FROW + cp]);
+            // columns [0, cout) belong to the first head, [cout, cout + cout_b) to the second (cout is even: a pair never straddles)
+            const bool second = n >= NC1;
+            const int nc = second ? a.cout_b : NC1, nn = second ? n - NC1 : n;
+            float* o = (second ? reinterpret_cast<float*>(a.out_b) + (size_t)a.out_b_base + (size_t)img * a.out_b_img_stride
+                               : reinterpret_cast<float*>(a.out) + (size_t)a.out_base + (size_t)img * a.out_img_stride) +
+                       (size_t)(m - img * a.hw) * nc + nn;
+            if ((second ? pair2 : pair1) && nn + 1 < nc) {
+                *reinterpret_cast<float2*>(o) = v;
+            } else {
+                o[0] = v.x;
+                if (nn + 1 < nc) o[1] = v.y;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // An LDS-DMA wave-instruction writes 1 KB linearly (lane l -> base + 16 l): the stage image is rows of 128 B without padding, 8 rows
 // per instruction, and the bank-conflict swizzle goes on the SOURCE: position p of row r holds K-chunk p ^ ((r >> 1) & 7); the
 // fragment reads apply the same XOR (conflict-free for the 16-lane groups of ds_read_b128).
@@ -258,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 constexpr int HK = 32;                      // K per half-stage
 constexpr int halo_run_rows(int tp) { return tp == 4 ? 544 : 832; }      // 256 + 288 (W <= 143 at pad 1), 512 + 320 (W <= 159)
 
-template <int KSZ, int TP, int TC>
+template <int KSZ, int TP, int TC, bool HEAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_halo_kernel(PwArgs a) {
     constexpr int NT = KSZ * KSZ;           // taps; the unrolled body below is written for NT == 9
     static_assert(NT == 9, "3x3 only");
@@ -279,7 +342,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wp = wave >> 1, wc = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * BPt, n0 = blockIdx.y * BCt;
-    const int M = a.m, K = a.cin, NC = a.cout, CIN = a.cv_cin;
+    const int M = a.m, K = a.cin, CIN = a.cv_cin;
+    const int NC = HEAD ? a.cout + a.cout_b : a.cout;       // head kernel: the channels of a second head on the same input follow
     const int W = a.cv_w, pad = a.cv_pad, dil = a.cv_dil;
     const int HALO = pad * W + pad;
     const int NPIECE = (BPt + 2 * HALO + 15) >> 4;      // 16-row DMA pieces of a run (<= 4 APW)
@@ -297,8 +361,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
     const char* xbase = reinterpret_cast<const char*>(a.x);
     const int arow0 = m0 - HALO + lrow;      // input pixel of run row lrow
-    const char* wbase = reinterpret_cast<const char*>(a.w) + ((size_t)(n0 + wave * (BCt / 4)) * K) * 2;
-    const unsigned wlo = (unsigned)((lrow * K + lchunk * 8) * 2);
+    // weight rows beyond the last channel (last channel tile of a head): the last row again, its outputs are never stored
+    const char* wbase = reinterpret_cast<const char*>(a.w);
+    const long wdelta = HEAD && a.w_b ? reinterpret_cast<const char*>(a.w_b) - wbase : 0;
+    long wro[TC];
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+        const int row = min(n0 + wave * (BCt / 4) + j * 16 + lrow, NC - 1);
+        wro[j] = (row < a.cout ? (long)row * K : wdelta / 2 + (long)(row - a.cout) * K) * 2 + lchunk * 16;
+    }
 
     auto issue_a = [&](int ab, int slice, int i) {               // piece i of this wave, 32-channel slice `slice` -> run buffer ab
         const int pc = min(wave + 4 * i, NPIECE - 1);            // beyond the run: the last piece again (same bytes, same place)
@@ -307,11 +378,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Abuf + ab * A_BUF + pc * 16 * HK), 16, 0, 0);
     };
     auto issue_b = [&](int bb, int hf, int slice, int tap, int j) {      // 16 weight rows j of this wave's BCt / 4, half-stage (slice, tap)
-        const char* p = wbase + (size_t)(j * 16) * K * 2 + (wlo + (unsigned)((tap * CIN + slice * 32) * 2));
+        const char* p = wbase + (wro[j] + (long)((tap * CIN + slice * 32) * 2));
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Bbuf + bb * B_STAGE + hf * B_HALF + (wave * (BCt / 4) + j * 16) * HK), 16, 0, 0);
     };
 
-    if (tid < BCt) bsh[tid] = a.bias[n0 + tid];
+    if (tid < BCt) {
+        const int n = n0 + tid;
+        bsh[tid] = n < a.cout ? a.bias[n] : (HEAD && n < NC) ? a.bias_b[n - a.cout] : 0.f;
+    }
 
     // ---- fragment geometry
     unsigned vm[TP];                        // tap-validity mask of this lane's TP pixels (pixel tiles jt)
@@ -450,7 +524,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stage(std::integral_constant<int, 8>{});
     }
     __syncthreads();
-    conv_epilogue<TP, TC>(acc, a, lds, bsh, m0, n0);
+    if constexpr (HEAD) conv_epilogue_fp32<TP, TC>(acc, a, lds, bsh, m0, n0);
+    else conv_epilogue<TP, TC>(acc, a, lds, bsh, m0, n0);
 }
 
 }  // namespace
@@ -482,11 +557,11 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
         const size_t lds2 = (st2 > otile ? st2 : otile) * sizeof(half_t) + 256 * sizeof(float);
         static bool attr2 = false;
         if (!attr2) {
-            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 4, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr2 = true;
         }
         dn_note_kernel("conv_halo_kernel<3,4,4>");
-        hipLaunchKernelGGL((conv_halo_kernel<3, 4, 4>), dim3(dn_cdiv(a.m, 256), a.cout / 256), dim3(256), lds2, s, a);
+        hipLaunchKernelGGL((conv_halo_kernel<3, 4, 4, false>), dim3(dn_cdiv(a.m, 256), a.cout / 256), dim3(256), lds2, s, a);
         return DN_OK;
     }
     if (halo_ok && a.cv_cin >= 128 && 512 + halo_rows <= halo_run_rows(8)) {        // 512 pixels x 128 channels: the 128-channel layers
@@ -494,15 +569,41 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
         const size_t lds2 = (st2 > ot2 ? st2 : ot2) * sizeof(half_t) + 128 * sizeof(float);
         static bool attr3 = false;
         if (!attr3) {
-            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 8, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr3 = true;
         }
         dn_note_kernel("conv_halo_kernel<3,8,2>");
-        hipLaunchKernelGGL((conv_halo_kernel<3, 8, 2>), dim3(dn_cdiv(a.m, 512), a.cout / 128), dim3(256), lds2, s, a);
+        hipLaunchKernelGGL((conv_halo_kernel<3, 8, 2, false>), dim3(dn_cdiv(a.m, 512), a.cout / 128), dim3(256), lds2, s, a);
         return DN_OK;
     }
     DN_REQUIRE(a.cout % BC == 0, "conv: cout=%d not a multiple of 256 on the 256x256 tile", a.cout);
     dn_note_kernel("conv_glds_kernel");
     hipLaunchKernelGGL(conv_glds_kernel, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds, s, a);
+    return DN_OK;
+}
+
+// Dense 3x3 heads with fp32 outputs (SSDHead, generalized_ssd.py:77-92) on the run-staged 256x256 tile; channel tiles beyond cout
+// compute on the last weight row and are not stored.
+bool conv_head_big_supported(const PwArgs& a) {
+    static const int on = getenv("DN_CONV_HEAD_BIG") ? atoi(getenv("DN_CONV_HEAD_BIG")) : 1;
+    static const int minwg = getenv("DN_CONV_HEAD_BIG_MIN") ? atoi(getenv("DN_CONV_HEAD_BIG_MIN")) : 40;
+    if (!on || !a.out_fp32 || a.residual || a.se || a.cv_cin % 64 || a.cv_k != 3 || a.cv_stride != 1 || a.cv_pad != a.cv_dil) return false;
+    if (a.cv_ho != a.cv_h || a.cv_wo != a.cv_w || 256 + 2 * (a.cv_pad * a.cv_w + a.cv_pad) > halo_run_rows(4)) return false;
+    if ((long)a.m * a.cv_cin * 2 >= (1L << 31) || (long)a.cout * a.cin * 2 >= (1L << 32)) return false;
+    if (a.cout & 1) return false;
+    const int tiles = dn_cdiv(a.cout, 256);
+    return a.cout * 10 >= tiles * 256 * 6 && (long)dn_cdiv(a.m, 256) * tiles >= minwg;      // at most 40 % of the channel tiles idle
+}
+
+int launch_conv_head_big(const PwArgs& a, hipStream_t s) {
+    const size_t st2 = (size_t)2 * halo_run_rows(4) * HK + 2 * 2 * 256 * HK, ot2 = (size_t)2 * 128 * 260;
+    const size_t lds2 = (st2 > ot2 ? st2 : ot2) * sizeof(half_t) + 256 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    dn_note_kernel("conv_halo_kernel<3,4,4,head>");
+    hipLaunchKernelGGL((conv_halo_kernel<3, 4, 4, true>), dim3(dn_cdiv(a.m, 256), dn_cdiv(a.cout + a.cout_b, 256)), dim3(256), lds2, s, a);
     return DN_OK;
 }

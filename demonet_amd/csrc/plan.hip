@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -551,13 +552,63 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 if (lst.empty()) continue;
                 PwArgs arr[12];
                 const bool conv = p->ops[lst[0]].type == DN_OP_CONV;
-                for (size_t q = 0; q < lst.size(); ++q)
-                    arr[q] = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
-                rc = launch_pointwise_group(arr, (int)lst.size(), conv, s);
-                if (rc != DN_OK) return rc;
-                for (int q : lst) note(q, seg);
-                ++seg;
-                if (record && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], s);
+                int cnt = 0;
+                std::vector<int> grouped;
+                std::set<int> taken;
+                // wide heads first, so that a box head that rides along is known before the groups are formed
+                std::stable_sort(lst.begin(), lst.end(), [&](int x, int y) { return p->ops[x].cout > p->ops[y].cout; });
+                for (size_t q = 0; q < lst.size(); ++q) {
+                    PwArgs pa = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
+                    if (conv && taken.count(lst[q])) continue;          // rides in another head's launch
+                    if (conv && conv_head_big_supported(pa)) {
+                        // the wide dense heads of the large levels: MFMA-bound, each on the run-staged 256x256 tile. The box head of the
+                        // same level (same input, 16 / 24 channels) fits in the idle part of its last channel tile.
+                        int rider = -1;
+                        for (size_t u = 0; u < lst.size() && rider < 0; ++u) {
+                            const dn_op_desc &ou = p->ops[lst[u]], &oq = p->ops[lst[q]];
+                            if (u != q && !taken.count(lst[u]) && ou.in == oq.in && ou.type == oq.type && ou.k == oq.k && ou.stride == oq.stride &&
+                                ou.pad == oq.pad && ou.dil == oq.dil && ou.act == oq.act && ou.cout < oq.cout &&
+                                dn_cdiv(oq.cout + ou.cout, 256) == dn_cdiv(oq.cout, 256))
+                                rider = (int)u;
+                        }
+                        if (rider >= 0) {
+                            const PwArgs pb = conv_to_pw(make_conv(p->ops[lst[rider]]));
+                            pa.w_b = pb.w; pa.bias_b = pb.bias; pa.out_b = pb.out; pa.cout_b = pb.cout;
+                            pa.out_b_img_stride = pb.out_img_stride; pa.out_b_base = pb.out_base;
+                            taken.insert(lst[rider]);
+                        }
+                        rc = launch_conv_head_big(pa, s);
+                        if (rc != DN_OK) return rc;
+                        note(lst[q], seg);
+                        if (rider >= 0) note(lst[rider], seg);
+                        ++seg;
+                        if (record && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], s);
+                        continue;
+                    }
+                    arr[cnt++] = pa;
+                    grouped.push_back(lst[q]);
+                }
+                if (cnt == 0) continue;
+                // once the wide heads have left, the narrow box heads (16 / 24 channels) would pay the wide tile of the remaining
+                // class heads: dense-conv groups are split into a narrow and a wide launch
+                const bool split_narrow = conv && cnt < (int)lst.size();
+                for (int pass = 0; pass < (split_narrow ? 2 : 1); ++pass) {
+                    PwArgs sub[12];
+                    std::vector<int> ids;
+                    int nsub = 0;
+                    for (int q = 0; q < cnt; ++q) {
+                        const bool narrow = arr[q].cout <= 32;
+                        if (split_narrow && narrow != (pass == 0)) continue;
+                        sub[nsub++] = arr[q];
+                        ids.push_back(grouped[q]);
+                    }
+                    if (nsub == 0) continue;
+                    rc = launch_pointwise_group(sub, nsub, conv, s);
+                    if (rc != DN_OK) return rc;
+                    for (int q : ids) note(q, seg);
+                    ++seg;
+                    if (record && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], s);
+                }
             }
             for (size_t q = seg + 1; q < p->ops.size(); ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
