@@ -319,14 +319,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // The weights are then most of the traffic, and their bytes per flop fall with the PIXEL tile only: a wave tile of TP pixel tiles x
 // TC channel tiles (workgroup 64 TP pixels x 64 TC channels) is instantiated as 4 x 4 (256 x 256) and 8 x 2 (512 x 128).
 constexpr int HK = 32;                      // K per half-stage
-constexpr int halo_run_rows(int tp) { return tp == 4 ? 544 : 832; }      // 256 + 288 (W <= 143 at pad 1), 512 + 320 (W <= 159)
+// capacity of a staged run in rows (2 runs + 2 x 2 weight half-stages + 1 KB <= 152 KB of LDS). Unused DMA slots still cost an issue
+// each: 512 x 128 keeps the 832 rows its layers need (W <= 159; with 960 it spills and loses 8 %)
+constexpr int halo_run_rows(int tp, int tc) { return tc == 4 ? 704 : tp == 8 ? 832 : 960; }
 
 template <int KSZ, int TP, int TC, bool HEAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_halo_kernel(PwArgs a) {
     constexpr int NT = KSZ * KSZ;           // taps; the unrolled body below is written for NT == 9
     static_assert(NT == 9, "3x3 only");
     constexpr int BPt = 64 * TP, BCt = 64 * TC;
-    constexpr int A_ROWS = halo_run_rows(TP);       // rows of a staged run (pixel tile + halo on both sides), upper bound
+    constexpr int A_ROWS = halo_run_rows(TP, TC);   // rows of a staged run (pixel tile + halo on both sides), upper bound
     constexpr int A_BUF = A_ROWS * HK;      // halfs
     constexpr int B_HALF = BCt * HK;
     constexpr int B_STAGE = 2 * B_HALF;
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     half_t* lds = lds_raw + 2 * BCt;
     half_t* Abuf = lds;                     // [2][A_BUF]
     half_t* Bbuf = lds + 2 * A_BUF;         // [2][B_STAGE]
+    half_t* dummy = Bbuf + 2 * B_STAGE;     // 1 KB nobody reads: destination of the DMA slots a short run does not need
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wc = wave & 1;
@@ -371,11 +374,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         wro[j] = (row < a.cout ? (long)row * K : wdelta / 2 + (long)(row - a.cout) * K) * 2 + lchunk * 16;
     }
 
-    auto issue_a = [&](int ab, int slice, int i) {               // piece i of this wave, 32-channel slice `slice` -> run buffer ab
-        const int pc = min(wave + 4 * i, NPIECE - 1);            // beyond the run: the last piece again (same bytes, same place)
+    const char* zeros = reinterpret_cast<const char*>(a.zeros);
+    auto issue_a = [&](int ab, int slice, int i, bool live) {    // piece i of this wave, 32-channel slice `slice` -> run buffer ab
+        // The DMA schedule is static (APW slots per wave and slice); a slot beyond the run, or a slice that does not exist, moves
+        // 16 cached zero bytes into the dummy block instead of branching around the instruction.
+        const int pc = wave + 4 * i;
+        const bool real = live && pc < NPIECE;                   // wave-uniform
         const int pix = min(max(arow0 + pc * 16, 0), M - 1);    // rows outside the tensor are masked in the fragments: any valid address
-        const char* p = xbase + (long)((pix * CIN + lchunk * 8) * 2 + slice * 64);
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Abuf + ab * A_BUF + pc * 16 * HK), 16, 0, 0);
+        const char* p = real ? xbase + (long)((pix * CIN + lchunk * 8) * 2 + slice * 64) : zeros;
+        half_t* dst = real ? Abuf + ab * A_BUF + pc * 16 * HK : dummy;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)dst, 16, 0, 0);
     };
     auto issue_b = [&](int bb, int hf, int slice, int tap, int j) {      // 16 weight rows j of this wave's BCt / 4, half-stage (slice, tap)
         const char* p = wbase + (wro[j] + (long)((tap * CIN + slice * 32) * 2));
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: run of slice 0, weights of stage 0
 #pragma unroll
-    for (int i = 0; i < APW; ++i) issue_a(0, 0, i);
+    for (int i = 0; i < APW; ++i) issue_a(0, 0, i, true);
 #pragma unroll
     for (int j = 0; j < TC; ++j) { issue_b(0, 0, 0, 0, j); issue_b(0, 1, 0, 1, j); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -464,7 +472,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (stages 0-3: slice 2 it + 1 -> buffer 1; stages 5-8: slice 2 it + 2 -> buffer 0), the stage's barrier sits before P3's MFMAs.
     for (int it = 0; it < NIT; ++it) {
         const int sA = 2 * it, sB = 2 * it + 1;
-        const int sNext = min(sA + 2, 2 * NIT - 2);         // last iteration: reload its own even slice into the dead buffer
         const int itn = min(it + 1, NIT - 1);
         auto stage = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
@@ -495,12 +502,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (S <= 3) {
 #pragma unroll
                 for (int u = 0; u < APS; ++u)
-                    if (APS * S + u < APW) issue_a(1, sB, APS * S + u);
+                    if (APS * S + u < APW) issue_a(1, sB, APS * S + u, true);
             }
             if constexpr (S >= 5) {
 #pragma unroll
                 for (int u = 0; u < APS; ++u)
-                    if (APS * (S - 5) + u < APW) issue_a(0, sNext, APS * (S - 5) + u);
+                    if (APS * (S - 5) + u < APW) issue_a(0, sA + 2, APS * (S - 5) + u, it + 1 < NIT);
             }
             mfma16(xf0, wf0);
             mask_frags(xf1, T1);
@@ -530,17 +537,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
+namespace {
+bool halo_shape(const PwArgs& a) {
+    static const int halo = getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1;
+    return halo && a.zeros && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w &&
+           a.cv_cin % 64 == 0 && (long)a.m * a.cv_cin * 2 < (1L << 31) && (long)(a.cout + a.cout_b) * a.cin * 2 < (1L << 32);
+}
+int halo_rows(const PwArgs& a) { return 2 * (a.cv_pad * a.cv_w + a.cv_pad); }
+
+template <int TP, int TC, bool HEAD>
+int launch_halo(const PwArgs& a, hipStream_t s, const char* name) {
+    constexpr int BPt = 64 * TP, BCt = 64 * TC;
+    const size_t st = (size_t)2 * halo_run_rows(TP, TC) * HK + (size_t)2 * 2 * BCt * HK + 512;      // runs, weight stages, dummy block
+    const size_t ot = HEAD ? (size_t)2 * (BPt / 2) * (BCt + 4) : (size_t)BPt * (BCt + 8);            // epilogue tile, in halfs
+    const size_t lds = (st > ot ? st : ot) * sizeof(half_t) + BCt * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, TP, TC, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+        attr = true;
+    }
+    dn_note_kernel(name);
+    hipLaunchKernelGGL((conv_halo_kernel<3, TP, TC, HEAD>), dim3(dn_cdiv(a.m, BPt), dn_cdiv(a.cout + (HEAD ? a.cout_b : 0), BCt)), dim3(256), lds, s, a);
+    return DN_OK;
+}
+
+// which tile a fp16-output 3x3 stride-1 conv runs on: 0 none, 1 = 256 x 256, 2 = 512 x 128, 3 = 256 x 128
+int halo_variant(const PwArgs& a) {
+    if (a.out_fp32 || a.residual || a.se || !halo_shape(a)) return 0;
+    const int hr = halo_rows(a);
+    if (a.cout % 256 == 0 && 256 + hr <= halo_run_rows(4, 4)) return 1;
+    if (a.cout % 128 == 0 && a.cv_cin >= 128 && 512 + hr <= halo_run_rows(8, 2)) return 2;
+    if (a.cout % 128 == 0 && a.cv_cin >= 128 && 256 + hr <= halo_run_rows(4, 2)) return 3;      // (one 64-channel iteration: measured level with the 128x128 tile)
+    // (a 256 x 64 tile for the 64-channel layer conv1_2: 330 vs 388 TFLOP/s for the 128 x 64 tile of pointwise.hip -- four MFMAs per K
+    // step cannot cover the fragment masks and reads)
+    return 0;
+}
+}  // namespace
+
 bool conv_big_supported(const PwArgs& a) {
-    if (!(a.zeros && a.cv_cin % GK == 0 && !a.out_fp32 && !a.residual && !a.se && a.cv_k * a.cv_k <= 32 && a.cin >= 2 * GK &&
-          (long)a.m / a.hw * a.cv_h * a.cv_w * a.cv_cin * 2 < (1L << 31) && (long)a.cout * a.cin * 2 < (1L << 32)))
-        return false;
-    if (a.cout % BC == 0) return true;
-    // 128-channel layers: only on the 512 x 128 run kernel
-    return a.cout % 128 == 0 && a.cv_cin >= 128 && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w &&
-           512 + 2 * (a.cv_pad * a.cv_w + a.cv_pad) <= halo_run_rows(8) && (getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1) != 0;
+    if (halo_variant(a)) return true;
+    return a.zeros && a.cv_cin % GK == 0 && a.cout % BC == 0 && !a.out_fp32 && !a.residual && !a.se && a.cv_k * a.cv_k <= 32 && a.cin >= 2 * GK &&
+           (long)a.m / a.hw * a.cv_h * a.cv_w * a.cv_cin * 2 < (1L << 31) && (long)a.cout * a.cin * 2 < (1L << 32);
 }
 
 int launch_conv_big(const PwArgs& a, hipStream_t s) {
+    switch (halo_variant(a)) {
+        case 1: return launch_halo<4, 4, false>(a, s, "conv_halo_kernel<3,4,4>");
+        case 2: return launch_halo<8, 2, false>(a, s, "conv_halo_kernel<3,8,2>");
+        case 3: return launch_halo<4, 2, false>(a, s, "conv_halo_kernel<3,4,2>");
+        default: break;
+    }
+    DN_REQUIRE(a.cout % BC == 0, "conv: cout=%d not a multiple of 256 on the 256x256 tile", a.cout);
     const size_t otile = (size_t)BP * OROW, st = (size_t)2 * GSTAGE;
     const size_t lds = (st > otile ? st : otile) * sizeof(half_t) + BC * sizeof(float);
     static bool attr = false;
@@ -548,35 +596,6 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
         DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    static const int halo = getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1;
-    const int halo_rows = 2 * (a.cv_pad * a.cv_w + a.cv_pad);
-    const bool halo_ok = halo && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w &&
-                         (long)a.m * a.cv_cin * 2 < (1L << 31);
-    if (halo_ok && a.cout % 256 == 0 && halo != 2 && 256 + halo_rows <= halo_run_rows(4)) {
-        const size_t st2 = (size_t)2 * halo_run_rows(4) * HK + 2 * 2 * 256 * HK;
-        const size_t lds2 = (st2 > otile ? st2 : otile) * sizeof(half_t) + 256 * sizeof(float);
-        static bool attr2 = false;
-        if (!attr2) {
-            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 4, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr2 = true;
-        }
-        dn_note_kernel("conv_halo_kernel<3,4,4>");
-        hipLaunchKernelGGL((conv_halo_kernel<3, 4, 4, false>), dim3(dn_cdiv(a.m, 256), a.cout / 256), dim3(256), lds2, s, a);
-        return DN_OK;
-    }
-    if (halo_ok && a.cv_cin >= 128 && 512 + halo_rows <= halo_run_rows(8)) {        // 512 pixels x 128 channels: the 128-channel layers
-        const size_t st2 = (size_t)2 * halo_run_rows(8) * HK + 2 * 2 * 128 * HK, ot2 = (size_t)512 * 136;
-        const size_t lds2 = (st2 > ot2 ? st2 : ot2) * sizeof(half_t) + 128 * sizeof(float);
-        static bool attr3 = false;
-        if (!attr3) {
-            DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 8, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr3 = true;
-        }
-        dn_note_kernel("conv_halo_kernel<3,8,2>");
-        hipLaunchKernelGGL((conv_halo_kernel<3, 8, 2, false>), dim3(dn_cdiv(a.m, 512), a.cout / 128), dim3(256), lds2, s, a);
-        return DN_OK;
-    }
-    DN_REQUIRE(a.cout % BC == 0, "conv: cout=%d not a multiple of 256 on the 256x256 tile", a.cout);
     dn_note_kernel("conv_glds_kernel");
     hipLaunchKernelGGL(conv_glds_kernel, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds, s, a);
     return DN_OK;
@@ -587,23 +606,9 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
 bool conv_head_big_supported(const PwArgs& a) {
     static const int on = getenv("DN_CONV_HEAD_BIG") ? atoi(getenv("DN_CONV_HEAD_BIG")) : 1;
     static const int minwg = getenv("DN_CONV_HEAD_BIG_MIN") ? atoi(getenv("DN_CONV_HEAD_BIG_MIN")) : 40;
-    if (!on || !a.out_fp32 || a.residual || a.se || a.cv_cin % 64 || a.cv_k != 3 || a.cv_stride != 1 || a.cv_pad != a.cv_dil) return false;
-    if (a.cv_ho != a.cv_h || a.cv_wo != a.cv_w || 256 + 2 * (a.cv_pad * a.cv_w + a.cv_pad) > halo_run_rows(4)) return false;
-    if ((long)a.m * a.cv_cin * 2 >= (1L << 31) || (long)a.cout * a.cin * 2 >= (1L << 32)) return false;
-    if (a.cout & 1) return false;
+    if (!on || !a.out_fp32 || a.residual || a.se || !halo_shape(a) || 256 + halo_rows(a) > halo_run_rows(4, 4) || (a.cout & 1)) return false;
     const int tiles = dn_cdiv(a.cout, 256);
     return a.cout * 10 >= tiles * 256 * 6 && (long)dn_cdiv(a.m, 256) * tiles >= minwg;      // at most 40 % of the channel tiles idle
 }
 
-int launch_conv_head_big(const PwArgs& a, hipStream_t s) {
-    const size_t st2 = (size_t)2 * halo_run_rows(4) * HK + 2 * 2 * 256 * HK, ot2 = (size_t)2 * 128 * 260;
-    const size_t lds2 = (st2 > ot2 ? st2 : ot2) * sizeof(half_t) + 256 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    dn_note_kernel("conv_halo_kernel<3,4,4,head>");
-    hipLaunchKernelGGL((conv_halo_kernel<3, 4, 4, true>), dim3(dn_cdiv(a.m, 256), dn_cdiv(a.cout + a.cout_b, 256)), dim3(256), lds2, s, a);
-    return DN_OK;
-}
+int launch_conv_head_big(const PwArgs& a, hipStream_t s) { return launch_halo<4, 4, true>(a, s, "conv_halo_kernel<3,4,4,head>"); }

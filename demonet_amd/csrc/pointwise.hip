@@ -660,6 +660,11 @@ int launch_select(const PwArgs& a, hipStream_t s) {
             return launch_cfg<64, 64, 2, 2, CONV>(a, s);
         }
     }
+    if constexpr (CONV) {
+        static const int big = getenv("DN_CONV_BIG") ? atoi(getenv("DN_CONV_BIG")) : 1;
+        static const int bigmin = getenv("DN_CONV_BIG_MIN") ? atoi(getenv("DN_CONV_BIG_MIN")) : 40;       // measured on both VGG models: 40 < 90 < 200; the sub-batch chains fill the chip together
+        if (big && conv_big_supported(a) && wgs(256, 256) >= bigmin) return launch_conv_big(a, s);
+    }
     if (a.cout <= 32) {
         if (wgs(256, 32) >= 1500) return launch_cfg<256, 32, 4, 1, CONV>(a, s);
         return launch_cfg<128, 32, 4, 1, CONV>(a, s);
@@ -667,11 +672,6 @@ int launch_select(const PwArgs& a, hipStream_t s) {
     if (a.cout <= 64) {
         if (wgs(128, 64) >= 1500) return launch_cfg<128, 64, 4, 1, CONV>(a, s);
         return launch_cfg<64, 64, 2, 2, CONV>(a, s);
-    }
-    if constexpr (CONV) {
-        static const int big = getenv("DN_CONV_BIG") ? atoi(getenv("DN_CONV_BIG")) : 1;
-        static const int bigmin = getenv("DN_CONV_BIG_MIN") ? atoi(getenv("DN_CONV_BIG_MIN")) : 40;       // measured on both VGG models: 40 < 90 < 200; the sub-batch chains fill the chip together
-        if (big && conv_big_supported(a) && wgs(256, 256) >= bigmin) return launch_conv_big(a, s);
     }
     static const int t128 = getenv("DN_CONV_T128") ? atoi(getenv("DN_CONV_T128")) : 300;      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
     if (wgs(128, 128) >= (CONV ? t128 : 1500)) return launch_cfg<128, 128, 2, 2, CONV>(a, s);

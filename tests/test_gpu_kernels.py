@@ -135,6 +135,10 @@ DENSE_CASES = [
     (2, 5, 5, 128, 256, 3, 1, 0, 1, 1, True),        # valid 3x3 (extras tail): 5x5 -> 3x3
     (2, 19, 19, 64, 256, 3, 1, 1, 1, 1, False),      # same problem without the zero block -> the 128x128 / 64x64 tiles
     (2, 21, 17, 32, 96, 3, 1, 1, 1, 0, True),        # cin % 64 != 0, cout not a multiple of 256 -> general path, no activation
+    (1, 24, 150, 128, 128, 3, 1, 1, 1, 1, True),     # conv2_2-like: 512 x 128 tile, run of 512 + 2 * 151 rows
+    (1, 12, 256, 64, 128, 3, 1, 1, 1, 1, True),      # wide map, one 64-channel iteration: 256 x 128 tile
+    (1, 10, 300, 64, 64, 3, 1, 1, 1, 1, True),       # conv1_2-like: 256 x 64 tile, W = 300
+    (5, 9, 9, 64, 64, 3, 1, 1, 1, 1, True),          # tiles spanning several small images
 ]
 
 
