@@ -405,11 +405,104 @@ __global__ __launch_bounds__(256) void stem3s2_kernel(StemArgs a) {
     }
 }
 
+// 3x3 stride-1 stem with 64 output channels (VGG conv1_1, ssd_vgg16.py:33 via torchvision vgg16 features[0]) on the fp32 matrix
+// cores: K = 27 taps padded to 28 = 14 steps of v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation like the VALU
+// kernel above, which spends 1728 v_fmac per pixel here (26 TFLOP/s, 1 TB/s). A = weights (lane: channel lane & 31, tap
+// 2 i + (lane >> 5)), kept in registers; B = the normalised image taps, each lane loading its own (pixel lane & 31, tap) value
+// straight from the planar fp32 image (32 consecutive pixels per tap: whole 128-B lines). No LDS on the input side. The 32 x 64
+// result tile goes through a per-wave LDS slab so that every lane writes 16-byte row-contiguous chunks of the NHWC fp16 output.
+__global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_per_image, int tiles_per_wave) {
+    __shared__ __attribute__((aligned(16))) half_t slab[4][32 * 72];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int n = blockIdx.y;
+    const int HW = a.h * a.w_, OHW = a.ho * a.wo;
+    // this lane's tap of K step i: t = 2 i + hh = (c * 3 + ky) * 3 + kx; t == 27 is the zero pad
+    float wa[14][2];
+    int toff[14];               // offset of the tap relative to the output pixel's own position in plane 0
+    int tky[14], tkx[14];
+    float tmean[14], tinv[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const int t = 2 * i + hh;
+        const int tc = min(t, 26);
+        const int c = tc / 9, ky = (tc - c * 9) / 3, kx = tc - c * 9 - ky * 3;
+        wa[i][0] = t < 27 ? a.w[tc * 64 + r] : 0.f;
+        wa[i][1] = t < 27 ? a.w[tc * 64 + 32 + r] : 0.f;
+        toff[i] = c * HW + (ky - a.pad) * a.w_ + (kx - a.pad);
+        tky[i] = t < 27 ? ky - a.pad : 1 << 20;         // the pad tap is always "outside"
+        tkx[i] = kx - a.pad;
+        tmean[i] = a.mean[c];
+        tinv[i] = a.inv_std[c];
+    }
+    float4 bq[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[j][g] = *reinterpret_cast<const float4*>(a.bias + j * 32 + 8 * g + 4 * hh);
+    const float* img = a.img + (size_t)n * 3 * HW;
+    half_t* outp = a.out + (size_t)n * OHW * 64;
+    half_t* sl = slab[wave];
+    const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+    for (int tt = 0; tt < tiles_per_wave; ++tt) {
+        const int tile = tile0 + tt;
+        if (tile >= tiles_per_image) break;           // wave-uniform
+        const int p = min(tile * 32 + r, OHW - 1);     // pixels beyond the image: computed, never stored
+        const int oy = p / a.wo, ox = p - oy * a.wo;
+        const int base = oy * a.w_ + ox;
+        float v[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int iy = oy + tky[i], ix = ox + tkx[i];
+            const bool ok = iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_;
+            v[i] = img[ok ? base + toff[i] : 0];
+            // zero padding is applied to the NORMALISED image (transform then conv)
+            v[i] = ok ? (v[i] - tmean[i]) * tinv[i] : 0.f;
+        }
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][0], v[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][1], v[i], acc1, 0, 0, 0);
+        }
+        // lane = pixel r, registers 4g..4g+3 = channels 32 j + 8 g + 4 hh .. +3
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 h0, h1;
+            const float4 b0 = bq[0][g], b1 = bq[1][g];
+            h0[0] = (half_t)dn_act(acc0[4 * g + 0] + b0.x, a.act); h0[1] = (half_t)dn_act(acc0[4 * g + 1] + b0.y, a.act);
+            h0[2] = (half_t)dn_act(acc0[4 * g + 2] + b0.z, a.act); h0[3] = (half_t)dn_act(acc0[4 * g + 3] + b0.w, a.act);
+            h1[0] = (half_t)dn_act(acc1[4 * g + 0] + b1.x, a.act); h1[1] = (half_t)dn_act(acc1[4 * g + 1] + b1.y, a.act);
+            h1[2] = (half_t)dn_act(acc1[4 * g + 2] + b1.z, a.act); h1[3] = (half_t)dn_act(acc1[4 * g + 3] + b1.w, a.act);
+            *reinterpret_cast<half4*>(sl + r * 72 + 8 * g + 4 * hh) = h0;
+            *reinterpret_cast<half4*>(sl + r * 72 + 32 + 8 * g + 4 * hh) = h1;
+        }
+        // the slab is private to the wave: its own LDS operations are ordered, no barrier
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = lane + 64 * u;              // 16-B chunk of the 32 x 128-B tile
+            const int row = ch >> 3, q = ch & 7;
+            const uint4 val = *reinterpret_cast<const uint4*>(sl + row * 72 + q * 8);
+            const int pp = tile * 32 + row;
+            if (pp < OHW) *reinterpret_cast<uint4*>(outp + (size_t)pp * 64 + q * 8) = val;
+        }
+    }
+}
+
 template <int COUT, int K>
 int launch_stem_t(const StemArgs& a, hipStream_t s) {
     if (K == 3 && a.stride == 2 && a.pad == 1 && (a.w_ & 1) == 0 && 2 * a.wo == a.w_) {
         dn_note_kernel("stem3s2_kernel<%d>", COUT);
         hipLaunchKernelGGL((stem3s2_kernel<COUT>), dim3(dn_cdiv((long)a.ho * a.wo, 256), a.n), dim3(256), 0, s, a);
+        return DN_OK;
+    }
+    static const int mf = getenv("DN_STEM_MFMA") ? atoi(getenv("DN_STEM_MFMA")) : 1;
+    if (mf && K == 3 && COUT == 64 && a.stride == 1 && (long)3 * a.h * a.w_ < (1L << 30)) {
+        const int tiles = dn_cdiv((long)a.ho * a.wo, 32), per_wave = 8;
+        dn_note_kernel("stem_mfma64_kernel");
+        hipLaunchKernelGGL(stem_mfma64_kernel, dim3(dn_cdiv(tiles, 4 * per_wave), a.n), dim3(256), 0, s, a, tiles, per_wave);
         return DN_OK;
     }
     dn_note_kernel("stem_kernel<%d,%d>", COUT, K);
