@@ -390,3 +390,19 @@ def test_num_classes_and_postprocess_kwargs(ncls, post):
             assert np.array_equal(labels[i, :cnt], d["labels"])
             np.testing.assert_allclose(boxes[i, :cnt], d["boxes"], rtol=1e-5, atol=1e-3)
         np.testing.assert_allclose(np.sort(scores[i, :cnt])[::-1], np.sort(d["scores"])[::-1], rtol=1e-5, atol=1e-7)
+
+
+def test_vgg_batched_kernels_match_single_image_path():
+    """ssd300_vgg16 at batch 70 runs on the 256x256-tile conv kernels in two sub-batch chains; one image at a time runs on the
+    small tiles. Same weights, same images: the head logits agree within the fp16 tolerance for images at the start, around the
+    sub-batch boundary and at the end of the batch."""
+    m = models.load_synthetic(models.ssd300_vgg16(num_classes=91), 0).cuda()
+    imgs = torch.from_numpy(synth.images(77, 70, 300, 300)).cuda()
+    picks = (0, 1, 34, 35, 69)
+    single = [m.forward_heads(imgs[i:i + 1])[0][0].cpu() for i in picks]
+    batched = m.forward_heads(imgs)[0].cpu()
+    for ref, i in zip(single, picks):
+        tol = LOGIT_ATOL + LOGIT_RTOL * ref.abs()
+        assert bool(((batched[i] - ref).abs() <= tol).all()), i
+    boxes, scores, labels, counts = m.forward_batch(imgs)
+    assert bool(torch.isfinite(scores).all()) and int(counts.min()) > 0
