@@ -343,10 +343,13 @@ def main():
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, g, 1002)
-    if rank == 0:
-        print(json.dumps(result))
     if distributed:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to the C stdout of rank 0; push it out first so that the JSON line is the last line
+        C.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
