@@ -399,10 +399,13 @@ def test_vgg_batched_kernels_match_single_image_path():
     m = models.load_synthetic(models.ssd300_vgg16(num_classes=91), 0).cuda()
     imgs = torch.from_numpy(synth.images(77, 70, 300, 300)).cuda()
     picks = (0, 1, 34, 35, 69)
-    single = [m.forward_heads(imgs[i:i + 1])[0][0].cpu() for i in picks]
-    batched = m.forward_heads(imgs)[0].cpu()
-    for ref, i in zip(single, picks):
+    single = [tuple(t[0].cpu().clone() for t in m.forward_heads(imgs[i:i + 1])) for i in picks]
+    batched, batched_reg = (t.cpu() for t in m.forward_heads(imgs))
+    for (ref, ref_reg), i in zip(single, picks):
         tol = LOGIT_ATOL + LOGIT_RTOL * ref.abs()
         assert bool(((batched[i] - ref).abs() <= tol).all()), i
+        # the box heads of the large levels ride in the class heads' launch (channels beyond cout of the last channel tile)
+        tol_reg = LOGIT_ATOL + LOGIT_RTOL * ref_reg.abs()
+        assert bool(((batched_reg[i] - ref_reg).abs() <= tol_reg).all()), i
     boxes, scores, labels, counts = m.forward_batch(imgs)
     assert bool(torch.isfinite(scores).all()) and int(counts.min()) > 0
