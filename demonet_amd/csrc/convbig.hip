@@ -538,6 +538,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }  // namespace
 
 namespace {
+
+// ---- 64 input channels at full resolution (VGG conv1_2, conv2_1: 300^2 .. 512^2 maps) -----------------------------------------------
+// The flattened run of conv_halo_kernel needs 2 W + 2 halo rows -- too many for W >= 300 -- and with cin = 64 the whole K range of a
+// pixel is 128 B. Here a workgroup owns a 16 x 16 block of output pixels x 64 output channels: the 18 x 18 input patch (all 64
+// channels, 41 KB) is staged ONCE, zero-filled outside the image, so no tap needs a mask; the nine taps are nine row shifts of the
+// fragment reads inside the patch; only the weights stream (one 8-KB tap per stage, double-buffered). 58 KB of LDS and 64 accumulator
+// registers per workgroup: two workgroups per CU cover each other's barriers. Staging by LDS-DMA with the 128-B-row swizzle.
+constexpr int PT = 16, PP = PT + 2;             // output block edge, patch edge
+constexpr int PATCH_ROWS = 328;                 // 18 * 18 = 324 pixels, rounded up to 8-row DMA pieces
+constexpr int PATCH_HALFS = PATCH_ROWS * 64;
+constexpr int WTAP_HALFS = 64 * 64;             // one tap of 64 output channels
+
+__global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];
+    float* bsh = reinterpret_cast<float*>(lds_raw);             // [64]
+    half_t* patch = lds_raw + 128;                              // [PATCH_ROWS][64], swizzled 16-B chunks
+    half_t* wbuf = patch + PATCH_HALFS;                         // [2][64][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int H = a.cv_h, W = a.cv_w, NC = a.cout;
+    const int tiles_x = (W + PT - 1) / PT;
+    const int ty0 = (blockIdx.x / tiles_x) * PT, tx0 = (blockIdx.x % tiles_x) * PT;
+    const int n0 = blockIdx.y * 64, img = blockIdx.z;
+    const char* xbase = reinterpret_cast<const char*>(a.x) + (size_t)img * H * W * 128;
+    const char* zeros = reinterpret_cast<const char*>(a.zeros);
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)n0 * 9 * 128;
+
+    // DMA geometry: an instruction moves 8 rows of 128 B; lane -> row lane >> 3, position lane & 7, source chunk = position ^ ((row >> 1) & 7)
+    const int lrow = lane >> 3, lpos = lane & 7;
+    // patch pieces: 41 per workgroup, wave w takes pieces w, w + 4, ...
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int pc = wave + 4 * i;                            // wave-uniform
+        if (pc * 8 >= PATCH_ROWS) break;
+        const int q = pc * 8 + lrow;
+        const int py = q / PP, px = q - py * PP;
+        const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+        const bool ok = q < PP * PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int chunk = lpos ^ ((q >> 1) & 7);
+        const char* p = ok ? xbase + ((size_t)iy * W + ix) * 128 + chunk * 16 : zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(patch + pc * 8 * 64), 16, 0, 0);
+    }
+    auto issue_w = [&](int tap, int b) {                        // 64 rows: 8 pieces, two per wave
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = (wave * 2 + u) * 8 + lrow;
+            const int chunk = lpos ^ ((row >> 1) & 7);
+            const char* p = wbase + ((size_t)row * 9 + tap) * 128 + chunk * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(wbuf + b * WTAP_HALFS + (wave * 2 + u) * 8 * 64), 16, 0, 0);
+        }
+    };
+    issue_w(0, 0);
+    if (tid < 64) bsh[tid] = a.bias[n0 + tid];
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // wave w: block rows 4 w .. 4 w + 3; pixel tile j = rows 4 w + 2 j, + 1; lane -> (row r >> 4, column r & 15)
+    int q0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) q0[j] = (4 * wave + 2 * j + (r >> 4)) * PP + (r & 15);       // patch pixel of tap (0, 0)
+    const int wsw = (r >> 1) & 7;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int tap = 0; tap < 9; ++tap) {
+        const int b = tap & 1;
+        if (tap + 1 < 9) issue_w(tap + 1, b ^ 1);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const half_t* wb = wbuf + b * WTAP_HALFS;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 xf[2], wf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = q0[j] + ky * PP + kx;
+                xf[j] = *reinterpret_cast<const half8*>(patch + q * 64 + (((2 * ks + hh) ^ ((q >> 1) & 7)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + (i * 32 + r) * 64 + (((2 * ks + hh) ^ wsw) * 8));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue: block -> LDS [256 pixels][64 + 8] halfs over the patch, then 16-B chunks: a block row is 2 KB contiguous in NHWC
+    half_t* ot = patch;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int prow = (4 * wave + 2 * j) * PT + r;           // pixel index inside the block
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = i * 32 + 8 * g + 4 * hh;
+                const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
+                half4 hv;
+                hv[0] = (half_t)dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
+                hv[1] = (half_t)dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
+                hv[2] = (half_t)dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
+                hv[3] = (half_t)dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                *reinterpret_cast<half4*>(&ot[prow * 72 + cl]) = hv;
+            }
+    }
+    __syncthreads();
+    half_t* outp = reinterpret_cast<half_t*>(a.out) + (size_t)img * H * W * NC;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int c = tid + 256 * u;                            // 16-B chunk: 256 pixels x 8 chunks
+        const int px = c >> 3, ch = c & 7;
+        const int oy = ty0 + (px >> 4), ox = tx0 + (px & 15);
+        if (oy < H && ox < W)
+            *reinterpret_cast<uint4*>(outp + ((size_t)oy * W + ox) * NC + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&ot[px * 72 + ch * 8]);
+    }
+}
+
+bool patch_shape(const PwArgs& a) {
+    static const int on = getenv("DN_CONV_PATCH") ? atoi(getenv("DN_CONV_PATCH")) : 1;
+    return on && a.zeros && !a.out_fp32 && !a.residual && !a.se && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == 1 && a.cv_dil == 1 &&
+           a.cv_ho == a.cv_h && a.cv_wo == a.cv_w && a.cv_cin == 64 && a.cout % 64 == 0 && a.m / a.hw <= 65535;
+}
+
+int launch_patch(const PwArgs& a, hipStream_t s) {
+    const size_t lds = 512 + (size_t)(PATCH_HALFS + 2 * WTAP_HALFS) * sizeof(half_t);
+    static bool attr = false;
+    if (!attr) {
+        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    dn_note_kernel("conv_patch_kernel");
+    const int tiles = dn_cdiv(a.cv_w, PT) * dn_cdiv(a.cv_h, PT);
+    hipLaunchKernelGGL(conv_patch_kernel, dim3(tiles, a.cout / 64, a.m / a.hw), dim3(256), lds, s, a);
+    return DN_OK;
+}
+}  // namespace
+
+namespace {
 bool halo_shape(const PwArgs& a) {
     static const int halo = getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1;
     return halo && a.zeros && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w &&
@@ -576,12 +720,13 @@ int halo_variant(const PwArgs& a) {
 }  // namespace
 
 bool conv_big_supported(const PwArgs& a) {
-    if (halo_variant(a)) return true;
+    if (halo_variant(a) || patch_shape(a)) return true;
     return a.zeros && a.cv_cin % GK == 0 && a.cout % BC == 0 && !a.out_fp32 && !a.residual && !a.se && a.cv_k * a.cv_k <= 32 && a.cin >= 2 * GK &&
            (long)a.m / a.hw * a.cv_h * a.cv_w * a.cv_cin * 2 < (1L << 31) && (long)a.cout * a.cin * 2 < (1L << 32);
 }
 
 int launch_conv_big(const PwArgs& a, hipStream_t s) {
+    if (!halo_variant(a) && patch_shape(a)) return launch_patch(a, s);
     switch (halo_variant(a)) {
         case 1: return launch_halo<4, 4, false>(a, s, "conv_halo_kernel<3,4,4>");
         case 2: return launch_halo<8, 2, false>(a, s, "conv_halo_kernel<3,8,2>");
