@@ -561,35 +561,39 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
     const int tiles_x = (W + PT - 1) / PT;
     const int ty0 = (blockIdx.x / tiles_x) * PT, tx0 = (blockIdx.x % tiles_x) * PT;
     const int n0 = blockIdx.y * 64, img = blockIdx.z;
-    const char* xbase = reinterpret_cast<const char*>(a.x) + (size_t)img * H * W * 128;
+    const int CIN = a.cv_cin, NS = CIN / 64;                   // 64-channel slices: the patch is re-staged per slice, the accumulators stay
+    const char* xbase = reinterpret_cast<const char*>(a.x) + (size_t)img * H * W * CIN * 2;
     const char* zeros = reinterpret_cast<const char*>(a.zeros);
-    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)n0 * 9 * 128;
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)n0 * 9 * CIN * 2;
 
     // DMA geometry: an instruction moves 8 rows of 128 B; lane -> row lane >> 3, position lane & 7, source chunk = position ^ ((row >> 1) & 7)
     const int lrow = lane >> 3, lpos = lane & 7;
     // patch pieces: 41 per workgroup, wave w takes pieces w, w + 4, ...
+    auto issue_patch = [&](int slice) {
 #pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        const int pc = wave + 4 * i;                            // wave-uniform
-        if (pc * 8 >= PATCH_ROWS) break;
-        const int q = pc * 8 + lrow;
-        const int py = q / PP, px = q - py * PP;
-        const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-        const bool ok = q < PP * PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const int chunk = lpos ^ ((q >> 1) & 7);
-        const char* p = ok ? xbase + ((size_t)iy * W + ix) * 128 + chunk * 16 : zeros;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(patch + pc * 8 * 64), 16, 0, 0);
-    }
-    auto issue_w = [&](int tap, int b) {                        // 64 rows: 8 pieces, two per wave
+        for (int i = 0; i < 11; ++i) {
+            const int pc = wave + 4 * i;                            // wave-uniform
+            if (pc * 8 >= PATCH_ROWS) break;
+            const int q = pc * 8 + lrow;
+            const int py = q / PP, px = q - py * PP;
+            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            const bool ok = q < PP * PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int chunk = lpos ^ ((q >> 1) & 7);
+            const char* p = ok ? xbase + ((size_t)iy * W + ix) * CIN * 2 + slice * 128 + chunk * 16 : zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(patch + pc * 8 * 64), 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int slice, int tap, int b) {              // 64 rows: 8 pieces, two per wave
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int row = (wave * 2 + u) * 8 + lrow;
             const int chunk = lpos ^ ((row >> 1) & 7);
-            const char* p = wbase + ((size_t)row * 9 + tap) * 128 + chunk * 16;
+            const char* p = wbase + (((size_t)row * 9 + tap) * CIN + slice * 64) * 2 + chunk * 16;
             __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(wbuf + b * WTAP_HALFS + (wave * 2 + u) * 8 * 64), 16, 0, 0);
         }
     };
-    issue_w(0, 0);
+    issue_patch(0);
+    issue_w(0, 0, 0);
     if (tid < 64) bsh[tid] = a.bias[n0 + tid];
 
     floatx16 acc[2][2];
@@ -607,28 +611,36 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int tap = 0; tap < 9; ++tap) {
-        const int b = tap & 1;
-        if (tap + 1 < 9) issue_w(tap + 1, b ^ 1);
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const half_t* wb = wbuf + b * WTAP_HALFS;
+    for (int sl = 0; sl < NS; ++sl) {
+        for (int tap = 0; tap < 9; ++tap) {
+            const int b = (sl * 9 + tap) & 1;
+            if (tap + 1 < 9) issue_w(sl, tap + 1, b ^ 1);
+            else if (sl + 1 < NS) issue_w(sl + 1, 0, b ^ 1);
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const half_t* wb = wbuf + b * WTAP_HALFS;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            half8 xf[2], wf[2];
+            for (int ks = 0; ks < 4; ++ks) {
+                half8 xf[2], wf[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int q = q0[j] + ky * PP + kx;
-                xf[j] = *reinterpret_cast<const half8*>(patch + q * 64 + (((2 * ks + hh) ^ ((q >> 1) & 7)) * 8));
+                for (int j = 0; j < 2; ++j) {
+                    const int q = q0[j] + ky * PP + kx;
+                    xf[j] = *reinterpret_cast<const half8*>(patch + q * 64 + (((2 * ks + hh) ^ ((q >> 1) & 7)) * 8));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + (i * 32 + r) * 64 + (((2 * ks + hh) ^ wsw) * 8));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + (i * 32 + r) * 64 + (((2 * ks + hh) ^ wsw) * 8));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            if (tap == 8 && sl + 1 < NS) {
+                // everyone is done with this slice's patch only after the barrier: restage it behind one
+                __syncthreads();
+                issue_patch(sl + 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
     // epilogue: block -> LDS [256 pixels][64 + 8] halfs over the patch, then 16-B chunks: a block row is 2 KB contiguous in NHWC
     half_t* ot = patch;
@@ -661,10 +673,12 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
     }
 }
 
+int patch_max_cin() { return 128; }
+
 bool patch_shape(const PwArgs& a) {
     static const int on = getenv("DN_CONV_PATCH") ? atoi(getenv("DN_CONV_PATCH")) : 1;
     return on && a.zeros && !a.out_fp32 && !a.residual && !a.se && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == 1 && a.cv_dil == 1 &&
-           a.cv_ho == a.cv_h && a.cv_wo == a.cv_w && a.cv_cin == 64 && a.cout % 64 == 0 && a.m / a.hw <= 65535;
+           a.cv_ho == a.cv_h && a.cv_wo == a.cv_w && a.cv_cin % 64 == 0 && a.cv_cin <= patch_max_cin() && a.cout % 64 == 0 && a.m / a.hw <= 65535;
 }
 
 int launch_patch(const PwArgs& a, hipStream_t s) {
@@ -726,7 +740,9 @@ bool conv_big_supported(const PwArgs& a) {
 }
 
 int launch_conv_big(const PwArgs& a, hipStream_t s) {
-    if (!halo_variant(a) && patch_shape(a)) return launch_patch(a, s);
+    // 64 input channels: always the patch kernel; 128: where the run kernel would need its 256 x 128 tile (maps wider than 159; measured:
+    // conv2_2 of ssd512 882 vs 568 TFLOP/s, while the 512 x 128 run tile of the 150-wide map keeps the faster step)
+    if (patch_shape(a) && (a.cv_cin <= 64 || halo_variant(a) == 0 || halo_variant(a) == 3)) return launch_patch(a, s);
     switch (halo_variant(a)) {
         case 1: return launch_halo<4, 4, false>(a, s, "conv_halo_kernel<3,4,4>");
         case 2: return launch_halo<8, 2, false>(a, s, "conv_halo_kernel<3,8,2>");
