@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="images per GPU per step")
     ap.add_argument("--model", default=DEFAULT_MODEL)
+    ap.add_argument("--image-size", type=int, default=0, help="ssd_lite_mobilenet_v2 only: network input size (BASELINE config C3 is 300)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replay")
@@ -137,7 +138,8 @@ def main():
     from demonet_amd import models, synth
     from demonet_amd.dist import DetectionGatherer
     ncls = 21 if args.model == "ssd_lite_mobilenet_v2" else 91
-    model = models.load_synthetic(getattr(models, args.model)(num_classes=ncls), 0)
+    fkw = {"image_size": args.image_size} if (args.image_size and args.model == "ssd_lite_mobilenet_v2") else {}
+    model = models.load_synthetic(getattr(models, args.model)(num_classes=ncls, **fkw), 0)
     if args.weights == "worstcase":
         sd = {k: torch.from_numpy(v.copy()) for k, v in synth.state_dict(model.graph, 0).items()}
         for k in sd:

@@ -409,3 +409,24 @@ def test_vgg_batched_kernels_match_single_image_path():
         assert bool(((batched_reg[i] - ref_reg).abs() <= tol_reg).all()), i
     boxes, scores, labels, counts = m.forward_batch(imgs)
     assert bool(torch.isfinite(scores).all()) and int(counts.min()) > 0
+
+
+def test_v2_at_300_matches_oracle():
+    """BASELINE config C3: ssd_lite_mobilenet_v2 at 300 x 300 (odd maps 150 -> 75 -> 38 -> 19 -> 10 -> 5 -> 3 -> 2 -> 1, 3000 anchors):
+    head outputs against the fp32 CPU path, detections finite."""
+    name = "ssd_lite_mobilenet_v2"
+    m = models.ssd_lite_mobilenet_v2(image_size=300, num_classes=21, score_thresh=0.02)
+    g = m.graph
+    sd = synth.state_dict(g, 0)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.cuda()
+    imgs = torch.stack(_images(g, [611, 612]))
+    o = so.OracleSSD(name, sd, 21, size=(300, 300), score_thresh=0.02)
+    raw = o.forward_raw([i.cpu() for i in imgs])
+    logits, reg = (t.cpu() for t in m.forward_heads(imgs))
+    assert tuple(logits.shape) == (2, 3000, 21) == tuple(raw["cls_logits"].shape)
+    tol = 8e-2 + 1.5e-2 * raw["cls_logits"].abs()            # the tolerance of the 320 x 320 golden test of this model
+    assert bool(((logits - raw["cls_logits"]).abs() <= tol).all())
+    assert bool(((reg - raw["bbox_regression"]).abs() <= 8e-2 + 1.5e-2 * raw["bbox_regression"].abs()).all())
+    boxes, scores, labels, counts = m.forward_batch(imgs)
+    assert bool(torch.isfinite(scores).all()) and int(counts.max()) <= g.post["detections_per_img"]
