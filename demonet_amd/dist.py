@@ -58,8 +58,9 @@ class DetectionGatherer:
         self.acc = torch.zeros(self.K, batch, dets + 1, 6, dtype=torch.float32, device=device)
         # gathered windows, two deep: out[w][rank][slot] = payload of step (window w, slot)
         self.out = [torch.zeros(self.world, self.K, batch, dets + 1, 6, dtype=torch.float32, device=device) for _ in range(2)]
-        self.n = 0                  # steps submitted
-        self.gathered = 0           # steps covered by completed collectives
+        self.n = 0                  # next ticket (steps submitted, plus the slots a flush() of a partial window skipped)
+        self.gathered = 0           # tickets covered by completed collectives (always a multiple of the window after a gather)
+        self.filled = [0, 0]        # per gathered window (two deep): how many of its slots hold a submitted step
 
     def next_buffer(self):
         """The packed buffer the forward should write into (SSD.forward_batch(packed=...): the merge kernel fills it, no
@@ -68,6 +69,7 @@ class DetectionGatherer:
 
     def _gather_window(self):
         w = (self.gathered // self.K) & 1
+        self.filled[w] = self.n - self.gathered
         if self.world == 1 and not dist.is_initialized():
             self.out[w][0].copy_(self.acc)
         else:
@@ -97,13 +99,18 @@ class DetectionGatherer:
         """Gather the last, partial window (collective: every rank calls it after the same number of steps)."""
         if self.gathered < self.n:
             self._gather_window()
+            # the rest of that window was never submitted: the next submit() starts a fresh window (otherwise its ticket would
+            # already count as gathered and result() would hand out the stale rows of the flushed window)
+            self.n = self.gathered
 
     def result(self, ticket: int):
         """Detections of the global batch of step `ticket`, rank-major: (packed [W*B, D, 6], counts [W*B] int32). Available
         once its window is gathered (every `every` steps or after flush()) and until two windows later."""
         if ticket >= self.gathered:
             raise RuntimeError("step %d is not gathered yet: call flush() (collectively) first" % ticket)
-        if ticket < self.gathered - 2 * self.K:
+        if ticket < 0 or ticket < self.gathered - 2 * self.K:
             raise RuntimeError("step %d was overwritten by later windows" % ticket)
+        if ticket % self.K >= self.filled[(ticket // self.K) & 1]:
+            raise RuntimeError("ticket %d was never submitted (its window was flushed early)" % ticket)
         o = self.out[(ticket // self.K) & 1][:, ticket % self.K].reshape(self.world * self.B, self.D + 1, 6)
         return o[:, :self.D, :], o[:, self.D, 0].to(torch.int32)

@@ -295,8 +295,8 @@ def _ssdlite_head(g: Graph, feats, num_anchors, num_classes, eps, logit_std, reg
                  target=std * std, bias_std=0.3 * std)
 
 
-def ssdlite320_mobilenet_v3_large_graph(num_classes=91, logit_std=1.5, reg_std=1.0, **post) -> Graph:
-    eps = 1e-3                                                # ssd_mobilenetv3.py:196
+def ssdlite320_mobilenet_v3_large_graph(num_classes=91, logit_std=1.5, reg_std=1.0, eps=1e-3, **post) -> Graph:
+    # eps: BatchNorm eps of the factory's norm_layer (default 1e-3: ssd_mobilenetv3.py:196)
     g = Graph("ssdlite320_mobilenet_v3_large", (320, 320), [0.5] * 3, [0.5] * 3, num_classes)
     tab = _v3_large_table(2)
     x = g.input()

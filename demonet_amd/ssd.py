@@ -79,12 +79,29 @@ class SSD(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------
     def _weights_signature(self):
+        """What the folded fp16 weight blob of the plan was built from: every tensor's identity, storage address and in-place
+        version counter (optimizer steps, load_state_dict, .to(), load_state_dict(assign=True) and swapped Parameters all change
+        one of them). Writes that bypass the version counter (`p.data.copy_()`, `p.data.mul_()`) do not: call invalidate()."""
         dev = None
-        ver = 0
+        sig = []
         for t in list(self.parameters()) + list(self.buffers()):
-            ver += t._version
+            sig.append((id(t), t.data_ptr(), t._version))
             dev = t.device
-        return (ver, str(dev), self.score_thresh, self.nms_thresh, self.detections_per_img, self.topk_candidates)
+        return (hash(tuple(sig)), str(dev), self.score_thresh, self.nms_thresh, self.detections_per_img, self.topk_candidates)
+
+    def invalidate(self):
+        """Drop the device plan; the next forward lowers the current parameters again. Needed only after weight edits that bypass
+        autograd's version counter (`.data` writes)."""
+        self.release()
+        self._sig = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def _plan(self, device):
         if device.type != "cuda":
@@ -105,7 +122,7 @@ class SSD(nn.Module):
         return self._handle
 
     def release(self):
-        if self._handle is not None:
+        if getattr(self, "_handle", None) is not None:
             _lib.lib().dn_destroy(C.c_void_p(self._handle))
             self._handle = None
             self._bufs = {}
@@ -155,6 +172,7 @@ class SSD(nn.Module):
             raise TypeError(f"Expected input images to be of floating type (in range [0, 1]), but found type {images.dtype} instead")
         handle = self._plan(images.device)
         n, _, h, w = images.shape
+        self._check_packed(packed, n, images.device)
         b = self._buffers_for(n, h, w, images.device)
         if persistent_input and images.dtype == torch.float32 and images.is_contiguous():
             src = images
@@ -170,6 +188,15 @@ class SSD(nn.Module):
                                              C.c_void_p(b["ws"].data_ptr()), b["ws"].numel(), C.c_void_p(stream)), "dn_forward")
         return b["boxes"], b["scores"], b["labels"], b["counts"]
 
+    def _check_packed(self, packed, n, device):
+        """The merge kernel writes [n][D+1][6] fp32 rows through this pointer: anything else would be an out-of-bounds device write."""
+        if packed is None:
+            return
+        want = (n, self.detections_per_img + 1, 6)
+        if tuple(packed.shape) != want or packed.dtype != torch.float32 or not packed.is_contiguous() or packed.device != device:
+            raise ValueError("packed must be a contiguous float32 tensor of shape {} on {}, got {} {} on {}".format(
+                want, device, tuple(packed.shape), packed.dtype, packed.device))
+
     def forward_uint8(self, images: Tensor, packed: Optional[Tensor] = None):
         """images: [N,H,W,3] uint8 on the GPU -- a decoder's output (HWC, RGB). ToTensor (/255), the bilinear resize to the network
         size and the HWC -> planar conversion run on the device ahead of the stem (transform.py:27-53,129-138); results equal
@@ -181,6 +208,7 @@ class SSD(nn.Module):
             raise ValueError("forward_uint8 needs a contiguous [N,H,W,3] tensor")
         handle = self._plan(images.device)
         n, h, w, _ = images.shape
+        self._check_packed(packed, n, images.device)
         b = self._buffers_for(n, h, w, images.device)
         stream = torch.cuda.current_stream(images.device).cuda_stream
         _lib.check(_lib.lib().dn_set_packed_output(C.c_void_p(handle), C.c_void_p(packed.data_ptr()) if packed is not None else None))
@@ -199,6 +227,10 @@ class SSD(nn.Module):
 
     def forward_heads(self, images: Tensor):
         """Backbone + heads only: returns (cls_logits [N,A,K], bbox_regression [N,A,4]) fp32 device tensors (copies)."""
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError("expected a [N,3,H,W] batch, got {}".format(tuple(images.shape)))
+        if not images.is_floating_point():
+            raise TypeError(f"Expected input images to be of floating type (in range [0, 1]), but found type {images.dtype} instead")
         handle = self._plan(images.device)
         n, _, h, w = images.shape
         b = self._buffers_for(n, h, w, images.device)

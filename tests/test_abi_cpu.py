@@ -136,3 +136,74 @@ def test_graph_geometry_matches_survey():
     assert abs(macs / 1e6 - 583.17) < 1.0                       # 583.17 MMAC / image
     v = spec.ssd512_vgg16_graph(91)
     assert v.num_anchors() == 24732 and [g_.h for g_ in (v.t(f) for f in v.features)] == [64, 32, 16, 8, 6, 4, 1]
+
+
+@pytest.mark.parametrize("name,factory,kw", [
+    ("ssdlite320_mobilenet_v3_large", "ssdlite320_mobilenet_v3_large", {}),
+    ("ssd_lite_mobilenet_v2", "ssd_lite_mobilenet_v2", {}),
+    ("ssd300_vgg16", "ssd300_vgg16", {}),
+    ("ssd512_vgg16", "ssd512_vgg16", {}),
+])
+def test_product_anchors_bit_equal_reference(golden_dir, name, factory, kw):
+    """demonet_amd.anchors.default_boxes (the table the plan uploads) against the anchors the real reference's
+    DefaultBoxGenerator produced (anchor_utils.py:75-126; goldens from tests/golden/make_golden.py): bit-equal."""
+    import os
+    from demonet_amd import anchors
+    p = os.path.join(golden_dir, name + ".npz")
+    if not os.path.exists(p):
+        pytest.skip("no golden for " + name)
+    z = np.load(p)
+    g = getattr(models, factory)(num_classes=int(z["num_classes"]), **kw).graph
+    grid = [(g.t(f).h, g.t(f).w) for f in g.features]
+    a = anchors.default_boxes(grid, (g.size[1], g.size[0]), **g.anchor_spec)
+    assert a.dtype == np.float32 and a.shape == z["anchors"].shape
+    assert np.array_equal(a, z["anchors"])
+
+
+def test_factory_kwargs_over_defaults():
+    """{**defaults, **kwargs} of the reference factories (ssd_mobilenetv3.py:207-218, ssd_vgg16.py:200-206): image_mean / image_std
+    reach the plan's dn_model_desc; the training-only SSD.__init__ arguments are accepted; anything else raises instead of being
+    dropped; norm_layer's BatchNorm eps is honoured."""
+    import functools
+    from torch import nn
+    m = models.ssdlite320_mobilenet_v3_large(num_classes=3, image_mean=[0.4, 0.5, 0.6], image_std=(0.2, 0.3, 0.4), iou_thresh=0.4,
+                                             positive_fraction=0.3)
+    assert m.graph.image_mean == [0.4, 0.5, 0.6] and m.graph.image_std == [0.2, 0.3, 0.4]
+    low = LoweredModel(m.graph, {k: v.numpy() for k, v in m.state_dict().items()})
+    assert [round(x, 6) for x in low.desc.mean] == [0.4, 0.5, 0.6] and [round(x, 6) for x in low.desc.std] == [0.2, 0.3, 0.4]
+    d = models.ssdlite320_mobilenet_v3_large(num_classes=3)
+    assert d.graph.image_mean == [0.5] * 3 and d.graph.image_std == [0.5] * 3
+    v = models.ssd300_vgg16(num_classes=3, image_mean=[0.1, 0.2, 0.3])
+    assert v.graph.image_mean == [0.1, 0.2, 0.3] and abs(v.graph.image_std[0] - 1 / 255.0) < 1e-12
+    with pytest.raises(TypeError):
+        models.ssdlite320_mobilenet_v3_large(width_mult=0.5)
+    with pytest.raises(TypeError):
+        models.ssd300_vgg16(nonsense=1)
+    with pytest.raises(ValueError):
+        models.ssd300_vgg16(image_std=[1.0, 2.0])
+    with pytest.raises(NotImplementedError):
+        models.ssdlite320_mobilenet_v3_large(norm_layer=nn.GroupNorm)
+    # eps of the norm layer changes the folded weights
+    sd = {k: v.numpy() for k, v in d.state_dict().items()}
+    e = models.ssdlite320_mobilenet_v3_large(num_classes=3, norm_layer=functools.partial(nn.BatchNorm2d, eps=0.1, momentum=0.03))
+    a, b = LoweredModel(d.graph, sd), LoweredModel(e.graph, sd)
+    assert bytes(a.blob) != bytes(b.blob)
+
+
+def test_plan_signature_tracks_weight_updates():
+    """The cached device plan is keyed on identity / storage / version of every tensor and dropped by load_state_dict and
+    _apply (.to(), .half() ...); `.data` edits need invalidate()."""
+    m = models.ssdlite320_mobilenet_v3_large(num_classes=3)
+    s0 = m._weights_signature()
+    p = next(m.parameters())
+    p.data.mul_(1.0)
+    assert m._weights_signature() == s0                     # bypasses the version counter: documented, needs invalidate()
+    with torch.no_grad():
+        p.mul_(1.0)
+    assert m._weights_signature() != s0
+    s1 = m._weights_signature()
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, assign=True)
+    assert m._weights_signature() != s1
+    m._handle = None
+    m.invalidate()
+    assert m._sig is None

@@ -40,6 +40,28 @@ def _worker(rank, world, port, ret):
         assert pk.shape == (world * B, D, 6) and cn.tolist() == [D, 2, 0, 1, D, 3]
         assert torch.equal(pk[rank * B:(rank + 1) * B, :, :4], boxes + step)
         assert torch.equal(pk[rank * B:(rank + 1) * B, :, 5].to(torch.int64), labels)
+    # submit after a flush (a gatherer reused across evaluation epochs): tickets restart on a fresh window, the slot the
+    # flushed window never filled is not handed out as data
+    assert G.n == 6
+    idx2 = [G.submit(boxes + 10 + step, scores, labels, counts) for step in range(3)]
+    assert idx2 == [6, 7, 8]
+    for bad in (5, 8):                        # 5: never submitted; 8: not gathered yet
+        try:
+            G.result(bad)
+            raise AssertionError("expected RuntimeError")
+        except RuntimeError:
+            pass
+    G.flush()
+    for step, t in enumerate(idx2):
+        pk, cn = G.result(t)
+        assert torch.equal(pk[rank * B:(rank + 1) * B, :, :4], boxes + 10 + step) and cn.tolist() == [D, 2, 0, 1, D, 3]
+    # bench.py's C4 sharding arithmetic: global batch 256 over 8 ranks -> 32 contiguous images each, every image exactly once
+    world8 = [shard_range(256, r, 8) for r in range(8)]
+    assert all(hi - lo == 32 for lo, hi in world8) and [lo for lo, _ in world8] == list(range(0, 256, 32))
+    lo, hi = shard_range(2 * B, rank, world)          # and end to end here: each rank's shard, gathered, is the global batch in order
+    glob = torch.arange(2 * B * D * 6, dtype=torch.float32).view(2 * B, D, 6)
+    gp2, _ = gather_detections(glob[lo:hi].contiguous(), counts)
+    assert torch.equal(gp2, glob)
     ret[rank] = float(gp.sum())
     dist.destroy_process_group()
 
