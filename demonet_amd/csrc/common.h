@@ -56,6 +56,36 @@ __device__ __forceinline__ void fma_mix_h8(float (&acc)[8], const uint4& e, cons
 
 static inline int dn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Environment knob, read on EVERY call -- never latched in a static -- so that a test can A/B two settings in one process
+// (a new plan / the next eager launch sees the new value; a captured hipGraph keeps what it was captured with).
+int dn_knob(const char* name, int dflt);
+// hipFuncAttributeMaxDynamicSharedMemorySize = 160 KB, once per (device, kernel): the attribute is per device, so a process-wide
+// flag would leave the second GPU of a process at the 64 KB default.
+hipError_t dn_allow_big_lds(const void* kernel, int bytes = 160 * 1024);     // (kernels with static LDS pass 160 KB minus that)
+
+// XCD affinity. Measured on MI355X (tools/xcd_probe.hip): workgroup b of a dispatch runs on XCD (b + x0) % 8 with x0 fixed per
+// queue -- also for the parallel branches of a hipGraph -- and a kernel that reads what the SAME XCD's previous kernel wrote is
+// served from that XCD's 4 MB L2 (2 - 2.5x faster on 8 - 32 MB hand-offs than reading another XCD's output through the fabric).
+// So every kernel of the chain gives the workgroups with (flat index % 8) == g the images of group g = [g*q, (g+1)*q), q =
+// ceil(n / 8): a layer then reads what its own XCD has just written. Speed only -- results never depend on the placement.
+// Below 8 images there are fewer groups than XCDs and the plain mapping (all XCDs share every image) is kept.
+int xcd_images_per_group(int n);       // 0: grouping off (n < 8 or DN_XCD=0)
+// device side: flat workgroup index of a [8 groups][xq images][per_image] launch -> image and index within the image; false for
+// the slots of images beyond n (n % 8 != 0). Plain mapping (xq == 0): flat = image * per_image + index.
+__device__ __forceinline__ bool xcd_image_of(int flat, int per_image, int xq, int n, int& img, int& idx) {
+    if (xq > 0) {
+        const int g = flat & 7, w = flat >> 3;
+        const int j = w / per_image;
+        idx = w - j * per_image;
+        img = g * xq + j;
+        return img < n;
+    }
+    img = flat / per_image;
+    idx = flat - img * per_image;
+    return img < n;
+}
+static inline int xcd_image_slots(int xq, int n) { return xq > 0 ? 8 * xq : n; }     // image slots of such a launch
+
 // launchers implemented by the per-kernel translation units (used by plan.hip and by the single-op C entry points)
 struct PwArgs {
     // implicit-GEMM geometry (dense kxk conv); pointwise uses k=1: x rows are then simply [m][cin]
@@ -75,6 +105,7 @@ struct PwArgs {
     long out_img_stride;    // elements between images in `out`
     long out_base;          // element offset of image 0 (head ops: level offset * columns)
     long long* stamps = nullptr;   // dev-only phase stamps
+    int xq = 0;             // XCD grouping: images per group (0: plain mapping); see xcd_images_per_group
 };
 int launch_pointwise(const PwArgs& a, hipStream_t s);
 int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t s);
@@ -88,6 +119,7 @@ struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;
     int n, h, w_, c, k, stride, pad, act, ho, wo;
     float* pool = nullptr;      // optional: [n][blocks][c] fp32 per-workgroup sums of the outputs (SE squeeze)
+    int xq = 0;                 // XCD grouping: images per group (0: plain mapping)
 };
 int launch_depthwise(const DwArgs& a, hipStream_t s);
 int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s);
@@ -100,17 +132,19 @@ struct StemArgs {
     half_t* out;            // [n][ho][wo][cout]
     int n, h, w_, cout, k, stride, pad, act, ho, wo;
     float mean[3], inv_std[3];
+    int xq = 0;             // XCD grouping: images per group (0: plain mapping)
 };
 int launch_stem(const StemArgs& a, hipStream_t s);
 
 int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b1, const void* w2t, const float* b2, float* scale,
-                 int n, int c, int squeeze, int pool_pixels, hipStream_t s);
+                 int n, int c, int squeeze, int pool_pixels, hipStream_t s, int xq = 0);
 
 struct ConvArgs {
     const half_t* x; const half_t* w; const float* bias; void* out;
     const half_t* zeros = nullptr;      // >= 16 zero bytes on the device (optional; enables convbig.hip)
     int n, h, w_, cin, cout, k, stride, pad, dil, act, ho, wo, out_fp32;
     long out_img_stride, out_base;
+    int xq = 0;                         // XCD grouping: images per group (0: plain mapping)
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 PwArgs conv_to_pw(const ConvArgs& c);
@@ -136,6 +170,7 @@ struct TailArgs {
     const half_t* in0; long in0_stride;     // first op's input [n][pixels][cin], per-image stride in halfs
     const half_t* weights;
     long long* stamps;                      // dev-only
+    int xq;                                 // XCD grouping: images per group (0: plain mapping)
     TailOp op[TAIL_MAX_OPS];
 };
 int launch_tail(const TailArgs& a, int n, hipStream_t s);
@@ -149,6 +184,7 @@ struct ExpDwArgs {
     const half_t* w3; const float* b3;             // project [cout][cexp]; null: stop after the depthwise stage (out has cexp channels)
     int n, H, W, Ho, Wo, cin, cexp, cout, k, stride, pad, act1, act2, has_res;   // has_res: out += x (stride 1, cout == cin)
     int xw, chunks_per_wg;                         // filled by the launcher
+    int xq;                                        // XCD grouping: images per group (0: plain mapping)
     long long* stamps;                             // dev-only
 };
 int launch_expdw(const ExpDwArgs& a, hipStream_t s);
@@ -165,6 +201,7 @@ struct PostArgs {
     float* boxes; float* scores; int64_t* labels; int32_t* counts; int32_t* kept_anchor;
     float* packed = nullptr;    // optional [n][dets+1][6] fp32: rows (x1,y1,x2,y2,score,label), row `dets` = (count,0,..)
     void* ws; size_t ws_bytes;
+    int xq = 0;                 // XCD grouping: images per group (0: plain mapping)
 };
 size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets);
 int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev /* optional [4] phase boundaries */);

@@ -676,18 +676,14 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
 int patch_max_cin() { return 128; }
 
 bool patch_shape(const PwArgs& a) {
-    static const int on = getenv("DN_CONV_PATCH") ? atoi(getenv("DN_CONV_PATCH")) : 1;
+    const int on = dn_knob("DN_CONV_PATCH", 1);
     return on && a.zeros && !a.out_fp32 && !a.residual && !a.se && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == 1 && a.cv_dil == 1 &&
            a.cv_ho == a.cv_h && a.cv_wo == a.cv_w && a.cv_cin % 64 == 0 && a.cv_cin <= patch_max_cin() && a.cout % 64 == 0 && a.m / a.hw <= 65535;
 }
 
 int launch_patch(const PwArgs& a, hipStream_t s) {
     const size_t lds = 512 + (size_t)(PATCH_HALFS + 2 * WTAP_HALFS) * sizeof(half_t);
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_patch_kernel)));
     dn_note_kernel("conv_patch_kernel");
     const int tiles = dn_cdiv(a.cv_w, PT) * dn_cdiv(a.cv_h, PT);
     hipLaunchKernelGGL(conv_patch_kernel, dim3(tiles, a.cout / 64, a.m / a.hw), dim3(256), lds, s, a);
@@ -697,7 +693,7 @@ int launch_patch(const PwArgs& a, hipStream_t s) {
 
 namespace {
 bool halo_shape(const PwArgs& a) {
-    static const int halo = getenv("DN_CONV_HALO") ? atoi(getenv("DN_CONV_HALO")) : 1;
+    const int halo = dn_knob("DN_CONV_HALO", 1);
     return halo && a.zeros && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == a.cv_dil && a.cv_ho == a.cv_h && a.cv_wo == a.cv_w &&
            a.cv_cin % 64 == 0 && (long)a.m * a.cv_cin * 2 < (1L << 31) && (long)(a.cout + a.cout_b) * a.cin * 2 < (1L << 32);
 }
@@ -709,12 +705,7 @@ int launch_halo(const PwArgs& a, hipStream_t s, const char* name) {
     const size_t st = (size_t)2 * halo_run_rows(TP, TC) * HK + (size_t)2 * 2 * BCt * HK + 512;      // runs, weight stages, dummy block
     const size_t ot = HEAD ? (size_t)2 * (BPt / 2) * (BCt + 4) : (size_t)BPt * (BCt + 8);            // epilogue tile, in halfs
     const size_t lds = (st > ot ? st : ot) * sizeof(half_t) + BCt * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<3, TP, TC, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-        attr = true;
-    }
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_halo_kernel<3, TP, TC, HEAD>)));
     dn_note_kernel(name);
     hipLaunchKernelGGL((conv_halo_kernel<3, TP, TC, HEAD>), dim3(dn_cdiv(a.m, BPt), dn_cdiv(a.cout + (HEAD ? a.cout_b : 0), BCt)), dim3(256), lds, s, a);
     return DN_OK;
@@ -752,11 +743,7 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.cout % BC == 0, "conv: cout=%d not a multiple of 256 on the 256x256 tile", a.cout);
     const size_t otile = (size_t)BP * OROW, st = (size_t)2 * GSTAGE;
     const size_t lds = (st > otile ? st : otile) * sizeof(half_t) + BC * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_glds_kernel)));
     dn_note_kernel("conv_glds_kernel");
     hipLaunchKernelGGL(conv_glds_kernel, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds, s, a);
     return DN_OK;
@@ -765,8 +752,8 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
 // Dense 3x3 heads with fp32 outputs (SSDHead, generalized_ssd.py:77-92) on the run-staged 256x256 tile; channel tiles beyond cout
 // compute on the last weight row and are not stored.
 bool conv_head_big_supported(const PwArgs& a) {
-    static const int on = getenv("DN_CONV_HEAD_BIG") ? atoi(getenv("DN_CONV_HEAD_BIG")) : 1;
-    static const int minwg = getenv("DN_CONV_HEAD_BIG_MIN") ? atoi(getenv("DN_CONV_HEAD_BIG_MIN")) : 40;
+    const int on = dn_knob("DN_CONV_HEAD_BIG", 1);
+    const int minwg = dn_knob("DN_CONV_HEAD_BIG_MIN", 40);
     if (!on || !a.out_fp32 || a.residual || a.se || !halo_shape(a) || 256 + halo_rows(a) > halo_run_rows(4, 4) || (a.cout & 1)) return false;
     const int tiles = dn_cdiv(a.cout, 256);
     return a.cout * 10 >= tiles * 256 * 6 && (long)dn_cdiv(a.m, 256) * tiles >= minwg;      // at most 40 % of the channel tiles idle

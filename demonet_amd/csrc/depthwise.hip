@@ -14,13 +14,12 @@ namespace {
 
 // each thread: TW consecutive output pixels of one row x 8 channels; sliding input window kept in registers
 template <int K, int S, int TW>
-__device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int nblocks) {
+__device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int nblocks, const int n) {
     constexpr int NIN = (TW - 1) * S + K;
     extern __shared__ float red[];            // [256][8], only when pooling
     const int C8 = a.c >> 3;
     const int XS = (a.wo + TW - 1) / TW;
     int idx = bx * 256 + threadIdx.x;
-    const int n = blockIdx.y;
     const int cg = idx % C8;
     idx /= C8;
     const int xs = idx % XS;
@@ -112,8 +111,10 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
 }
 
 template <int K, int S, int TW>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
-    dw_body<K, S, TW>(a, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a, int nblocks) {
+    int img, bx;
+    if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, img, bx)) return;
+    dw_body<K, S, TW>(a, bx, nblocks, img);
 }
 
 // Grouped launch: up to 12 independent depthwise problems of the same (k, stride) and batch in ONE launch (the head
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
 struct DwGroup {
     int count;
     int start[13];
+    int nblocks[12];        // workgroups per image
     DwArgs a[12];
 };
 
@@ -130,7 +132,10 @@ __global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
 #pragma unroll
     for (int i = 1; i < 12; ++i)
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
-    dw_body<K, S, TW>(g.a[p], blockIdx.x - g.start[p], g.start[p + 1] - g.start[p]);
+    // start[] counts workgroups over all images of a problem (multiples of 8 with the XCD grouping: all problems share n)
+    int img, bx;
+    if (!xcd_image_of(blockIdx.x - g.start[p], g.nblocks[p], g.a[p].xq, g.a[p].n, img, bx)) return;
+    dw_body<K, S, TW>(g.a[p], bx, g.nblocks[p], img);
 }
 
 template <int K, int S, int TW>
@@ -141,11 +146,12 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
         g.start[i] = acc;
-        acc += dn_cdiv((long)arr[i].ho * ((arr[i].wo + TW - 1) / TW) * (arr[i].c / 8), 256);
+        g.nblocks[i] = dn_cdiv((long)arr[i].ho * ((arr[i].wo + TW - 1) / TW) * (arr[i].c / 8), 256);
+        acc += g.nblocks[i] * (arr[i].xq > 0 ? 8 * arr[i].xq : arr[i].n);
     }
     g.start[count] = acc;
     dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
-    hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].n), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc), dim3(256), 0, s, g);
     return DN_OK;
 }
 
@@ -153,7 +159,8 @@ template <int K, int S, int TW>
 int launch_dw(const DwArgs& a, hipStream_t s) {
     const long threads = (long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8);       // per image
     dn_note_kernel("dw_kernel<%d,%d,%d>", K, S, TW);
-    hipLaunchKernelGGL((dw_kernel<K, S, TW>), dim3(dn_cdiv(threads, 256), a.n), dim3(256), a.pool ? 256 * 8 * 4 : 0, s, a);
+    const int nblocks = dn_cdiv(threads, 256);
+    hipLaunchKernelGGL((dw_kernel<K, S, TW>), dim3(nblocks * (a.xq > 0 ? 8 * a.xq : a.n)), dim3(256), a.pool ? 256 * 8 * 4 : 0, s, a, nblocks);
     return DN_OK;
 }
 
@@ -170,7 +177,7 @@ int dw_blocks(const DwArgs& a) { return dn_cdiv((long)a.ho * ((a.wo + TW - 1) / 
 __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ partial, int nblk, const unsigned* __restrict__ w1t,
                                                    const float* __restrict__ b1, const unsigned* __restrict__ w2t,
                                                    const float* __restrict__ b2, float* __restrict__ scale,
-                                                   int c, int sq, float inv_pixels, long long* __restrict__ stamps) {
+                                                   int c, int sq, float inv_pixels, long long* __restrict__ stamps, int nimg, int xq) {
 #define SE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     // w1t: fc1 weight transposed [c][sq] fp16, read as [c][sq/2] half pairs; w2t: fc2 weight transposed [sq][c] fp16 as
     // [sq][c/2] pairs. A thread owns TWO adjacent outputs (one 4-byte load per weight row) and a K-slice.
@@ -178,7 +185,8 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ p
     float* mean = sh;
     float* z = sh + c;
     float* part = z + sq;
-    const int n = blockIdx.x;
+    int n, unused;
+    if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
     const int tid = threadIdx.x;
     SE_STAMP(0);
     const int sq2 = sq >> 1, c2 = c >> 1;
@@ -287,11 +295,12 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ p
 // with compile-time offsets makes hipcc fetch them with s_load (scalar cache) and feed them as SGPR operands of
 // v_fmac -- no LDS, no 400-register weight image (the first version needed 256 VGPRs and spilled for COUT >= 32).
 template <int COUT, int K>
-__global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs a, int nblocks) {
     const float* __restrict__ wts = a.w;
     const float* __restrict__ bias = a.bias;
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    const int n = blockIdx.y;
+    int n, bx;
+    if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, n, bx)) return;
+    int idx = bx * 256 + threadIdx.x;
     const int ox = idx % a.wo;
     const int oy = idx / a.wo;
     if (oy >= a.ho) return;
@@ -340,12 +349,13 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
 // above pays one exposed memory round trip per (channel, row) step because its loop must not be unrolled (SGPR pressure);
 // here the loads are hoisted and the normalised taps wait in LDS for the (still not unrolled) weight loop.
 template <int COUT>
-__global__ __launch_bounds__(256) void stem3s2_kernel(StemArgs a) {
+__global__ __launch_bounds__(256) void stem3s2_kernel(StemArgs a, int nblocks) {
     __shared__ float taps[27][256];     // this thread's 27 normalised taps, parked in its own LDS column between the phases
     const float* __restrict__ wts = a.w;
     const float* __restrict__ bias = a.bias;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int n = blockIdx.y;
+    int n, bx;
+    if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, n, bx)) return;
+    const int idx = bx * 256 + threadIdx.x;
     const int ox = idx % a.wo;
     int oy = idx / a.wo;
     const bool live = oy < a.ho;        // no early return: the shuffle needs every lane; dead threads redo the last row
@@ -411,11 +421,12 @@ __global__ __launch_bounds__(256) void stem3s2_kernel(StemArgs a) {
 // 2 i + (lane >> 5)), kept in registers; B = the normalised image taps, each lane loading its own (pixel lane & 31, tap) value
 // straight from the planar fp32 image (32 consecutive pixels per tap: whole 128-B lines). No LDS on the input side. The 32 x 64
 // result tile goes through a per-wave LDS slab so that every lane writes 16-byte row-contiguous chunks of the NHWC fp16 output.
-__global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_per_image, int tiles_per_wave) {
+__global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_per_image, int tiles_per_wave, int nblocks) {
     __shared__ __attribute__((aligned(16))) half_t slab[4][32 * 72];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int n = blockIdx.y;
+    int n, bx;
+    if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, n, bx)) return;
     const int HW = a.h * a.w_, OHW = a.ho * a.wo;
     // this lane's tap of K step i: t = 2 i + hh = (c * 3 + ky) * 3 + kx; t == 27 is the zero pad
     float wa[14][2];
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_
     const float* img = a.img + (size_t)n * 3 * HW;
     half_t* outp = a.out + (size_t)n * OHW * 64;
     half_t* sl = slab[wave];
-    const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+    const int tile0 = (bx * 4 + wave) * tiles_per_wave;
     for (int tt = 0; tt < tiles_per_wave; ++tt) {
         const int tile = tile0 + tt;
         if (tile >= tiles_per_image) break;           // wave-uniform
@@ -493,20 +504,24 @@ __global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_
 
 template <int COUT, int K>
 int launch_stem_t(const StemArgs& a, hipStream_t s) {
+    const int images = a.xq > 0 ? 8 * a.xq : a.n;      // image slots of the launch (XCD grouping: 8 groups of xq)
     if (K == 3 && a.stride == 2 && a.pad == 1 && (a.w_ & 1) == 0 && 2 * a.wo == a.w_) {
         dn_note_kernel("stem3s2_kernel<%d>", COUT);
-        hipLaunchKernelGGL((stem3s2_kernel<COUT>), dim3(dn_cdiv((long)a.ho * a.wo, 256), a.n), dim3(256), 0, s, a);
+        const int nblocks = dn_cdiv((long)a.ho * a.wo, 256);
+        hipLaunchKernelGGL((stem3s2_kernel<COUT>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks);
         return DN_OK;
     }
-    static const int mf = getenv("DN_STEM_MFMA") ? atoi(getenv("DN_STEM_MFMA")) : 1;
+    const int mf = dn_knob("DN_STEM_MFMA", 1);
     if (mf && K == 3 && COUT == 64 && a.stride == 1 && (long)3 * a.h * a.w_ < (1L << 30)) {
         const int tiles = dn_cdiv((long)a.ho * a.wo, 32), per_wave = 8;
         dn_note_kernel("stem_mfma64_kernel");
-        hipLaunchKernelGGL(stem_mfma64_kernel, dim3(dn_cdiv(tiles, 4 * per_wave), a.n), dim3(256), 0, s, a, tiles, per_wave);
+        const int nblocks = dn_cdiv(tiles, 4 * per_wave);
+        hipLaunchKernelGGL(stem_mfma64_kernel, dim3(nblocks * images), dim3(256), 0, s, a, tiles, per_wave, nblocks);
         return DN_OK;
     }
     dn_note_kernel("stem_kernel<%d,%d>", COUT, K);
-    hipLaunchKernelGGL((stem_kernel<COUT, K>), dim3(dn_cdiv((long)a.ho * a.wo, 256), a.n), dim3(256), 0, s, a);
+    const int nblocks = dn_cdiv((long)a.ho * a.wo, 256);
+    hipLaunchKernelGGL((stem_kernel<COUT, K>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks);
     return DN_OK;
 }
 
@@ -543,12 +558,12 @@ int depthwise_pool_blocks(const DwArgs& a) {
 }
 
 int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b1, const void* w2t, const float* b2, float* scale,
-                 int n, int c, int squeeze, int pool_pixels, hipStream_t s) {
+                 int n, int c, int squeeze, int pool_pixels, hipStream_t s, int xq) {
     DN_REQUIRE(c <= 1024 && squeeze <= 256 && c % 2 == 0 && squeeze % 2 == 0, "se: c=%d squeeze=%d outside the kernel's range (even, <= 1024 / 256)", c, squeeze);
     dn_note_kernel("se_fc_kernel");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(1024), (size_t)(c + squeeze + 2048) * sizeof(float), s, partial, nblk,
+    hipLaunchKernelGGL(se_fc_kernel, dim3(xq > 0 ? 8 * xq : n), dim3(1024), (size_t)(c + squeeze + 2048) * sizeof(float), s, partial, nblk,
                        reinterpret_cast<const unsigned*>(w1t), b1, reinterpret_cast<const unsigned*>(w2t), b2, scale, c, squeeze,
-                       1.0f / (float)pool_pixels, g_se_stamps);
+                       1.0f / (float)pool_pixels, g_se_stamps, n, xq);
     return DN_OK;
 }
 

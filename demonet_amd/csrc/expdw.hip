@@ -21,7 +21,7 @@
 
 static long long* g_xd_stamps = nullptr;     // dev hook (tools/probe_expdw.py): per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_expdw_stamps(void* dev_ptr) { g_xd_stamps = (long long*)dev_ptr; }
-#define XD_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define XD_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 namespace {
 
@@ -36,7 +36,7 @@ struct ExpDwGeom {
 };
 
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ>
-__global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
+__global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int zsplit) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
     static_assert(K * K * 8 <= NT, "one 16-byte piece of the chunk's depthwise weights per thread");
@@ -52,14 +52,30 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int n = blockIdx.y, tile = blockIdx.x;
+    // flat 1-D grid [image slot][chunk split z][tile]; XCD grouping (common.h): the workgroups with equal (index % 8) share the
+    // images of one group of a.xq images
+    int n, rem;
+    {
+        const int per_image = tiles * zsplit;
+        if (a.xq > 0) {
+            const int g = blockIdx.x & 7, w = blockIdx.x >> 3;
+            const int j = w / per_image;
+            rem = w - j * per_image;
+            n = g * a.xq + j;
+        } else {
+            n = blockIdx.x / per_image;
+            rem = blockIdx.x - n * per_image;
+        }
+        if (n >= a.n) return;
+    }
+    const int zblk = rem / tiles, tile = rem - zblk * tiles;
     const int tiles_x = (a.Wo + OW - 1) / OW;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = ty * OH, ox0 = tx * OW;
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
     const int cin = a.cin, cexp = a.cexp;
     const int KS = (cin + 15) >> 4;
-    const int c_begin = blockIdx.z * a.chunks_per_wg * 64;
+    const int c_begin = zblk * a.chunks_per_wg * 64;
     const int c_end = min(cexp, c_begin + a.chunks_per_wg * 64);
 
     // Per-chunk operands that come from global memory, requested one phase ahead of their use so that their latency hides
@@ -140,7 +156,6 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
     floatx16 pacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
-    const int tiles = gridDim.x;
     for (int c0 = c_begin; c0 < c_end; c0 += 64) {
         if (tid < K * K * 8) *reinterpret_cast<uint4*>(&Wd[(tid >> 3) * 64 + (tid & 7) * 8]) = wdreg;
         if (tid < 64) Bd[tid] = bdreg;
@@ -289,15 +304,12 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a) {
 }
 
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ>
-int launch_k(const ExpDwArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+int launch_k(const ExpDwArgs& a, dim3 grid3, size_t lds, hipStream_t s) {
+    const int tiles = grid3.x, zsplit = grid3.z;
+    const dim3 grid((unsigned)tiles * zsplit * (a.xq > 0 ? 8 * a.xq : a.n));
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>)));
     dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
-    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>), grid, dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>), grid, dim3(NT), lds, s, a, tiles, zsplit);
     return DN_OK;
 }
 
@@ -313,7 +325,7 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     // split the 64-channel chunks over grid.z until there are enough workgroups to fill the chip a few times over
     // (not with a project stage: it sums over all chunks inside the workgroup)
     const int tiles = dn_cdiv(a.Ho, OH) * dn_cdiv(a.Wo, OW), chunks = dn_cdiv(a.cexp, 64);
-    static const int want = getenv("DN_EXPDW_WGS") ? atoi(getenv("DN_EXPDW_WGS")) : 1024;
+    const int want = dn_knob("DN_EXPDW_WGS", 1024);
     int cpw = chunks;
     while (!proj && cpw > 1 && (long)tiles * a.n * dn_cdiv(chunks, cpw) < want) --cpw;
     a.chunks_per_wg = cpw;

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <tuple>
@@ -37,6 +38,31 @@ extern "C" int dn_abi_version(void) { return DN_ABI_VERSION; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+int dn_knob(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+hipError_t dn_allow_big_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
+}
+
+// XCD grouping policy (common.h). Read per call, never latched: DN_XCD=0 switches it off (A/B runs, tests of the plain mapping).
+int xcd_images_per_group(int n) {
+    const char* v = getenv("DN_XCD");
+    if (v && atoi(v) == 0) return 0;
+    return n >= 8 ? (n + 7) / 8 : 0;
+}
+
 struct Layout {
     int n = 0;
     std::vector<size_t> toff;       // per tensor byte offset in workspace (SIZE_MAX: not materialised)
@@ -46,9 +72,10 @@ struct Layout {
 
 struct GraphKey {
     const void* img; int n, h, w; void* ws; void* boxes; void* scores; void* labels; void* counts; int heads_only; void* packed;
+    int chain;          // sub-batch chain index (one single-chain graph per sub-batch), -1: the whole forward in one graph
     bool operator<(const GraphKey& o) const {
-        return std::tie(img, n, h, w, ws, boxes, scores, labels, counts, heads_only, packed) <
-               std::tie(o.img, o.n, o.h, o.w, o.ws, o.boxes, o.scores, o.labels, o.counts, o.heads_only, o.packed);
+        return std::tie(img, n, h, w, ws, boxes, scores, labels, counts, heads_only, packed, chain) <
+               std::tie(o.img, o.n, o.h, o.w, o.ws, o.boxes, o.scores, o.labels, o.counts, o.heads_only, o.packed, o.chain);
     }
 };
 
@@ -75,6 +102,8 @@ struct dn_plan {
     std::vector<int> op_feat_level;         // main op producing a feature map: its level, else -1
     bool multi_stream = false;
     int split = 2;                          // sub-batch branches per forward (see batch_split)
+    bool chain_graphs = false;              // DN_CHAIN_GRAPHS=1: one single-chain graph per sub-batch on its own stream (default: branches of ONE graph)
+    bool xcd = true;                        // XCD grouping of every kernel's workgroups by image (common.h; DN_XCD, read in dn_create)
     hipStream_t branch_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_branch[3] = {nullptr, nullptr, nullptr};
     std::map<std::pair<int, int>, Layout> sub_layouts;
@@ -215,7 +244,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             }
             // depthwise -> project without an expand (first block of the MobileNets): correct but measured slower than the two
             // launches (16 channels leave half of the workgroup idle in the depthwise stage) -- opt-in
-            static const bool noexp = getenv("DN_EXPDW_NOEXP") ? atoi(getenv("DN_EXPDW_NOEXP")) != 0 : false;
+            const bool noexp = dn_knob("DN_EXPDW_NOEXP", 0) != 0;
             if (noexp && dw_ok(a) && p->tensors[a.in].kind == DN_T_ACT && expdw_supported(a.cin, a.cin, a.k, a.stride) && a.cin <= 32 &&
                 proj_ok(d, a, a.in)) {
                 p->fused_len[i] = 2; p->fused_kind[i] = 2; i += 1;
@@ -313,6 +342,8 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         }
     }
     p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
+    p->xcd = getenv("DN_XCD") ? atoi(getenv("DN_XCD")) != 0 : true;
+    p->chain_graphs = dn_knob("DN_CHAIN_GRAPHS", 0) != 0;
     p->split = getenv("DN_SPLIT") ? atoi(getenv("DN_SPLIT")) : 2;
     if (p->split < 1) p->split = 1;
     if (p->split > 4) p->split = 4;
@@ -443,6 +474,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     float* logits = reinterpret_cast<float*>(ws + L.logits_off);
     float* reg = reinterpret_cast<float*>(ws + L.reg_off);
     const unsigned char* const Wb = p->weights_dev;
+    const int xq = (p->xcd && n >= 8) ? (n + 7) / 8 : 0;        // images per XCD group of this (sub-)batch, 0: plain mapping
     auto make_pw = [&](const dn_op_desc& o) {
         const dn_tensor_desc& ti = p->tensors[o.in];
         PwArgs a;
@@ -455,6 +487,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.hw = ti.h * ti.w;
         a.m = n * a.hw;
         a.cin = o.cin; a.cout = o.cout; a.act = o.act;
+        a.xq = xq;
         if (o.head) {
             const int cols = (o.head == 1) ? d.num_classes : 4;
             a.out = (o.head == 1) ? (void*)logits : (void*)reg;
@@ -478,6 +511,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.n = n; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
         a.ho = to.h; a.wo = to.w;
         a.pool = o.pool >= 0 ? reinterpret_cast<float*>(tptr(o.pool)) : nullptr;
+        a.xq = xq;
         return a;
     };
     auto make_conv = [&](const dn_op_desc& o) {
@@ -490,6 +524,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.zeros = reinterpret_cast<const half_t*>(Wb + p->zeros_off);
         a.n = n; a.h = ti.h; a.w_ = ti.w; a.cin = o.cin; a.cout = o.cout; a.k = o.k; a.stride = o.stride;
         a.pad = o.pad; a.dil = o.dil; a.act = o.act; a.ho = to.h; a.wo = to.w;
+        a.xq = xq;
         if (o.head) {
             const int cols = (o.head == 1) ? d.num_classes : 4;
             a.out = (o.head == 1) ? (void*)logits : (void*)reg;
@@ -540,7 +575,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             }
             // box and class heads of all levels in ONE launch when they fit (a dependent launch costs ~4.5 us even when empty, and
             // the narrow box heads then share the class heads' tile instead of running as a launch of their own)
-            static const bool merge_heads = getenv("DN_HEAD_MERGE") ? atoi(getenv("DN_HEAD_MERGE")) != 0 : true;
+            const bool merge_heads = dn_knob("DN_HEAD_MERGE", 1) != 0;
             const bool one = merge_heads && !p->head_reg.empty() && !p->head_cls.empty() && p->head_reg.size() + p->head_cls.size() <= 12 &&
                              p->ops[p->head_reg[0]].type == p->ops[p->head_cls[0]].type;
             for (int kind = 0; kind < 2; ++kind) {
@@ -621,6 +656,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             const dn_op_desc& o0 = p->ops[i];
             ta.in0 = reinterpret_cast<const half_t*>(tptr(o0.in));
             ta.in0_stride = (long)(L.tbytes[o0.in] / (size_t)L.n / 2);
+            ta.xq = xq;
             for (int q = 0; q < ta.count; ++q) {
                 const dn_op_desc& oq = p->ops[i + q];
                 const dn_tensor_desc& tq = p->tensors[oq.in];
@@ -658,6 +694,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             a.cin = tin.c; a.cexp = dwo.cin; a.cout = pj ? pj->cout : dwo.cin;
             a.k = dwo.k; a.stride = dwo.stride; a.pad = dwo.pad;
             a.has_res = (pj && pj->residual >= 0) ? 1 : 0;
+            a.xq = xq;
             rc = launch_expdw(a, s);
             if (rc != DN_OK) return rc;
             for (int q = 0; q < len; ++q) note(i + q, i);
@@ -676,6 +713,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 a.n = n; a.h = ti.h; a.w_ = ti.w; a.cout = o.cout; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
                 a.ho = to.h; a.wo = to.w;
                 for (int c = 0; c < 3; ++c) { a.mean[c] = d.mean[c]; a.inv_std[c] = 1.0f / d.std[c]; }
+                a.xq = xq;
                 rc = launch_stem(a, s);
                 break;
             }
@@ -689,7 +727,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), p->pool_blocks[o.in], W + o.w_off,
                                   reinterpret_cast<const float*>(W + o.b_off), W + o.w2_off,
                                   reinterpret_cast<const float*>(W + o.b2_off), reinterpret_cast<float*>(tptr(o.out)), n,
-                                  o.cin, o.squeeze, o.pool_pixels, s);
+                                  o.cin, o.squeeze, o.pool_pixels, s, xq);
                 break;
             }
             case DN_OP_CONV:
@@ -726,6 +764,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = nullptr;
         a.packed = packed;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
+        a.xq = xq;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
         if (rc) return rc;
@@ -773,6 +812,21 @@ static int enqueue_all(dn_plan* p, const float* images, int n, int h, int w, flo
     return DN_OK;
 }
 
+// chain k of S on stream s (no fork / join): what one per-chain graph captures
+static int enqueue_chain(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
+                         int32_t* counts, unsigned char* ws, bool heads_only, hipStream_t s, int S, int k) {
+    const size_t D = (size_t)p->d.detections_per_img;
+    size_t n0 = 0;
+    for (int q = 0; q < k; ++q) n0 += sub_count(n, S, q);
+    const int ns = sub_count(n, S, k);
+    const Layout& V = get_sub_layout(p, n, S, k);
+    const float* sub_images = p->input_u8 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(images) + n0 * 3 * (size_t)h * w)
+                                          : images + n0 * 3 * (size_t)h * w;
+    return enqueue(p, sub_images, ns, h, w, boxes ? boxes + n0 * D * 4 : nullptr, scores ? scores + n0 * D : nullptr,
+                   labels ? labels + n0 * D : nullptr, counts ? counts + n0 : nullptr, ws, V, heads_only, s, false,
+                   p->packed_out ? p->packed_out + n0 * (D + 1) * 6 : nullptr, 0);
+}
+
 static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
                         int32_t* counts, void* workspace, size_t ws_bytes, void* stream, bool heads_only) {
     DN_REQUIRE(p && images && workspace, "dn_forward: null argument");
@@ -812,32 +866,68 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     }
     if (!p->graph_mode) return enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, false);
 
-    GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, (heads_only ? 1 : 0) | (p->input_u8 ? 2 : 0), p->packed_out};
+    // Default: the sub-batch chains are parallel branches of ONE graph. DN_CHAIN_GRAPHS=1: one single-chain hipGraph per
+    // sub-batch, each replayed on a stream of its own (the caller's and the plan's branch streams, forked / joined with events
+    // around the launches). In isolation (tools/queue_probe.hip) single-chain graphs on different streams overlap completely and
+    // each queue pays its own 1.7 us per dependent launch, while the branches of one graph pay ~2.9 us per launch one after
+    // another; on the real chain the two forms measure the same at two chains (1.25 vs 1.24 ms) and per-chain graphs lose
+    // badly at three or four (1.9 ms): kept as an opt-in for that measurement only.
+    const int S = batch_split(p, n);
+    const bool per_chain = S > 1 && p->chain_graphs;
+    const int flags = (heads_only ? 1 : 0) | (p->input_u8 ? 2 : 0);
+    auto capture = [&](const GraphKey& key, hipGraphExec_t* out) -> int {
+        hipGraph_t g = nullptr;
+        if (!p->capture_stream) DN_HIP_CHECK(hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking));
+        hipStream_t cs = p->capture_stream;
+        DN_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc;
+        if (key.chain < 0) rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, cs, false);
+        else rc = enqueue_chain(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, cs, S, key.chain);
+        hipError_t e = hipStreamEndCapture(cs, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) { dn_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DN_E_HIP; }
+        e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { dn_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return DN_E_HIP; }
+        return DN_OK;
+    };
+    GraphKey key{images, n, h, w, workspace, boxes, scores, labels, counts, flags, p->packed_out, per_chain ? 0 : -1};
     auto it = p->graphs.find(key);
     if (it == p->graphs.end()) {
         // first call with this signature: run once eagerly (sets function attributes, validates), then capture
         int rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, false);
         if (rc) return rc;
-        hipGraph_t g = nullptr;
-        if (!p->capture_stream) DN_HIP_CHECK(hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking));
-        hipStream_t cs = p->capture_stream;
-        DN_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, cs, false);
-        hipError_t e = hipStreamEndCapture(cs, &g);
-        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess) { dn_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return DN_E_HIP; }
-        hipGraphExec_t ge = nullptr;
-        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (e != hipSuccess) { dn_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return DN_E_HIP; }
-        if (p->graphs.size() >= 16) {       // bound the cache
+        if (p->graphs.size() + (per_chain ? S : 1) > 16) {       // bound the cache
             for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
             p->graphs.clear();
         }
-        p->graphs.emplace(key, ge);
+        for (int k = 0; k < (per_chain ? S : 1); ++k) {
+            GraphKey kk = key;
+            kk.chain = per_chain ? k : -1;
+            hipGraphExec_t ge = nullptr;
+            rc = capture(kk, &ge);
+            if (rc) return rc;
+            p->graphs.emplace(kk, ge);
+        }
         return DN_OK;       // the eager run above already produced this call's results
     }
+    if (!per_chain) {
+        DN_HIP_CHECK(hipGraphLaunch(it->second, s));
+        return DN_OK;
+    }
+    DN_HIP_CHECK(hipEventRecord(p->ev_fork, s));
+    for (int k = 1; k < S; ++k) {
+        GraphKey kk = key;
+        kk.chain = k;
+        auto itk = p->graphs.find(kk);
+        DN_REQUIRE(itk != p->graphs.end(), "dn_forward: chain graph %d missing", k);
+        hipStream_t bs = p->branch_stream[k - 1];
+        DN_HIP_CHECK(hipStreamWaitEvent(bs, p->ev_fork, 0));
+        DN_HIP_CHECK(hipGraphLaunch(itk->second, bs));
+        DN_HIP_CHECK(hipEventRecord(p->ev_branch[k - 1], bs));
+    }
     DN_HIP_CHECK(hipGraphLaunch(it->second, s));
+    for (int k = 1; k < S; ++k) DN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_branch[k - 1], 0));
     return DN_OK;
 }
 
@@ -936,6 +1026,7 @@ extern "C" int dn_postprocess(const float* logits, const float* reg, const float
     a.score_thresh = score_thresh; a.nms_thresh = nms_thresh; a.topk = topk; a.dets = dets;
     a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = kept_anchor;
     a.ws = ws; a.ws_bytes = ws_bytes;
+    a.xq = xcd_images_per_group(n);
     return launch_postprocess(a, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
@@ -949,6 +1040,7 @@ extern "C" int dn_pointwise_conv(const void* x, const void* w, const void* w_fra
     a.residual = reinterpret_cast<const half_t*>(residual); a.se = se; a.out = out;
     a.m = m; a.cin = cin; a.cout = cout; a.hw = hw; a.act = act; a.out_fp32 = out_fp32;
     a.out_img_stride = out_fp32 ? (long)out_img_stride : 0; a.out_base = 0;
+    a.xq = (hw > 0 && m % hw == 0) ? xcd_images_per_group(m / hw) : 0;
     int rc = launch_pointwise(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     DN_HIP_CHECK(hipGetLastError());
@@ -967,6 +1059,7 @@ extern "C" int dn_expand_depthwise(const void* x, const void* w1, const float* b
     a.n = n; a.H = h; a.W = w; a.k = k; a.stride = stride; a.pad = (k - 1) / 2;
     a.Ho = (h + 2 * a.pad - k) / stride + 1; a.Wo = (w + 2 * a.pad - k) / stride + 1;
     a.cin = cin; a.cexp = cexp; a.cout = w3 ? cout : cexp; a.act1 = act1; a.act2 = act2; a.has_res = has_res;
+    a.xq = xcd_images_per_group(n);
     int rc = launch_expdw(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     DN_HIP_CHECK(hipGetLastError());
@@ -987,6 +1080,7 @@ extern "C" int dn_dense_conv(const void* x, const void* w, const float* bias, co
     a.wo = (wd + 2 * pad - dil * (k - 1) - 1) / stride + 1;
     DN_REQUIRE(a.ho > 0 && a.wo > 0, "dn_dense_conv: empty output");
     a.out_fp32 = 0; a.out_img_stride = 0; a.out_base = 0;
+    a.xq = xcd_images_per_group(n);
     int rc = launch_conv(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     DN_HIP_CHECK(hipGetLastError());
@@ -1002,6 +1096,7 @@ extern "C" int dn_depthwise_conv(const void* x, const void* w, const float* bias
     a.n = n; a.h = h; a.w_ = wd; a.c = c; a.k = k; a.stride = stride; a.pad = pad; a.act = act;
     a.ho = (h + 2 * pad - k) / stride + 1;
     a.wo = (wd + 2 * pad - k) / stride + 1;
+    a.xq = xcd_images_per_group(n);
     int rc = launch_depthwise(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
     DN_HIP_CHECK(hipGetLastError());

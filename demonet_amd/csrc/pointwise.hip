@@ -19,7 +19,10 @@ static int g_pw_tile = 0;                   // dev hook (tools/tune_pw.py): forc
 extern "C" __attribute__((visibility("default"))) void dn_debug_pw_tile(int t) { g_pw_tile = t; }
 static long long* g_pw_stamps = nullptr;     // dev hook (tools/probe_pw_stamps.py): per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_pw_stamps(void* dev_ptr) { g_pw_stamps = (long long*)dev_ptr; }
-#define PW_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)by * gridDim.x + bx) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define PW_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+
+// row tiles of BP pixels: per XCD group of a.xq images when the grouping is on, else of the whole problem
+static inline int pw_row_tiles(const PwArgs& a, int BP) { return a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, BP) : dn_cdiv(a.m, BP); }
 
 namespace {
 
@@ -27,8 +30,28 @@ namespace {
 // CONV = true: implicit GEMM for a dense kxk convolution (VGG path, SSDHead 3x3 heads; ssd_vgg16.py, generalized_ssd.py:77-92):
 // K runs over (ky, kx, cin) with the weight stored [cout][ky][kx][cin]; each 32-deep K stage lies inside one tap
 // (cin % 32 == 0), so the pixel tile of a stage is the NHWC rows of the tap-shifted input pixels (zeros outside).
+// XCD affinity (common.h, xcd_group_rows): with a.xq > 0 the workgroups of a launch with equal (flat index % 8) -- one XCD --
+// own the rows of one contiguous group of a.xq images, in every kernel of the chain, so that a layer reads what the same XCD's
+// L2 has just written. flat = workgroup index within its problem, tiles = row tiles per group (plain mapping: per problem).
+template <int BP>
+__device__ __forceinline__ bool pw_tile_rows(const PwArgs& a, int flat, int tiles, int& m0, int& mend, int& by) {
+    if (a.xq > 0) {
+        const int g = flat & 7, w = flat >> 3;
+        by = w / tiles;
+        const int t = w - by * tiles;
+        const int r0 = g * a.xq * a.hw;
+        mend = min(a.m, r0 + a.xq * a.hw);
+        m0 = r0 + t * BP;
+        return m0 < mend;
+    }
+    by = flat / tiles;
+    m0 = (flat - by * tiles) * BP;
+    mend = a.m;
+    return true;
+}
+
 template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
-__device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
+__device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, const int by) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
     constexpr int CPR = BK / 8;         // 16-B chunks per row per stage (any multiple of 2: divisions by a constant)
@@ -47,9 +70,8 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
     const int wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC;
     const int r = lane & 31, hh = lane >> 5;
-    const int m0 = bx * BP;
     const int n0 = by * BC;
-    const int M = a.m, K = a.cin, NC = a.cout;
+    const int M = mend, K = a.cin, NC = a.cout;      // rows beyond the group's end belong to another workgroup
     const int dbg = a.act >> 8;            // probe-only knobs: 1 = skip stores, 2 = skip global loads of x
     a.act &= 0xff;
 
@@ -134,6 +156,21 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
 
     const int KT = (K + BK - 1) / BK;
     if (tid < BC) bsh[tid] = (n0 + tid < NC) ? a.bias[n0 + tid] : 0.f;      // visible after the first barrier below
+    // residual rows of the output tile: requested now as row-contiguous 16-B chunks, consumed after the K loop (one exposed
+    // memory round trip less per workgroup than loading them in the epilogue)
+    constexpr int CPRO = BC / 8;                    // 16-B chunks per tile row
+    constexpr int NCH = (BP * CPRO + 255) / 256;
+    uint4 rv[NCH];
+    const bool staged_res = a.residual && !a.out_fp32;
+    if (staged_res) {
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int c = tid + 256 * u;
+            const int row = c / CPRO, ch = c % CPRO;
+            const int m = m0 + row, n = n0 + ch * 8;
+            rv[u] = (row < BP && m < M && n < NC) ? *reinterpret_cast<const uint4*>(a.residual + (size_t)m * NC + n) : make_uint4(0, 0, 0, 0);
+        }
+    }
     auto mfma_stage = [&](int b, int kt) {
         const int ksteps = min(BK / 16, (K - kt * BK + 15) >> 4);
 #pragma unroll
@@ -201,8 +238,52 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
         // row-contiguous 16-byte chunks -> every wave store covers whole 128-B lines; the residual is read the same way.
         constexpr int OROW = BC + 8;
         // (the launcher sizes the dynamic LDS as max(K-loop buffers, output tile))
-        half_t* ot = lds_dyn;
         // (the last K-loop iteration ended with a barrier: nobody reads the staging buffers any more)
+        if (staged_res) {
+            // residual layers stage the tile in fp32: the chunk loop below then adds the residual (requested before the K loop, already
+            // in this chunk layout) in fp32 and rounds ONCE -- act(conv + bias) + x as mobilenetv3.py:97-99 computes it
+            constexpr int FROW = BC + 4;
+            float* otf = reinterpret_cast<float*>(lds_dyn);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int prow = (wp * TP + j) * 32 + r;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                        const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
+                        float4 v;
+                        v.x = dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
+                        v.y = dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
+                        v.z = dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
+                        v.w = dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                        *reinterpret_cast<float4*>(&otf[prow * FROW + cl]) = v;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                const int c = tid + 256 * u;
+                const int row = c / CPRO, ch = c % CPRO;
+                const int m = m0 + row, n = n0 + ch * 8;
+                if (row < BP && m < M && n < NC) {
+                    const float4 lo = *reinterpret_cast<const float4*>(&otf[row * FROW + ch * 8]);
+                    const float4 hi = *reinterpret_cast<const float4*>(&otf[row * FROW + ch * 8 + 4]);
+                    const half8 rr = *reinterpret_cast<const half8*>(&rv[u]);
+                    half8 hv;
+                    hv[0] = (half_t)(lo.x + (float)rr[0]); hv[1] = (half_t)(lo.y + (float)rr[1]);
+                    hv[2] = (half_t)(lo.z + (float)rr[2]); hv[3] = (half_t)(lo.w + (float)rr[3]);
+                    hv[4] = (half_t)(hi.x + (float)rr[4]); hv[5] = (half_t)(hi.y + (float)rr[5]);
+                    hv[6] = (half_t)(hi.z + (float)rr[6]); hv[7] = (half_t)(hi.w + (float)rr[7]);
+                    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(a.out) + (size_t)m * NC + n) = hv;
+                }
+            }
+            PW_STAMP(3);
+            return;
+        }
+        half_t* ot = lds_dyn;
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int prow = (wp * TP + j) * 32 + r;
@@ -222,36 +303,13 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
             }
         }
         __syncthreads();
-        constexpr int CPRO = BC / 8;                    // 16-B chunks per tile row
-        constexpr int NCH = BP * CPRO / 256;
-        uint4 rv[NCH];
-        if (a.residual) {
-#pragma unroll
-            for (int u = 0; u < NCH; ++u) {
-                const int c = tid + 256 * u;
-                const int row = c / CPRO, ch = c % CPRO;
-                const int m = m0 + row, n = n0 + ch * 8;
-                rv[u] = (m < M && n < NC) ? *reinterpret_cast<const uint4*>(a.residual + (size_t)m * NC + n) : make_uint4(0, 0, 0, 0);
-            }
-        }
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int c = tid + 256 * u;
             const int row = c / CPRO, ch = c % CPRO;
             const int m = m0 + row, n = n0 + ch * 8;
-            if (m < M && n < NC) {
-                uint4 v = *reinterpret_cast<const uint4*>(&ot[row * OROW + ch * 8]);
-                if (a.residual) {
-                    half8 hv = *reinterpret_cast<half8*>(&v);
-                    const half8 rr = *reinterpret_cast<const half8*>(&rv[u]);
-                    // the reference adds the residual in fp32 after BN; here the conv result was rounded to fp16 once
-                    // before the add (LDS staging) -- one extra half-ulp, inside the stated tolerance
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) hv[e] = (half_t)((float)hv[e] + (float)rr[e]);
-                    v = *reinterpret_cast<uint4*>(&hv);
-                }
-                *reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(a.out) + (size_t)m * NC + n) = v;
-            }
+            if (row < BP && m < M && n < NC)
+                *reinterpret_cast<uint4*>(reinterpret_cast<half_t*>(a.out) + (size_t)m * NC + n) = *reinterpret_cast<const uint4*>(&ot[row * OROW + ch * 8]);
         }
         PW_STAMP(3);
         return;
@@ -370,8 +428,10 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int bx, const int by) {
 }
 
 template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
-__global__ __launch_bounds__(256) void pw_kernel(PwArgs a) {
-    pw_body<BP, BC, WP, WC, CONV, BK, PF>(a, blockIdx.x, blockIdx.y);
+__global__ __launch_bounds__(256) void pw_kernel(PwArgs a, int tiles) {
+    int m0, mend, by;
+    if (!pw_tile_rows<BP>(a, blockIdx.x, tiles, m0, mend, by)) return;
+    pw_body<BP, BC, WP, WC, CONV, BK, PF>(a, m0, mend, by);
 }
 
 // Grouped launch: up to 12 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
@@ -390,9 +450,9 @@ __global__ __launch_bounds__(256) void pw_group_kernel(PwGroup g) {
 #pragma unroll
     for (int i = 1; i < 12; ++i)
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
-    const int local = blockIdx.x - g.start[p];
-    const int gx = g.gx[p];
-    pw_body<BP, BC, WP, WC, CONV, BK, PF>(g.a[p], local % gx, local / gx);
+    int m0, mend, by;       // (start[] are multiples of 8 when the XCD grouping is on: local % 8 == blockIdx.x % 8)
+    if (!pw_tile_rows<BP>(g.a[p], blockIdx.x - g.start[p], g.gx[p], m0, mend, by)) return;
+    pw_body<BP, BC, WP, WC, CONV, BK, PF>(g.a[p], m0, mend, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -404,16 +464,17 @@ __global__ __launch_bounds__(256) void pw_group_kernel(PwGroup g) {
 // loads fly under the current chunk's MFMAs. No barrier after the staging one.
 // ---------------------------------------------------------------------------------------------------------------
 template <int BP>
-__global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a) {
+__global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a, int tiles) {
     constexpr int TP = BP / 32;
     constexpr int KC = 8;                       // k-steps (of 16) per weight chunk
     extern __shared__ __attribute__((aligned(16))) half_t xs[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int M = a.m, K = a.cin, NC = a.cout;
+    const int K = a.cin, NC = a.cout;
     const int KS = (K + 15) >> 4;
     const int KP = KS * 16 + 8;                 // row stride (halfs): odd number of 16-B slots -> conflict-free b128 reads
-    const int m0 = blockIdx.x * BP;
+    int m0, M, by_unused;                       // this workgroup's rows [m0, min(m0 + BP, M)) (XCD grouping: pw_tile_rows)
+    if (!pw_tile_rows<BP>(a, blockIdx.x, tiles, m0, M, by_unused)) return;
 
     // ---- stage the pixel strip (zero-filled beyond M / K), 8 independent 16-B loads per thread per batch
     const int CPR = KS * 2;                     // 16-B chunks per row (incl. zero padding up to KS*16)
@@ -579,32 +640,24 @@ template <int BP>
 int launch_xs(const PwArgs& a, hipStream_t s) {
     const int KS = (a.cin + 15) / 16;
     const size_t lds = (size_t)BP * (KS * 16 + 8) * sizeof(half_t);
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_xs_kernel<BP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-        attr = true;
-    }
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_xs_kernel<BP>)));
     dn_note_kernel("pw_xs_kernel<%d>", BP);
-    hipLaunchKernelGGL((pw_xs_kernel<BP>), dim3(dn_cdiv(a.m, BP)), dim3(256), lds, s, a);
+    const int tiles = pw_row_tiles(a, BP);
+    hipLaunchKernelGGL((pw_xs_kernel<BP>), dim3(a.xq > 0 ? 8 * tiles : tiles), dim3(256), lds, s, a, tiles);
     return DN_OK;
 }
 
 template <int BP, int BC, int WP, int WC, bool CONV, int BK, int PF = 1>
 int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
-    dim3 grid(dn_cdiv(a.m, BP), dn_cdiv(a.cout, BC));
+    const int tiles = pw_row_tiles(a, BP);
+    dim3 grid((a.xq > 0 ? 8 * tiles : tiles) * dn_cdiv(a.cout, BC));
     size_t halfs = (size_t)nbuf * (BP + BC) * (BK + 8);
-    const size_t otile = a.out_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);     // epilogue staging tile, in halfs
+    const size_t otile = (a.out_fp32 || a.residual) ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);     // epilogue staging tile, in halfs (fp32 for head rows and for residual layers)
     if (otile > halfs) halfs = otile;
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK, PF>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK, PF>)));
     dn_note_kernel(PF > 1 ? "pw_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK, PF);
-    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK, PF>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK, PF>), grid, dim3(256), lds, s, a, tiles);
     return DN_OK;
 }
 
@@ -616,7 +669,7 @@ int launch_cfg(const PwArgs& a, hipStream_t s) {
     if constexpr (CONV && BP == 128 && BC == 128) {
         // MFMA-bound dense convolutions (VGG): 64-deep stages halve the barriers per MFMA; the tile is register-limited to two
         // workgroups per CU either way, and 2 x 74 KB of LDS fit
-        static const int bk64 = getenv("DN_CONV_BK64") ? atoi(getenv("DN_CONV_BK64")) : 1;
+        const int bk64 = dn_knob("DN_CONV_BK64", 1);
         if (bk64 && a.cv_cin % 64 == 0) return launch_bk<BP, BC, WP, WC, CONV, 64>(a, s, 2);
     }
     return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 2);
@@ -645,7 +698,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         // of the model shows the small tiles (most workgroups, fewest registers: 64 VGPRs -> 8 waves/SIMD) winning or tying
         // everywhere, 128x32 when there is a single channel tile. The big tiles only pay off for MFMA-bound shapes.
         if (a.cin < 256 || a.cout < 128) {
-            static const int shortk = getenv("DN_PW_SHORTK") ? atoi(getenv("DN_PW_SHORTK")) : 1;
+            const int shortk = dn_knob("DN_PW_SHORTK", 1);
             if (shortk && a.cin > 32 && a.cin <= 128) {       // 2..4 K stages: all loads up front
                 const_cast<PwArgs&>(a).stamps = g_pw_stamps;
                 if (a.cout <= 32) return launch_bk<128, 32, 4, 1, CONV, 32, 4>(a, s, 2);
@@ -661,8 +714,8 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         }
     }
     if constexpr (CONV) {
-        static const int big = getenv("DN_CONV_BIG") ? atoi(getenv("DN_CONV_BIG")) : 1;
-        static const int bigmin = getenv("DN_CONV_BIG_MIN") ? atoi(getenv("DN_CONV_BIG_MIN")) : 40;       // measured on both VGG models: 40 < 90 < 200; the sub-batch chains fill the chip together
+        const int big = dn_knob("DN_CONV_BIG", 1);
+        const int bigmin = dn_knob("DN_CONV_BIG_MIN", 40);       // measured on both VGG models: 40 < 90 < 200; the sub-batch chains fill the chip together
         if (big && conv_big_supported(a) && wgs(256, 256) >= bigmin) return launch_conv_big(a, s);
     }
     if (a.cout <= 32) {
@@ -673,7 +726,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         if (wgs(128, 64) >= 1500) return launch_cfg<128, 64, 4, 1, CONV>(a, s);
         return launch_cfg<64, 64, 2, 2, CONV>(a, s);
     }
-    static const int t128 = getenv("DN_CONV_T128") ? atoi(getenv("DN_CONV_T128")) : 300;      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
+    const int t128 = dn_knob("DN_CONV_T128", 300);      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
     if (wgs(128, 128) >= (CONV ? t128 : 1500)) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
     if (wgs(128, 64) >= 1500 || a.cout % 128 > 64 || a.cout % 128 == 0) {
         if (wgs(64, 128) >= 600) return launch_cfg<64, 128, 2, 2, CONV>(a, s);
@@ -690,26 +743,24 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     PwGroup g{};
     g.count = count;
     int acc = 0;
+    bool all_xq = true;         // XCD grouping needs every problem's first workgroup at a multiple of 8: all problems or none
+    for (int i = 0; i < count; ++i) all_xq &= arr[i].xq > 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
+        if (!all_xq) g.a[i].xq = 0;
         g.a[i].stamps = nullptr;
         g.start[i] = acc;
-        g.gx[i] = dn_cdiv(arr[i].m, BP);
-        acc += g.gx[i] * dn_cdiv(arr[i].cout, BC);
+        g.gx[i] = pw_row_tiles(g.a[i], BP);
+        acc += (g.a[i].xq > 0 ? 8 * g.gx[i] : g.gx[i]) * dn_cdiv(arr[i].cout, BC);
     }
     g.start[count] = acc;
     size_t halfs = (size_t)2 * (BP + BC) * (BK + 8);
     bool any_fp32 = false;
-    for (int i = 0; i < count; ++i) any_fp32 |= arr[i].out_fp32 != 0;
+    for (int i = 0; i < count; ++i) any_fp32 |= arr[i].out_fp32 != 0 || arr[i].residual != nullptr;
     const size_t otile = any_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);
     if (otile > halfs) halfs = otile;
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>)));
     dn_note_kernel(GPF > 1 ? "pw_group_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_group_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK, GPF);
     hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>), dim3(acc), dim3(256), lds, s, g);
     return DN_OK;
@@ -727,7 +778,7 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         if (arr[i].cout > maxc) maxc = arr[i].cout;
         wg128 += (long)dn_cdiv(arr[i].m, 128) * dn_cdiv(arr[i].cout, 128);
     }
-    static const int gt = getenv("DN_PW_GROUP_TILE") ? atoi(getenv("DN_PW_GROUP_TILE")) : 0;   // dev knob
+    const int gt = dn_knob("DN_PW_GROUP_TILE", 0);   // dev knob
     if (!conv && maxc > 64 && gt == 4) return launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
     if (!conv && maxc > 64 && gt == 5) return launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
     if (!conv && maxc > 64 && gt == 6) return launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
@@ -736,7 +787,7 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
     if (wg128 >= 1500 && conv) {
         // MFMA-bound dense-conv heads: 64-deep stages as in launch_cfg (half the barriers per MFMA)
-        static const int bk64 = getenv("DN_CONV_GROUP_BK64") ? atoi(getenv("DN_CONV_GROUP_BK64")) : 1;
+        const int bk64 = dn_knob("DN_CONV_GROUP_BK64", 1);
         bool all64 = bk64 != 0;
         for (int i = 0; i < count; ++i) all64 &= arr[i].cv_cin % 64 == 0;
         if (all64) return launch_group_cfg<128, 128, 2, 2, true, 64>(arr, count, s);
@@ -749,7 +800,7 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.cin % 8 == 0, "pointwise: cin=%d must be a multiple of 8", a.cin);
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
-    static const int xs_mode = getenv("DN_PW_XS") ? atoi(getenv("DN_PW_XS")) : 1;
+    const int xs_mode = dn_knob("DN_PW_XS", 1);
     if (g_pw_tile == 8 && a.wfrag) return launch_xs<32>(a, s);
     if (xs_mode && !g_pw_tile && a.wfrag && a.cin % 16 == 0 && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&      // (K % 16 == 8: measured slower than the tiled kernel)
         ((a.cin >= 64 && a.m <= 8192) || (a.cin >= 160 && a.m <= 16384))) {
@@ -769,6 +820,7 @@ PwArgs conv_to_pw(const ConvArgs& c) {
     a.m = c.n * a.hw;
     a.cin = c.k * c.k * c.cin;
     a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
+    a.xq = c.xq;
     return a;
 }
 
@@ -783,6 +835,7 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     a.m = c.n * a.hw;
     a.cin = c.k * c.k * c.cin;
     a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
+    a.xq = c.xq;
     DN_REQUIRE(a.m > 0, "conv: empty problem");
     return launch_select<true>(a, s);
 }

@@ -26,7 +26,7 @@ extern "C" __attribute__((visibility("default"))) void dn_debug_pp_stamps(void* 
 
 namespace {
 
-#define PP_STAMP(k) do { if (stamps && tid == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define PP_STAMP(k) do { if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
 constexpr int HSHIFT = 19;                               // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
@@ -39,15 +39,16 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
                                                             const float* __restrict__ anchors, float* __restrict__ scoresT,
                                                             float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
                                                             float score_thr, unsigned* __restrict__ phist, int hb0, int nb,
-                                                            long long* __restrict__ stamps) {
+                                                            long long* __restrict__ stamps, int nimg, int tiles, int xq) {
     extern __shared__ float tile[];            // [64][K] then rowsum[64] then hist[HBINS]
     float* rowsum = tile + 64 * K;
     unsigned* lhist = reinterpret_cast<unsigned*>(rowsum + 64);
     // only bins [hb0, hb0 + nb) can be hit: scores lie in (score_thr, 1] (161 bins for score_thr = 0.001; nb <= HBINS)
     if (threadIdx.x < nb) lhist[threadIdx.x] = 0u;
     const int tid = threadIdx.x;
-    const int n = blockIdx.y;
-    const int a0 = blockIdx.x * 64;
+    int n, atile;                              // flat grid [image slot][anchor tile] (XCD grouping: common.h)
+    if (!xcd_image_of(blockIdx.x, tiles, xq, nimg, n, atile)) return;
+    const int a0 = atile * 64;
     PP_STAMP(8);
     const int na = min(64, A - a0);
     const float* src = logits + ((size_t)n * A + a0) * K;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     PP_STAMP(11);
     // this workgroup's histogram goes to its own row; tau_kernel adds the rows. (Device-scope atomics into one per-image table
     // made a few workgroups per launch wait 15-25 us on the hot bins: the kernel's whole tail.)
-    phist[(((size_t)n * gridDim.x + blockIdx.x) << 8) + threadIdx.x] = (threadIdx.x < nb) ? lhist[threadIdx.x] : 0u;
+    phist[(((size_t)n * tiles + atile) << 8) + threadIdx.x] = (threadIdx.x < nb) ? lhist[threadIdx.x] : 0u;
     if (tid < na) {
         const int a = a0 + tid;
         const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
@@ -357,8 +358,10 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
                                                         int A, int Km1, float score_thr, float nms_thr, int topk,
                                                         float* __restrict__ keptScore, int* __restrict__ keptAnchor,
                                                         int* __restrict__ keptCount, const int* __restrict__ needFull,
-                                                        long long* stamps) {
-    if (needFull && !needFull[blockIdx.y]) return;      // the fast path already produced this image's result
+                                                        long long* stamps, int nimg, int xq) {
+    int n, cls;                          // flat grid [image slot][class]; cls 0..Km1-1 (label = cls + 1)
+    if (!xcd_image_of(blockIdx.x, Km1, xq, nimg, n, cls)) return;
+    if (needFull && !needFull[n]) return;      // the fast path already produced this image's result
     constexpr int MC = 64 * NW;
     constexpr int SORTN = (NW <= 1) ? 64 : (NW <= 2) ? 128 : (NW <= 4) ? 256 : 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -373,8 +376,6 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     unsigned* key = sh + 16;                                                                // [A]
 
     const int tid = threadIdx.x;
-    const int cls = blockIdx.x;          // 0..Km1-1  (label = cls + 1)
-    const int n = blockIdx.y;
     const float* col = scoresT + ((size_t)n * Km1 + cls) * A;
 
     PP_STAMP(0);
@@ -477,9 +478,11 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
 // with score < tau ranks below them and cannot appear in the output. Otherwise needFull[n] triggers the full path.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ phist, int tiles, int hb0, int clamped, unsigned want,
-                                                 unsigned* __restrict__ tauKey, int* __restrict__ needFull) {
+                                                 unsigned* __restrict__ tauKey, int* __restrict__ needFull, int nimg, int xq) {
     __shared__ unsigned part[256];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int n, unused;
+    if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
     // thread t owns bin t: sum of the per-workgroup rows of softmax_decode_kernel (fixed order, 16 loads in flight)
     const unsigned* h = phist + ((size_t)n * tiles << 8) + tid;
     unsigned s = 0;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
                                                              int A, int Km1, float score_thr, float nms_thr, int topk,
                                                              const unsigned* __restrict__ tauKey, int* __restrict__ needFull,
                                                              float* __restrict__ keptScore, int* __restrict__ keptAnchor,
-                                                             int* __restrict__ keptCount, long long* __restrict__ stamps) {
+                                                             int* __restrict__ keptCount, long long* __restrict__ stamps, int nimg, int xq) {
     constexpr int MC = 64 * NW;
     __shared__ unsigned long long cand[MC];
     __shared__ unsigned long long tmp[MC];
@@ -522,7 +525,8 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
     __shared__ float carea[MC];
     __shared__ unsigned cnt_sh;
     const int tid = threadIdx.x;
-    const int cls = blockIdx.x, n = blockIdx.y;
+    int n, cls;                          // flat grid [image slot][class]
+    if (!xcd_image_of(blockIdx.x, Km1, xq, nimg, n, cls)) return;
     const float* col = scoresT + ((size_t)n * Km1 + cls) * A;
     const unsigned tau = tauKey[n];
     PP_STAMP(0);
@@ -590,18 +594,19 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
                                                     float* __restrict__ oboxes, float* __restrict__ oscores,
                                                     long long* __restrict__ olabels, int* __restrict__ ocounts,
                                                     int* __restrict__ oanchor, int mode, const unsigned* __restrict__ tauKey,
-                                                    int* __restrict__ needFull, float* __restrict__ opacked) {
+                                                    int* __restrict__ needFull, float* __restrict__ opacked, int nimg, int xq) {
     // mode 0: after the fast per-class pass (may raise needFull); mode 1: after the full pass (only flagged images);
     // mode 2: unconditional (fast path disabled)
-    if (mode == 0 && needFull[blockIdx.x]) return;
-    if (mode == 1 && !needFull[blockIdx.x]) return;
+    int n, unused;
+    if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
+    if (mode == 0 && needFull[n]) return;
+    if (mode == 1 && !needFull[n]) return;
     __shared__ unsigned long long fin[512];
     __shared__ unsigned long long fin2[512];
     __shared__ unsigned hist[256];
     __shared__ unsigned sh[40];
     __shared__ int ccount[256];
     const int tid = threadIdx.x;
-    const int n = blockIdx.x;
     const int F = Km1 * topk;
     const float* ks = keptScore + (size_t)n * F;
     const int* ka = keptAnchor + (size_t)n * F;
@@ -746,14 +751,9 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
         dn_set_error("postprocess: %d anchors need %zu B of LDS (> 160 KiB)", a.A, lds);
         return DN_E_UNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_nms_kernel<NW>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((select_nms_kernel<NW>), dim3(a.K - 1, a.n), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps);
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW>)));
+    hipLaunchKernelGGL((select_nms_kernel<NW>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
+                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq);
     return DN_OK;
 }
 
@@ -762,8 +762,8 @@ int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes,
                    float* keptScore, int* keptAnchor, int* keptCount, hipStream_t s) {
     // 512 threads: the column scan is one batch of loads for A <= 4096, and a heavy class (up to topk candidates) spreads its
     // IoU-mask rows over 8 waves instead of 4 -- the kernel's duration is the lifetime of its heaviest workgroups
-    hipLaunchKernelGGL((select_nms_fast_kernel<NW, 512>), dim3(a.K - 1, a.n), dim3(512), 0, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps);
+    hipLaunchKernelGGL((select_nms_fast_kernel<NW, 512>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(512), 0, s, scoresT, boxes, a.A, a.K - 1,
+                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq);
     return DN_OK;
 }
 
@@ -809,11 +809,11 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     unsigned* tauKey = phist + (size_t)a.n * tiles * HBINS;
     int* needFull = reinterpret_cast<int*>(tauKey + a.n);
 
-    static const int fast = pp_env("DN_PP_FAST", 1);
+    const int fast = dn_knob("DN_PP_FAST", 1);
     // candidates per image kept by the cut-off, as a multiple of D. Any value is exact (too few survivors -> device-side
     // fallback to the full kernel for that image); 4 leaves a 4x margin for NMS suppression and keeps the heaviest per-class
     // workgroups (the kernel's tail) short: 8 -> 4 is -2.5 % on the step, 2 another -2 % but with no margin.
-    static const int want_mult = pp_env("DN_PP_WANT", 4);
+    const int want_mult = dn_knob("DN_PP_WANT", 4);
     long long* labels = reinterpret_cast<long long*>(a.labels);
     const int nw = (a.topk + 63) / 64;
 
@@ -831,19 +831,21 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     const int clamped = hb_thr < hb0;
     const int nb = top + 1 - hb0;
     const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)nb * sizeof(unsigned);
-    hipLaunchKernelGGL(softmax_decode_kernel, dim3(dn_cdiv(a.A, 64), a.n), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr);
+    const int slots = xcd_image_slots(a.xq, a.n);
+    hipLaunchKernelGGL(softmax_decode_kernel, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
+                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,
+                       a.n, tiles, a.xq);
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
     if (fast) {
-        hipLaunchKernelGGL(tau_kernel, dim3(a.n), dim3(256), 0, s, phist, tiles, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull);
+        hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, tiles, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq);
         if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
-        hipLaunchKernelGGL(merge_kernel, dim3(a.n), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed);
+        hipLaunchKernelGGL(merge_kernel, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed, a.n, a.xq);
     }
     const int* flag = fast ? needFull : nullptr;
     if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
@@ -853,8 +855,8 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
     if (rc != DN_OK) return rc;
     if (ev) (void)hipEventRecord(ev[2], s);
-    hipLaunchKernelGGL(merge_kernel, dim3(a.n), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull, a.packed);
+    hipLaunchKernelGGL(merge_kernel, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull, a.packed, a.n, a.xq);
     if (ev) (void)hipEventRecord(ev[3], s);
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;

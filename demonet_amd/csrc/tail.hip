@@ -24,7 +24,7 @@ constexpr int TT = 512;             // threads per workgroup
 constexpr int NWV = TT / 64;        // waves
 constexpr int PART_SLICES = 8;      // max K slices per output tile
 
-__global__ __launch_bounds__(TT) void tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(TT) void tail_kernel(TailArgs a, int nimg) {
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     half_t* buf[2] = {lds, lds + a.buf_halfs};          // ping (input, odd outputs) / pong (even outputs): sized separately
     float* part = reinterpret_cast<float*>(lds + a.buf_halfs + a.buf2_halfs);
@@ -35,7 +35,9 @@ __global__ __launch_bounds__(TT) void tail_kernel(TailArgs a) {
         reinterpret_cast<int*>(ops_sh)[i] = reinterpret_cast<const int*>(a.op)[i];       // [NWV][1024] fp32 partial tiles of the K slices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int n = blockIdx.x;
+    // XCD grouping (common.h): workgroup b serves image (b % 8) * xq + b / 8 -- the XCD that produced this image's input
+    const int n = a.xq > 0 ? (int)(blockIdx.x & 7) * a.xq + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (n >= nimg) return;
     TL_STAMP(0);
 
     // stage the first op's input [pixels][cin] (NHWC fp16, contiguous per image)
@@ -242,13 +244,9 @@ int launch_tail(const TailArgs& a0, int n, hipStream_t s) {
     a.buf2_halfs = (int)((pong + 7) & ~(size_t)7);
     const size_t lds = ((size_t)a.buf_halfs + a.buf2_halfs) * sizeof(half_t) + (size_t)NWV * 1024 * sizeof(float);
     DN_REQUIRE(lds <= 156 * 1024, "tail: activations need %zu B of LDS", lds);
-    static bool attr = false;
-    if (!attr) {
-        DN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr = true;
-    }
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(tail_kernel), 156 * 1024));     // + the static op table
     a.stamps = g_tail_stamps;
     dn_note_kernel("tail_kernel");
-    hipLaunchKernelGGL(tail_kernel, dim3(n), dim3(TT), lds, s, a);
+    hipLaunchKernelGGL(tail_kernel, dim3(a.xq > 0 ? 8 * a.xq : n), dim3(TT), lds, s, a, n);
     return DN_OK;
 }

@@ -44,6 +44,12 @@ PW_CASES = [
     (19200, 480, 112, 400, 0, False, True, False),    # SE scale, 48 images
     (200000, 24, 72, 200000, 1, False, False, False), # big-M tiled kernel
     (150000, 72, 24, 150000, 0, True, False, False),
+    # XCD-grouped mapping (>= 8 images: workgroups with equal index % 8 own one contiguous group of images)
+    (3600, 672, 546, 400, 0, False, False, True),     # 9 images (groups of 2, last groups empty / half), fp32 head rows
+    (1300, 80, 200, 100, 3, False, False, False),     # 13 images of 100 pixels: tiles end inside a group, ragged last group
+    (1100, 480, 80, 100, 0, True, True, False),       # strip kernel, 11 images, SE scale + residual
+    (17 * 25, 512, 128, 25, 2, False, False, False),  # 17 images of 25 pixels
+    (8 * 6400, 24, 72, 6400, 1, False, False, False), # one image per XCD group
 ]
 
 
@@ -101,6 +107,9 @@ DW_CASES = [
     (4, 1, 1, 128, 3, 1, 2),
     (1, 20, 20, 672, 3, 1, 3),
     (1, 20, 20, 672, 5, 2, 3),
+    (9, 10, 10, 120, 5, 1, 1),        # XCD-grouped mapping: 9 images (groups of 2)
+    (16, 21, 19, 64, 3, 2, 1),
+    (13, 3, 3, 128, 3, 2, 2),
 ]
 
 
@@ -187,6 +196,9 @@ EXPDW_CASES = [
     (2, 36, 44, 16, 64, 24, 3, 2, True, True, False, False, 1, 1),      # b2-like: expand -> dw s2 -> project, ragged tiles
     (1, 40, 40, 24, 72, 24, 3, 1, True, True, False, True, 1, 1),       # b3-like: full block with residual, two chunks (64 + 8)
     (2, 38, 38, 32, 96, 40, 3, 1, True, True, False, False, 2, 2),      # V2-like: 2 output channel tiles
+    (9, 20, 20, 40, 120, 0, 5, 1, True, False, True, False, 1, 1),      # XCD-grouped mapping (9 images): pooled sums per image
+    (12, 36, 44, 16, 64, 24, 3, 2, True, True, False, False, 1, 1),     # grouped, full block
+    (8, 20, 20, 80, 200, 0, 3, 1, True, False, False, False, 3, 3),     # grouped, chunks split over workgroups
 ]
 
 

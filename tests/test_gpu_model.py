@@ -54,7 +54,15 @@ def _postprocess(lib_mod, logits, reg, anchors, hw, st, nt, topk, dets):
     return boxes.cpu().numpy(), scores.cpu().numpy(), labels.cpu().numpy(), counts.cpu().numpy(), kept.cpu().numpy()
 
 
-def test_postprocess_on_golden_logits_is_index_exact(golden_dir):
+@pytest.fixture(params=["1", "0"], ids=["cutoff-fast-path", "full-path"])
+def pp_fast(request, monkeypatch):
+    """DN_PP_FAST: 1 = histogram cut-off + fast per-class kernel with device-side fallback (default), 0 = the full per-class
+    kernel for every image. The knob is read per call (csrc/common.h dn_knob), so both run in one process."""
+    monkeypatch.setenv("DN_PP_FAST", request.param)
+    return request.param
+
+
+def test_postprocess_on_golden_logits_is_index_exact(golden_dir, pp_fast):
     """Isolation test: the reference's own logits/regression in -> kept-box indices bit-exact (fixture is tie-free)."""
     from demonet_amd import _lib
     z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
@@ -78,8 +86,9 @@ def test_postprocess_on_golden_logits_is_index_exact(golden_dir):
     (1, 70, 3, 300, 300, 0.0),        # fewer anchors than topk
     (2, 200, 5, 64, 512, 0.01),       # dets at the cap
     (1, 128, 4, 100, 50, 0.9999),     # nothing passes the threshold -> empty output
+    (11, 640, 6, 80, 40, 0.03),       # 11 images: the XCD-grouped mapping of the post-process launches
 ])
-def test_postprocess_random_vs_oracle(n, A, K, topk, dets, st):
+def test_postprocess_random_vs_oracle(n, A, K, topk, dets, st, pp_fast):
     """Same scores/boxes semantics as the oracle on random inputs, including exact score ties (duplicated rows):
     the canonical tie-break (score desc, class asc, anchor asc) must make the index lists identical."""
     from demonet_amd import _lib
@@ -200,6 +209,28 @@ def test_list_api_batching_and_resize():
     iou = so.box_iou_np(od[1]["boxes"], bb)
     same = od[1]["labels"][:, None] == out[1]["labels"].cpu().numpy()[None, :]
     assert ((iou > 0.9) & same).any(1).mean() > 0.8
+
+
+@pytest.mark.parametrize("n", [8, 13, 37])
+def test_xcd_grouping_is_placement_only(n):
+    """Every kernel maps its workgroups to images so that the workgroups with equal (index % 8) -- one XCD on MI355X -- own one
+    contiguous group of images (common.h). That is a speed matter only: the outputs must be bit-identical to the plain mapping
+    (DN_XCD=0), for batch sizes that are / are not multiples of 8 and with the sub-batch branches (n >= 32)."""
+    imgs = torch.from_numpy(synth.images(21, n, 320, 320)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["DN_XCD"] = flag
+        try:
+            m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+            heads = [t.clone() for t in m.forward_heads(imgs)]
+            dets = [t.clone() for t in m.forward_batch(imgs, persistent_input=True)]
+            torch.cuda.synchronize()
+            res[flag] = heads + dets
+        finally:
+            del os.environ["DN_XCD"]
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+    assert int(res["1"][5].sum()) > 0
 
 
 def test_graph_replay_equals_eager():
