@@ -68,6 +68,11 @@ struct Layout {
     std::vector<size_t> toff;       // per tensor byte offset in workspace (SIZE_MAX: not materialised)
     std::vector<size_t> tbytes;
     size_t resized_off = 0, logits_off = 0, reg_off = 0, scale_off = 0, post_off = 0, post_bytes = 0, total = 0;
+    // liveness reuse: every sub-batch chain owns one arena of `arena` bytes (chains run concurrently at different points of the
+    // op list, so blocks that different tensors share must not be shared between chains); toff / tbytes then describe chain 0
+    // (chain_n images), chain k adds k * arena. arena == 0: one contiguous [n]-image block per tensor.
+    size_t arena = 0;
+    int chain_n = 0;
 };
 
 struct GraphKey {
@@ -102,6 +107,7 @@ struct dn_plan {
     std::vector<int> op_feat_level;         // main op producing a feature map: its level, else -1
     bool multi_stream = false;
     int split = 2;                          // sub-batch branches per forward (see batch_split)
+    bool ws_reuse = true;                   // DN_WS_REUSE=0: one private block per tensor (every intermediate stays readable after the forward)
     bool chain_graphs = false;              // DN_CHAIN_GRAPHS=1: one single-chain graph per sub-batch on its own stream (default: branches of ONE graph)
     bool xcd = true;                        // XCD grouping of every kernel's workgroups by image (common.h; DN_XCD, read in dn_create)
     hipStream_t branch_stream[3] = {nullptr, nullptr, nullptr};
@@ -146,16 +152,95 @@ static const Layout& get_layout(dn_plan* p, int n) {
     const size_t T = p->tensors.size();
     L.toff.assign(T, (size_t)-1);
     L.tbytes.assign(T, 0);
+    const int S_chains = batch_split(p, n);
+    const int nn = p->ws_reuse ? sub_count(n, S_chains, 0) : n;      // images per block: one chain's share with reuse, else all
+    L.chain_n = nn;
     for (size_t i = 0; i < T; ++i) {
         const dn_tensor_desc& t = p->tensors[i];
         size_t b = 0;
-        if (t.kind == DN_T_ACT) b = (size_t)n * t.h * t.w * t.c * 2;
-        else if (t.kind == DN_T_VEC) b = (size_t)n * t.c * 4;
-        else if (t.kind == DN_T_POOL) b = (size_t)n * p->pool_blocks[i] * t.c * 4;
+        if (t.kind == DN_T_ACT) b = (size_t)nn * t.h * t.w * t.c * 2;
+        else if (t.kind == DN_T_VEC) b = (size_t)nn * t.c * 4;
+        else if (t.kind == DN_T_POOL) b = (size_t)nn * p->pool_blocks[i] * t.c * 4;
         else continue;      // image: caller's buffer (or the resized copy below)
-        L.toff[i] = off;
         L.tbytes[i] = b;
-        off += align256(b);
+    }
+    if (!p->ws_reuse) {
+        for (size_t i = 0; i < T; ++i)
+            if (L.tbytes[i]) { L.toff[i] = off; off += align256(L.tbytes[i]); }
+    } else {
+        // Liveness reuse: a tensor occupies its block from the launch that writes it to the last launch that reads it (launch
+        // time = op index, with the ops of one fused / grouped launch sharing a time step); blocks are placed first-fit at the
+        // lowest offset that is free over the whole interval. Tensors that only exist inside a fused launch get no block. The
+        // pyramid features live until the head launches. Every block still holds all n images, so the sub-batch chains keep
+        // addressing disjoint rows of the same blocks. 2.6 GB -> ~0.4 GB at batch 64: producer -> consumer pairs of the large maps
+        // now rewrite lines that are already resident in the Infinity Cache instead of streaming through fresh memory.
+        const int NO = (int)p->ops.size();
+        std::vector<int> when(NO);                 // launch time step of every op
+        std::vector<char> inner(T, 0);             // tensor produced AND consumed inside one fused launch (never materialised)
+        {
+            int tstep = 0;
+            for (int i = 0; i < NO;) {
+                int len = 1;
+                if (p->head_first >= 0 && i >= p->head_first) {
+                    // head launches: the depthwise group, then the 1x1 / dense group(s)
+                    for (int q = i; q < NO; ++q) when[q] = tstep + (p->ops[q].type == DN_OP_DW ? 0 : 1);
+                    break;
+                }
+                if (i == p->tail_first) len = p->tail_end - p->tail_first;
+                else if (p->fused_len[i] > 0) len = p->fused_len[i];
+                for (int q = 0; q < len; ++q) when[i + q] = tstep;
+                if (len > 1) {
+                    for (int q = 0; q + 1 < len; ++q) {
+                        const int tid = p->ops[i + q].out;
+                        bool keep = false;
+                        if (i == p->tail_first) keep = p->tail_materialise[q] != 0;
+                        for (int l = 0; l < p->d.n_levels; ++l) keep |= p->d.level_tensor[l] == tid;
+                        for (int u = 0; u < NO; ++u) {
+                            if (u >= i && u < i + len) continue;
+                            const dn_op_desc& o = p->ops[u];
+                            keep |= (o.in == tid || o.residual == tid || o.se == tid);
+                        }
+                        if (!keep) inner[tid] = 1;
+                    }
+                }
+                ++tstep;
+                i += len;
+            }
+        }
+        std::vector<int> born(T, -1), dies(T, -1);
+        for (int i = 0; i < NO; ++i) {
+            const dn_op_desc& o = p->ops[i];
+            auto use = [&](int tid) { if (tid >= 0) dies[tid] = std::max(dies[tid], when[i]); };
+            use(o.in); use(o.residual); use(o.se);
+            if (born[o.out] < 0) born[o.out] = when[i];
+            dies[o.out] = std::max(dies[o.out], when[i]);
+            if (o.pool >= 0) { if (born[o.pool] < 0) born[o.pool] = when[i]; dies[o.pool] = std::max(dies[o.pool], when[i]); }
+        }
+        const int t_end = NO + 2;
+        for (int l = 0; l < p->d.n_levels; ++l) dies[p->d.level_tensor[l]] = t_end;      // read back by tests / callers after the forward
+        struct Blk { size_t off, bytes; int born, dies; };
+        std::vector<Blk> placed;
+        std::vector<size_t> order;
+        for (size_t i = 0; i < T; ++i)
+            if (L.tbytes[i] && !inner[i] && born[i] >= 0) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return born[a] < born[b]; });
+        for (size_t i : order) {
+            const size_t need = align256(L.tbytes[i]);
+            std::vector<std::pair<size_t, size_t>> busy;       // blocks alive at some point of [born, dies]
+            for (const Blk& b : placed)
+                if (!(b.dies < born[i] || b.born > dies[i])) busy.push_back({b.off, b.off + b.bytes});
+            std::sort(busy.begin(), busy.end());
+            size_t at = 0;
+            for (const auto& iv : busy) {
+                if (iv.first >= at + need) break;
+                at = std::max(at, iv.second);
+            }
+            L.toff[i] = at;
+            placed.push_back({at, need, born[i], dies[i]});
+            off = std::max(off, at + need);
+        }
+        L.arena = align256(off);
+        off = L.arena * (size_t)S_chains;
     }
     L.resized_off = off;
     off += align256((size_t)n * 3 * p->d.image_h * p->d.image_w * 4);
@@ -344,6 +429,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
     p->xcd = getenv("DN_XCD") ? atoi(getenv("DN_XCD")) != 0 : true;
     p->chain_graphs = dn_knob("DN_CHAIN_GRAPHS", 0) != 0;
+    p->ws_reuse = dn_knob("DN_WS_REUSE", 1) != 0 && !p->multi_stream;      // (head chains on side streams overlap the backbone: no reuse)
     p->split = getenv("DN_SPLIT") ? atoi(getenv("DN_SPLIT")) : 2;
     if (p->split < 1) p->split = 1;
     if (p->split > 4) p->split = 4;
@@ -429,8 +515,8 @@ static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
     V.tbytes = L.tbytes;
     for (size_t t = 0; t < L.toff.size(); ++t) {
         if (L.toff[t] == (size_t)-1) continue;
-        const size_t per = L.tbytes[t] / (size_t)n;
-        V.toff[t] = L.toff[t] + (size_t)n0 * per;
+        const size_t per = L.tbytes[t] / (size_t)L.chain_n;
+        V.toff[t] = L.arena ? L.toff[t] + (size_t)k * L.arena : L.toff[t] + (size_t)n0 * per;
         V.tbytes[t] = (size_t)ns * per;
     }
     V.resized_off = L.resized_off + (size_t)n0 * 3 * p->d.image_h * p->d.image_w * 4;
@@ -966,6 +1052,8 @@ extern "C" int dn_tensor_ptr(const dn_plan* p, void* workspace, int n, int tenso
     DN_REQUIRE(tensor_id >= 0 && tensor_id < (int)p->tensors.size(), "dn_tensor_ptr: tensor id %d out of range", tensor_id);
     const Layout& L = get_layout(const_cast<dn_plan*>(p), n);
     DN_REQUIRE(L.toff[tensor_id] != (size_t)-1, "dn_tensor_ptr: tensor %d is not materialised in the workspace", tensor_id);
+    DN_REQUIRE(L.chain_n == n, "dn_tensor_ptr: with workspace reuse the rows of a tensor are not contiguous across the sub-batch chains of a "
+               "%d-image forward (DN_WS_REUSE=0 keeps one block per tensor)", n);
     *ptr = reinterpret_cast<unsigned char*>(workspace) + L.toff[tensor_id];
     if (bytes) *bytes = L.tbytes[tensor_id];
     return DN_OK;

@@ -84,3 +84,35 @@ def voc_class_pr(det_image_ids: Sequence, det_scores: np.ndarray, det_boxes: np.
     rec = tp / float(npos) if npos > 0 else np.zeros_like(tp)
     prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
     return rec, prec
+
+
+def voc_mean_ap(detections: Sequence[Dict[str, np.ndarray]], ground_truth: Sequence[Dict[str, np.ndarray]], ovthresh: float = 0.5,
+                use_07_metric: bool = False) -> Tuple[float, Dict[int, float]]:
+    """mAP over an image set as the reference's VOC evaluation reports it (data/voc_eval.py:186-214 `do_python_eval`: AP per
+    class, then the mean over the classes; here over the classes that occur in the ground truth).
+    detections[i] / ground_truth[i]: dicts of one image with `boxes` [K,4] xyxy, `labels` [K] (+ `scores` [K] for detections,
+    optional `difficult` [K] for ground truth). Returns (mean AP in percent, {class: AP in percent})."""
+    classes = sorted({int(c) for g in ground_truth for c in np.asarray(g["labels"]).reshape(-1)})
+    aps = {}
+    for c in classes:
+        ids, scores, boxes = [], [], []
+        for i, d in enumerate(detections):
+            lab = np.asarray(d["labels"]).reshape(-1)
+            sel = lab == c
+            n = int(sel.sum())
+            if n:
+                ids.extend([i] * n)
+                scores.append(np.asarray(d["scores"], dtype=np.float64).reshape(-1)[sel])
+                boxes.append(np.asarray(d["boxes"], dtype=np.float64).reshape(-1, 4)[sel])
+        gt = {}
+        for i, g in enumerate(ground_truth):
+            lab = np.asarray(g["labels"]).reshape(-1)
+            sel = lab == c
+            diff = np.asarray(g.get("difficult", np.zeros(lab.shape[0], dtype=bool))).reshape(-1).astype(bool)
+            gt[i] = (np.asarray(g["boxes"], dtype=np.float64).reshape(-1, 4)[sel], diff[sel])
+        if ids:
+            rec, prec = voc_class_pr(ids, np.concatenate(scores), np.concatenate(boxes), gt, ovthresh)
+            aps[c] = 100.0 * voc_ap(rec, prec, use_07_metric)
+        else:
+            aps[c] = 0.0
+    return (float(np.mean(list(aps.values()))) if aps else 0.0), aps

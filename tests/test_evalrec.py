@@ -55,3 +55,24 @@ def test_voc_matching_rules():
     np.testing.assert_allclose(rec, [0.0, 0.5, 0.5, 0.5, 1.0])
     np.testing.assert_allclose(prec, [0.0, 0.5, 1 / 3, 1 / 3, 0.5])
     assert abs(evalrec.voc_ap(rec, prec, False) - 0.5) < 1e-12
+
+
+def test_voc_class_pr_matches_reference_voc_eval():
+    """TP/FP marking + precision/recall of evalrec.voc_class_pr against vectors produced by the reference's own voc_eval
+    (data/voc_eval.py:60-165) run on synthetic VOC xml / detection files (tests/golden/make_eval_golden.py): 3 classes, 14 images,
+    duplicates, 'difficult' boxes, images without ground truth, two overlap thresholds."""
+    z = np.load(GOLDEN)
+    nimg = int(z["ve_num_images"])
+    for ci in range(3):
+        gt = {}
+        for k in range(nimg):
+            sel = z[f"ve_gt_img_{ci}"] == k
+            gt[k] = (z[f"ve_gt_box_{ci}"][sel], z[f"ve_gt_diff_{ci}"][sel].astype(bool))
+        ids = z[f"ve_det_img_{ci}"].tolist()
+        for thr, tag in ((0.5, "t50"), (0.3, "t30")):
+            rec, prec = evalrec.voc_class_pr(ids, z[f"ve_det_score_{ci}"], z[f"ve_det_box_{ci}"], gt, thr)
+            np.testing.assert_array_equal(rec, z[f"ve_rec_{ci}_{tag}"])
+            np.testing.assert_array_equal(prec, z[f"ve_prec_{ci}_{tag}"])
+            assert evalrec.voc_ap(rec, prec, False) == float(z[f"ve_ap_{ci}_{tag}"])
+            assert evalrec.voc_ap(rec, prec, True) == float(z[f"ve_ap07_{ci}_{tag}"])
+        assert len(ids) > 10 and float(z[f"ve_rec_{ci}_t50"].max()) > 0

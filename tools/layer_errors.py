@@ -75,6 +75,7 @@ def run(name, out):
     from demonet_amd import models, synth
     os.environ["DN_EXPDW"] = "0"
     os.environ["DN_TAIL"] = "0"
+    os.environ["DN_WS_REUSE"] = "0"         # every intermediate tensor keeps its own block (readable after the forward)
     ncls = 21 if name == "ssd_lite_mobilenet_v2" else 91
     size = None
     if ":" in name:                         # "ssd_lite_mobilenet_v2:300": the hub model at another input size (BASELINE config C3)
