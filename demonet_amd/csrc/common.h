@@ -95,6 +95,7 @@ struct PwArgs {
     const half_t* w_b = nullptr; const float* bias_b = nullptr; void* out_b = nullptr;
     int cout_b = 0; long out_b_img_stride = 0, out_b_base = 0;
     const half_t* wfrag = nullptr;   // optional: the weights in MFMA-fragment order (dn_op_desc::w2_off), used by the strip kernel
+    half_t* pool_out = nullptr;      // conv_patch_kernel only: write the 2x2 / stride-2 max-pooled map [n][h/2][w/2][cout] instead of `out`
     const half_t* x;        // [m][cin]
     const half_t* w;        // [cout][cin]
     const float* bias;      // [cout]
@@ -112,6 +113,10 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
 // 256x256-tile implicit GEMM for the MFMA-bound dense convs (convbig.hip)
 bool conv_big_supported(const PwArgs& a);
 int launch_conv_big(const PwArgs& a, hipStream_t s);
+// 3x3 "same" conv followed by MaxPool2d(2, 2) in one launch (the 16 x 16 output block of the patch kernel pools to 8 x 8 in its
+// epilogue): true where launch_conv_big would take the patch kernel for this geometry at every batch size
+bool conv_patch_pool_ok(int cin, int cout, int h, int w);
+int launch_conv_patch_pool(const PwArgs& a, hipStream_t s);      // a.pool_out set
 bool conv_head_big_supported(const PwArgs& a);
 int launch_conv_head_big(const PwArgs& a, hipStream_t s);
 

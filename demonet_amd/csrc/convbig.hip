@@ -662,6 +662,35 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
             }
     }
     __syncthreads();
+    if (a.pool_out) {
+        // fused MaxPool2d(kernel 2, stride 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the 16 x 16 block pools to 8 x 8,
+        // block origins are multiples of 16 and H, W are even, so every window lies inside one block. The conv output itself
+        // never reaches HBM (it is 4x the pooled map: conv1_2 of ssd512 alone is 537 MB written + read back per 16 images).
+        const int HP = H >> 1, WP = W >> 1;
+        half_t* pout = a.pool_out + (size_t)img * HP * WP * NC;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = tid + 256 * u;                        // 64 pooled pixels x 8 chunks
+            const int pp = c >> 3, ch = c & 7;
+            const int py = pp >> 3, pxx = pp & 7;
+            const int oy = (ty0 >> 1) + py, ox = (tx0 >> 1) + pxx;
+            if (oy < HP && ox < WP) {
+                const int p00 = (2 * py) * PT + 2 * pxx;
+                const half8 v0 = *reinterpret_cast<const half8*>(&ot[p00 * 72 + ch * 8]);
+                const half8 v1 = *reinterpret_cast<const half8*>(&ot[(p00 + 1) * 72 + ch * 8]);
+                const half8 v2 = *reinterpret_cast<const half8*>(&ot[(p00 + PT) * 72 + ch * 8]);
+                const half8 v3 = *reinterpret_cast<const half8*>(&ot[(p00 + PT + 1) * 72 + ch * 8]);
+                half8 mx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const half_t m01 = v0[e] > v1[e] ? v0[e] : v1[e], m23 = v2[e] > v3[e] ? v2[e] : v3[e];
+                    mx[e] = m01 > m23 ? m01 : m23;
+                }
+                *reinterpret_cast<half8*>(pout + ((size_t)oy * WP + ox) * NC + n0 + ch * 8) = mx;
+            }
+        }
+        return;
+    }
     half_t* outp = reinterpret_cast<half_t*>(a.out) + (size_t)img * H * W * NC;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -751,6 +780,23 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
 
 // Dense 3x3 heads with fp32 outputs (SSDHead, generalized_ssd.py:77-92) on the run-staged 256x256 tile; channel tiles beyond cout
 // compute on the last weight row and are not stored.
+bool conv_patch_pool_ok(int cin, int cout, int h, int w) {
+    if (!dn_knob("DN_CONV_BIG", 1) || !dn_knob("DN_CONV_POOL", 1) || (h & 1) || (w & 1)) return false;
+    static const half_t dummy_zero[8] = {};
+    PwArgs a{};
+    a.cv_k = 3; a.cv_stride = 1; a.cv_pad = 1; a.cv_dil = 1; a.cv_h = a.cv_ho = h; a.cv_w = a.cv_wo = w; a.cv_cin = cin;
+    a.zeros = dummy_zero; a.residual = nullptr; a.se = nullptr; a.out_fp32 = 0;
+    a.hw = h * w; a.m = a.hw; a.cin = 9 * cin; a.cout = cout;
+    // the patch kernel is what launch_conv_big picks when the run-staged 512 x 128 tile does not apply; a larger batch can only
+    // take the run-staged tiles away (their 2 GB addressing limit), never the patch kernel
+    return patch_shape(a) && (cin <= 64 || halo_variant(a) == 0 || halo_variant(a) == 3) && (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= dn_knob("DN_CONV_BIG_MIN", 40);
+}
+
+int launch_conv_patch_pool(const PwArgs& a, hipStream_t s) {
+    DN_REQUIRE(a.pool_out && patch_shape(a) && !(a.cv_h & 1) && !(a.cv_w & 1), "conv + max-pool: geometry not supported by the patch kernel");
+    return launch_patch(a, s);
+}
+
 bool conv_head_big_supported(const PwArgs& a) {
     const int on = dn_knob("DN_CONV_HEAD_BIG", 1);
     const int minwg = dn_knob("DN_CONV_HEAD_BIG_MIN", 40);

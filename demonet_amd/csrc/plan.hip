@@ -336,6 +336,29 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             }
         }
     }
+    // ---- dense 3x3 conv -> MaxPool2d(2, 2) pairs (VGG conv1_2 / conv2_2): one launch, fused_kind 4 (convbig.hip conv_patch_kernel)
+    {
+        std::vector<int> uses(desc->n_tensors, 0);
+        for (int i = 0; i < desc->n_ops; ++i) {
+            const dn_op_desc& o = p->ops[i];
+            uses[o.in]++;
+            if (o.residual >= 0) uses[o.residual]++;
+            if (o.se >= 0) uses[o.se]++;
+        }
+        for (int l = 0; l < desc->n_levels; ++l) uses[desc->level_tensor[l]] += 100;
+        for (int i = 0; i + 1 < desc->n_ops; ++i) {
+            const dn_op_desc& c = p->ops[i];
+            const dn_op_desc& m = p->ops[i + 1];
+            const dn_tensor_desc& tc = p->tensors[c.out];
+            if (c.type == DN_OP_CONV && !c.head && c.k == 3 && c.stride == 1 && c.pad == 1 && c.dil == 1 && m.type == DN_OP_MAXPOOL && m.in == c.out &&
+                uses[c.out] == 1 && m.k == 2 && m.stride == 2 && m.pad == 0 && p->fused_len[i] == 0 && p->tensors[c.in].h == tc.h &&
+                conv_patch_pool_ok(c.cin, c.cout, tc.h, tc.w)) {
+                p->fused_len[i] = 2;
+                p->fused_kind[i] = 4;
+                ++i;
+            }
+        }
+    }
     // partial-sum rows of every pooled tensor = workgroups per image of its producing depthwise op
     p->pool_blocks.assign(desc->n_tensors, 0);
     for (int i = 0; i < desc->n_ops; ++i) {
@@ -760,6 +783,17 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             for (int q = 1; q < ta.count; ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             i += ta.count - 1;
+            continue;
+        }
+        if (p->fused_len[i] > 0 && p->fused_kind[i] == 4) {
+            PwArgs pa = conv_to_pw(make_conv(o));
+            pa.out = nullptr;
+            pa.pool_out = reinterpret_cast<half_t*>(tptr(p->ops[i + 1].out));
+            rc = launch_conv_patch_pool(pa, s);
+            if (rc != DN_OK) return rc;
+            note(i, i); note(i + 1, i);
+            if (record) (void)hipEventRecord(p->events[ev++], s);
+            i += 1;
             continue;
         }
         if (p->fused_len[i] > 0) {

@@ -205,7 +205,7 @@ def test_end_to_end_detections_vs_golden(golden_dir):
         np.testing.assert_allclose(np.sort(s)[::-1][:50], z[f"det_scores_{i}"][:50], rtol=3e-2, atol=1e-3)
 
 
-def _synthetic_ground_truth(ref, num_classes, seed=77, min_gap=0.08, lo=4, hi=60):
+def _synthetic_ground_truth(ref, num_classes, seed=77, min_gap=0.03, lo=4, hi=60):
     """Fixed synthetic ground truth for a set of CPU-path detections: per class, the detections above the widest relative score
     gap (>= 8 %) among ranks lo..hi of the class-wide ranking become objects (boxes jittered by up to 8 % of their size, 10 %
     marked difficult), plus one unmatched object per five (a miss for any detector). Random-weight networks produce hundreds of
@@ -231,7 +231,7 @@ def _synthetic_ground_truth(ref, num_classes, seed=77, min_gap=0.08, lo=4, hi=60
         for (score, i, j) in items[:cut]:
             if "softmax" in ref[i]:
                 a = int(ref[i]["anchor_idx"][j])
-                rivals = np.nonzero(ref[i]["softmax"][:, c] >= 0.90 * score)[0]
+                rivals = np.nonzero(ref[i]["softmax"][:, c] >= 0.97 * score)[0]
                 rivals = rivals[rivals != a]
                 if rivals.size and float(so.box_iou_np(ref[i]["decoded"][a:a + 1], ref[i]["decoded"][rivals]).max()) > 0.35:
                     stable = False
@@ -255,7 +255,7 @@ def _synthetic_ground_truth(ref, num_classes, seed=77, min_gap=0.08, lo=4, hi=60
 
 
 def test_map_on_fixed_inputs_within_0p1_of_cpu_path():
-    """north_star: "mAP on fixed inputs within 0.1 of the CPU reference". 128 fixed synthetic images, a fixed synthetic ground truth
+    """north_star: "mAP on fixed inputs within 0.1 of the CPU reference". 256 fixed synthetic images, a fixed synthetic ground truth
     (_synthetic_ground_truth), PASCAL VOC AP per class (evalrec.voc_class_pr / voc_ap, pinned bit for bit to the reference's
     voc_eval: tests/test_evalrec.py) for the HIP detections and for the CPU path's detections; |mAP difference| <= 0.1 points on
     the 0-100 scale, for the area and the 11-point metric."""
@@ -263,12 +263,15 @@ def test_map_on_fixed_inputs_within_0p1_of_cpu_path():
     name = "ssdlite320_mobilenet_v3_large"
     m = _model(name, num_classes=91)
     sd = synth.state_dict(m.graph, 0)
-    n = 128
+    n = 256
     imgs = [torch.from_numpy(synth.images(4000 + i, 1, 320, 320)[0]) for i in range(n)]
     ref, _ = so.OracleSSD(name, sd, 91)(imgs, return_intermediates=True)
     gt = _synthetic_ground_truth(ref, 91)
-    boxes, scores, labels, counts = [t.cpu().numpy() for t in m.forward_batch(torch.stack(imgs).cuda())]
-    hip = [{"boxes": boxes[i, :int(counts[i])], "scores": scores[i, :int(counts[i])], "labels": labels[i, :int(counts[i])]} for i in range(n)]
+    hip = []
+    for i0 in range(0, n, 64):
+        boxes, scores, labels, counts = [t.cpu().numpy() for t in m.forward_batch(torch.stack(imgs[i0:i0 + 64]).cuda())]
+        hip += [{"boxes": boxes[i, :int(counts[i])].copy(), "scores": scores[i, :int(counts[i])].copy(), "labels": labels[i, :int(counts[i])].copy()}
+                for i in range(boxes.shape[0])]
     for metric07 in (False, True):
         map_ref, ap_ref = evalrec.voc_mean_ap(ref, gt, 0.5, metric07)
         map_hip, ap_hip = evalrec.voc_mean_ap(hip, gt, 0.5, metric07)
