@@ -181,6 +181,31 @@ struct TailArgs {
 int launch_tail(const TailArgs& a, int n, hipStream_t s);
 bool tail_op_supported(const dn_op_desc& o, int hin, int win, int hout, int wout);
 
+// run of inverted-residual blocks on the small maps, one workgroup per image (trunk.hip)
+constexpr int TRUNK_MAX_BLOCKS = 8;
+struct TrunkBlock {
+    int cin, cexp, cout, k, stride, pad, act1, act2, hin, hout, has_se, sq, has_res;
+    int w1f_off, b1_off, wd_off, bd_off, w3f_off, b3_off;      // byte offsets into the weight blob (expand / project: fragment-major copies)
+    int se_w1t_off, se_b1_off, se_w2t_off, se_b2_off;
+    int dsc_off;                    // halfs: this block's slice of the per-image scratch that parks the depthwise output of an SE block
+    int pad_;
+    half_t* feat_out;               // non-null: the expanded map is a pyramid feature, also written to HBM [n][hin*hin][cexp]
+    long feat_stride;               // halfs per image
+};
+struct TrunkArgs {
+    int count, xq;
+    int cin0, px0, cout_last, px_last;
+    const half_t* in0; long in0_stride;         // first block's input [n][pixels][cin], per-image stride in halfs
+    half_t* out; long out_stride;               // last block's output
+    half_t* dscratch; long dscratch_stride;     // [n][dscratch_stride] halfs
+    const half_t* weights;
+    long long* stamps;                          // dev-only
+    TrunkBlock blk[TRUNK_MAX_BLOCKS];
+};
+int launch_trunk(const TrunkArgs& a, int n, hipStream_t s);
+bool trunk_block_supported(int cin, int cexp, int cout, int k, int stride, int hin, int hout, int sq);
+size_t trunk_lds_bytes();
+
 // expand 1x1 + depthwise kxk in one launch (expdw.hip)
 struct ExpDwArgs {
     const half_t* x; half_t* out; float* pool;     // pool (optional): [n][tiles][cexp] fp32 per-tile channel sums

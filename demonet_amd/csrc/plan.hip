@@ -73,6 +73,7 @@ struct Layout {
     // (chain_n images), chain k adds k * arena. arena == 0: one contiguous [n]-image block per tensor.
     size_t arena = 0;
     int chain_n = 0;
+    size_t trunk_off = 0;       // [n][trunk_scratch_halfs] fp16
 };
 
 struct GraphKey {
@@ -120,6 +121,10 @@ struct dn_plan {
     std::vector<int> head_dw, head_cls, head_reg;
     // run of tiny backbone layers [tail_first, tail_end) executed by one per-image workgroup (tail.hip); -1: none
     int tail_first = -1, tail_end = -1;
+    // run of inverted-residual blocks on the small maps executed by one per-image workgroup (trunk.hip): ops [trunk_first, trunk_end)
+    int trunk_first = -1, trunk_end = -1;
+    std::vector<int> trunk_block_op;        // first op of every block of the run
+    long trunk_scratch_halfs = 0;           // per image: parked depthwise outputs of the run's SE blocks
     std::vector<char> tail_materialise;     // per op of the run: its output is read outside the run (pyramid feature) -> also to HBM            // optional extra output of the merge kernel (dn_set_packed_output)
     // inverted-residual stages that run as one launch (expdw.hip): at the first op of a group, fused_len = number of ops and
     // fused_kind bit0 = has expand (1x1), bit1 = has project (1x1 [+ residual]); the depthwise op is always part of it
@@ -187,6 +192,7 @@ static const Layout& get_layout(dn_plan* p, int n) {
                     break;
                 }
                 if (i == p->tail_first) len = p->tail_end - p->tail_first;
+                else if (i == p->trunk_first) len = p->trunk_end - p->trunk_first;
                 else if (p->fused_len[i] > 0) len = p->fused_len[i];
                 for (int q = 0; q < len; ++q) when[i + q] = tstep;
                 if (len > 1) {
@@ -250,6 +256,8 @@ static const Layout& get_layout(dn_plan* p, int n) {
     off += align256((size_t)n * p->d.num_anchors * 4 * 4);
     L.scale_off = off;
     off += align256((size_t)n * 2 * 4);
+    L.trunk_off = off;
+    off += align256((size_t)n * p->trunk_scratch_halfs * 2);
     L.post_off = off;
     {
         const int S = batch_split(p, n);          // one private post-process scratch slice per sub-batch branch
@@ -357,6 +365,75 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
                 p->fused_kind[i] = 4;
                 ++i;
             }
+        }
+    }
+    // ---- trunk run: consecutive inverted-residual blocks [expand 1x1][depthwise][SE][project 1x1 (+residual)] on maps of at most
+    //      20 x 20 pixels whose input is the previous block's output (trunk.hip). The expanded map may be a pyramid feature.
+    //      MEASURED (tools/probe_trunk.py, profiles/r02_trunk_stamps.txt): correct (head outputs within 2.3e-2 of the launch-per-layer
+    //      path, bit-identical without SE), but 1.68 ms per image-workgroup against ~0.43 ms for the 31 launches it replaces at 32
+    //      images per chain: a whole image on ONE CU makes every phase a latency chain (21-26 us per 64-channel chunk, 50-110 us
+    //      per SE FC pair at 2 waves per SIMD) and leaves 3/4 of the chip idle. Kept as an opt-in experiment (DN_TRUNK=1).
+    if (dn_knob("DN_TRUNK", 0) != 0) {
+        std::vector<int> uses(desc->n_tensors, 0);
+        for (int i = 0; i < desc->n_ops; ++i) {
+            const dn_op_desc& o = p->ops[i];
+            uses[o.in]++;
+            if (o.residual >= 0) uses[o.residual]++;
+            if (o.se >= 0) uses[o.se]++;
+        }
+        auto is_level = [&](int t) { for (int l = 0; l < desc->n_levels; ++l) if (desc->level_tensor[l] == t) return true; return false; };
+        auto block_at = [&](int i, int* len) -> bool {
+            if (i + 2 >= desc->n_ops) return false;
+            const dn_op_desc& e = p->ops[i];
+            const dn_op_desc& d = p->ops[i + 1];
+            if (e.type != DN_OP_PW || e.head || e.se >= 0 || e.residual >= 0 || e.w2_off < 0 || p->tensors[e.in].kind != DN_T_ACT) return false;
+            if (d.type != DN_OP_DW || d.head || d.in != e.out || d.dil != 1) return false;
+            if (uses[e.out] != 1 + 0 && !(is_level(e.out) && uses[e.out] >= 1)) return false;      // read by the depthwise (and by head ops if a feature)
+            int j = i + 2, se_vec = -1, sq = 0;
+            if (p->ops[j].type == DN_OP_SE) {
+                if (d.pool < 0 || p->ops[j].in != d.pool) return false;
+                se_vec = p->ops[j].out; sq = p->ops[j].squeeze;
+                ++j;
+                if (j >= desc->n_ops) return false;
+            } else if (d.pool >= 0) return false;
+            const dn_op_desc& pj = p->ops[j];
+            if (pj.type != DN_OP_PW || pj.head || pj.in != d.out || pj.se != se_vec || pj.act != DN_ACT_NONE || pj.w2_off < 0 || uses[d.out] != 1) return false;
+            if (pj.residual >= 0 && (pj.residual != e.in || d.stride != 1 || pj.cout != e.cin)) return false;
+            const dn_tensor_desc& ti = p->tensors[e.in];
+            const dn_tensor_desc& to = p->tensors[pj.out];
+            if (ti.h != ti.w || to.h != to.w || is_level(d.out) || is_level(pj.out)) return false;
+            if (!trunk_block_supported(e.cin, e.cout, pj.cout, d.k, d.stride, ti.h, to.h, sq)) return false;
+            for (int q = i; q <= j; ++q) if (p->fused_len[q] > 0) return false;
+            for (int q = 1; q <= 2 && i - q >= 0; ++q) if (p->fused_len[i - q] > q) return false;
+            *len = j - i + 1;
+            return true;
+        };
+        int best_first = -1, best_end = -1;
+        for (int i = 0; i < desc->n_ops; ++i) {
+            int len = 0, first = i, end = i, blocks = 0;
+            std::vector<int> starts;
+            while (blocks < TRUNK_MAX_BLOCKS && block_at(end, &len) && (blocks == 0 || p->ops[end].in == p->ops[end - 1].out)) {
+                starts.push_back(end);
+                end += len;
+                ++blocks;
+            }
+            if (blocks >= 2 && end - first > best_end - best_first) {
+                best_first = first; best_end = end;
+                p->trunk_block_op = starts;
+            }
+            if (blocks > 0) i = end - 1;
+        }
+        if (best_first >= 0) {
+            p->trunk_first = best_first;
+            p->trunk_end = best_end;
+            long halfs = 0;
+            for (int b : p->trunk_block_op) {
+                if (p->ops[b + 2].type == DN_OP_SE) {
+                    const dn_tensor_desc& to = p->tensors[p->ops[b + 1].out];
+                    halfs += (long)to.h * to.w * to.c;
+                }
+            }
+            p->trunk_scratch_halfs = halfs;
         }
     }
     // partial-sum rows of every pooled tensor = workgroups per image of its producing depthwise op
@@ -546,6 +623,7 @@ static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
     V.logits_off = L.logits_off + (size_t)n0 * p->d.num_anchors * p->d.num_classes * 4;
     V.reg_off = L.reg_off + (size_t)n0 * p->d.num_anchors * 16;
     V.scale_off = L.scale_off + (size_t)n0 * 8;
+    V.trunk_off = L.trunk_off + (size_t)n0 * p->trunk_scratch_halfs * 2;
     const size_t slice = L.post_bytes / (size_t)S;
     V.post_off = L.post_off + (size_t)k * slice;
     V.post_bytes = slice;
@@ -757,6 +835,54 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             for (size_t q = seg + 1; q < p->ops.size(); ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             break;
+        }
+        if ((int)i == p->trunk_first) {
+            TrunkArgs ta{};
+            ta.count = (int)p->trunk_block_op.size();
+            ta.xq = xq;
+            ta.weights = reinterpret_cast<const half_t*>(W);
+            const dn_op_desc& o0 = p->ops[i];
+            const dn_op_desc& ol = p->ops[p->trunk_end - 1];
+            ta.in0 = reinterpret_cast<const half_t*>(tptr(o0.in));
+            ta.in0_stride = (long)(L.tbytes[o0.in] / (size_t)L.n / 2);
+            ta.cin0 = o0.cin; ta.px0 = ti.h * ti.w;
+            ta.out = reinterpret_cast<half_t*>(tptr(ol.out));
+            ta.out_stride = (long)(L.tbytes[ol.out] / (size_t)L.n / 2);
+            ta.cout_last = ol.cout; ta.px_last = p->tensors[ol.out].h * p->tensors[ol.out].w;
+            ta.dscratch = reinterpret_cast<half_t*>(ws + L.trunk_off);
+            ta.dscratch_stride = p->trunk_scratch_halfs;
+            long dsc = 0;
+            for (int b = 0; b < ta.count; ++b) {
+                const int q = p->trunk_block_op[b];
+                const dn_op_desc& e = p->ops[q];
+                const dn_op_desc& dwo = p->ops[q + 1];
+                const bool has_se = p->ops[q + 2].type == DN_OP_SE;
+                const dn_op_desc& pj = p->ops[q + (has_se ? 3 : 2)];
+                TrunkBlock& t = ta.blk[b];
+                t.cin = e.cin; t.cexp = e.cout; t.cout = pj.cout; t.k = dwo.k; t.stride = dwo.stride; t.pad = dwo.pad;
+                t.act1 = e.act; t.act2 = dwo.act; t.hin = p->tensors[e.in].h; t.hout = p->tensors[pj.out].h;
+                t.has_se = has_se ? 1 : 0; t.sq = has_se ? p->ops[q + 2].squeeze : 0; t.has_res = pj.residual >= 0 ? 1 : 0;
+                t.w1f_off = (int)e.w2_off; t.b1_off = (int)e.b_off; t.wd_off = (int)dwo.w_off; t.bd_off = (int)dwo.b_off;
+                t.w3f_off = (int)pj.w2_off; t.b3_off = (int)pj.b_off;
+                if (has_se) {
+                    const dn_op_desc& so = p->ops[q + 2];
+                    t.se_w1t_off = (int)so.w_off; t.se_b1_off = (int)so.b_off; t.se_w2t_off = (int)so.w2_off; t.se_b2_off = (int)so.b2_off;
+                    t.dsc_off = (int)dsc;
+                    dsc += (long)t.hout * t.hout * t.cexp;
+                }
+                bool outside = false;       // the expanded map is read outside the run (pyramid feature): materialise it
+                for (int l = 0; l < d.n_levels; ++l) outside |= d.level_tensor[l] == e.out;
+                t.feat_out = outside ? reinterpret_cast<half_t*>(tptr(e.out)) : nullptr;
+                t.feat_stride = outside ? (long)(L.tbytes[e.out] / (size_t)L.n / 2) : 0;
+            }
+            rc = launch_trunk(ta, n, s);
+            if (rc != DN_OK) return rc;
+            const int cnt = p->trunk_end - p->trunk_first;
+            for (int q = 0; q < cnt; ++q) note(i + q, i);
+            for (int q = 1; q < cnt; ++q)
+                if (record) (void)hipEventRecord(p->events[ev++], s);
+            i += cnt - 1;
+            continue;
         }
         if ((int)i == p->tail_first) {
             TailArgs ta{};

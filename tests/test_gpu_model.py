@@ -341,6 +341,37 @@ def test_xcd_grouping_is_placement_only(n):
     assert int(res["1"][5].sum()) > 0
 
 
+@pytest.mark.parametrize("name,kw,n", [
+    ("ssdlite320_mobilenet_v3_large", dict(num_classes=91), 3),
+    ("ssdlite320_mobilenet_v3_large", dict(num_classes=91), 37),
+    ("ssd_lite_mobilenet_v2", dict(num_classes=21, score_thresh=0.02), 2),
+    ("ssd_lite_mobilenet_v2", dict(num_classes=21, image_size=300, score_thresh=0.02), 9),
+])
+def test_trunk_kernel_matches_launch_per_layer_path(name, kw, n):
+    """The inverted-residual blocks of the 20 x 20 / 10 x 10 maps run as one launch per layer (default) or in one per-image launch
+    (trunk.hip, DN_TRUNK=1: a measured-and-parked experiment). Same rounding points (fp16 expanded map, fp16 depthwise output, fp16 SE-scaled operand, fp32
+    accumulation in the same K order); only the SE pooled sums are added in a different order -> the head outputs agree far inside
+    the fp16 tolerance of the path, and the pyramid feature that the run materialises (the C4 expansion) agrees likewise."""
+    size = kw.get("image_size", 320)
+    imgs = torch.from_numpy(synth.images(55, n, size, size)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["DN_TRUNK"] = flag
+        try:
+            m = models.load_synthetic(getattr(models, name)(**kw), 0).cuda()
+            logits, reg = m.forward_heads(imgs)
+            f0 = m.tensor(imgs.shape, m.graph.features[0]).float() if n < 32 else None
+            res[flag] = (logits.clone(), reg.clone(), f0)
+        finally:
+            del os.environ["DN_TRUNK"]
+    d = (res["0"][0] - res["1"][0]).abs()
+    print(f"{name} n={n}: trunk vs per-layer logits max|d| {d.max().item():.4g} mean {d.mean().item():.3g}")
+    assert d.max().item() < 3e-2 and d.mean().item() < 2e-3
+    assert (res["0"][1] - res["1"][1]).abs().max().item() < 3e-2
+    if res["0"][2] is not None:
+        assert (res["0"][2] - res["1"][2]).abs().max().item() < 2e-2
+
+
 def test_graph_replay_equals_eager():
     m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
     imgs = torch.from_numpy(synth.images(9, 4, 320, 320)).cuda()
