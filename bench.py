@@ -31,6 +31,14 @@ DEFAULT_MODEL, DEFAULT_BATCH = "ssdlite320_mobilenet_v3_large", 64   # BASELINE.
 C4_GLOBAL_BATCH = 256                                                  # BASELINE.json configs[3]: batch 256 over the GPUs of one node
 
 
+def _norm_kernel(name):
+    """rocprofv3 spells defaulted template arguments out (conv_halo_kernel<3,4,4,false>), the library's labels do not."""
+    name = name.replace(" ", "")
+    while name.endswith(",false>"):
+        name = name[:-7] + ">"
+    return name
+
+
 def op_costs(graph, n):
     """Algorithmic bytes / flops per op for a batch of n (fp16 tensors, fp32 bias; fused op = external bytes)."""
     out = []
@@ -163,6 +171,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")       # (only matters for the 1-GPU DN_BENCH_FORCE_DIST run; torchrun sets all of these)
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from demonet_amd import models, synth
@@ -348,27 +359,29 @@ def main():
         else:
             ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         traffic, traffic_src = None, None
-        if args.model == DEFAULT_MODEL and B == DEFAULT_BATCH:
-            # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc_collect.sh + tools/pmc_traffic.py)
+        prof_tag = {("ssdlite320_mobilenet_v3_large", 64): "", ("ssd512_vgg16", 32): "_vgg512", ("ssd300_vgg16", 64): "_vgg300"}.get((args.model, B))
+        if prof_tag is not None:
+            # HBM bytes per launch from the PMC passes committed under profiles/ (tools/round_profile.sh + tools/pmc_traffic.py)
             import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_hbm_traffic.json")), reverse=True):
                 with open(path) as f:
                     tk = json.load(f)["kernels"]
-                if dom in tk:
-                    traffic, traffic_src = tk[dom]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                tk = {_norm_kernel(k): v for k, v in tk.items()}
+                if _norm_kernel(dom) in tk:
+                    traffic, traffic_src = tk[_norm_kernel(dom)]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
                     break
         rocprof_avg = None
-        if args.model == DEFAULT_MODEL and B == DEFAULT_BATCH:
+        if prof_tag is not None:
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
             # (graph replay, both sub-batch branches in flight); the live figure below is HIP events around each launch in
             # an eager pass, which adds the ~3 us dispatch gap to every launch
             import csv, glob, re
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_kernel_stats.csv")), reverse=True):
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_kernel_stats.csv")), reverse=True):
                 with open(path) as f:
                     for r in csv.DictReader(f):
                         nm = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
                         nm = re.sub(r"\(.*$", "", nm).replace("void ", "").replace(", ", ",").strip()
-                        if nm == dom:
+                        if _norm_kernel(nm) == _norm_kernel(dom):
                             rocprof_avg = round(float(r["AverageNs"]) / 1e3, 2)
                 if rocprof_avg is not None:
                     break

@@ -95,6 +95,10 @@ struct PwArgs {
     const half_t* w_b = nullptr; const float* bias_b = nullptr; void* out_b = nullptr;
     int cout_b = 0; long out_b_img_stride = 0, out_b_base = 0;
     const half_t* wfrag = nullptr;   // optional: the weights in MFMA-fragment order (dn_op_desc::w2_off), used by the strip kernel
+    // squeeze-excitation folded into the projection (pointwise.hip, SEF variant): instead of `se`, the pooled partial sums of the
+    // producing depthwise launch and the two FC weight sets; every workgroup computes the scale vector of its (at most two) images
+    const float* sef_part = nullptr; int sef_nblk = 0, sef_sq = 0; float sef_inv = 0.f;
+    const half_t* sef_w1t = nullptr; const half_t* sef_w2t = nullptr; const float* sef_b1 = nullptr; const float* sef_b2 = nullptr;
     half_t* pool_out = nullptr;      // conv_patch_kernel only: write the 2x2 / stride-2 max-pooled map [n][h/2][w/2][cout] instead of `out`
     const half_t* x;        // [m][cin]
     const half_t* w;        // [cout][cin]
@@ -109,6 +113,7 @@ struct PwArgs {
     int xq = 0;             // XCD grouping: images per group (0: plain mapping); see xcd_images_per_group
 };
 int launch_pointwise(const PwArgs& a, hipStream_t s);
+bool pw_se_fold_supported(int cin, int cout, int squeeze, int hw);
 int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t s);
 // 256x256-tile implicit GEMM for the MFMA-bound dense convs (convbig.hip)
 bool conv_big_supported(const PwArgs& a);

@@ -50,7 +50,7 @@ __device__ __forceinline__ bool pw_tile_rows(const PwArgs& a, int flat, int tile
     return true;
 }
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false>
 __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, const int by) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
@@ -62,7 +62,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
     constexpr int NWc = NW;
     extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];      // bias[BC] floats, then [1|2][(BP + BC) * LDS_ROW] halfs
     float* bsh = reinterpret_cast<float*>(lds_raw);
-    half_t* lds_dyn = lds_raw + 2 * BC;
+    constexpr int SEF_FLOATS = SEF ? 832 : 0;           // scale[2][128], mean[2][128], z[2][32], fc1 partials[2][4][32]
+    float* sef = bsh + BC;
+    half_t* lds_dyn = lds_raw + 2 * BC + 2 * SEF_FLOATS;
     half_t (*lds)[(BP + BC) * LDS_ROW] = reinterpret_cast<half_t (*)[(BP + BC) * LDS_ROW]>(lds_dyn);
 
     const int tid = threadIdx.x;
@@ -139,12 +141,22 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             sw[i] = v;
         }
     };
-    auto store_from = [&](const uint4 (&sx)[NX], const uint4 (&sw)[NWc], int b) {
+    int sef_split = 0x7fffffff;             // SEF: first row of the tile that belongs to the second image
+    auto store_from = [&](const uint4 (&sx)[NX], const uint4 (&sw)[NWc], int b, int k0 = 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int c = tid + 256 * i;
             const int row = c / CPR, q = c - row * CPR;
-            if (row < BP) *reinterpret_cast<uint4*>(&lds[b][row * LDS_ROW + q * 8]) = sx[i];
+            uint4 v = sx[i];
+            if constexpr (SEF) {
+                // SE scale applied as the rows are staged: (half)((float)x * s), the rounding of the launch-per-op path (load_into)
+                const float* sp = sef + (row >= sef_split ? 128 : 0) + min(k0 + q * 8, 120);
+                half8 hv = *reinterpret_cast<half8*>(&v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)((float)hv[e] * sp[e]);
+                v = *reinterpret_cast<uint4*>(&hv);
+            }
+            if (row < BP) *reinterpret_cast<uint4*>(&lds[b][row * LDS_ROW + q * 8]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -199,7 +211,73 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
 #pragma unroll
         for (int st = 0; st < PF; ++st)
             if (st < KT) load_into(px[st], pwt[st], st * BK);
-        store_from(px[0], pwt[0], 0);
+        if constexpr (SEF) {
+            // ---- squeeze-excitation FCs of this tile's (at most two) images, while the tile loads are in flight
+            //      (mobilenetv3.py:31-36: mean -> fc1 + ReLU -> fc2 + Hardsigmoid; c <= 128, squeeze <= 32)
+            float* s_scale = sef; float* s_mean = sef + 256; float* s_z = sef + 512; float* s_p = sef + 576;
+            const int C = K, sq = a.sef_sq, nblk = a.sef_nblk;
+            const int img0 = m0 / a.hw, img_last = (min(m0 + BP, M) - 1) / a.hw;
+            sef_split = (img0 + 1) * a.hw - m0;
+            const int im = tid >> 7;
+            const bool live = img0 + im <= img_last;
+            {
+                const int c = tid & 127;
+                float t = 0.f;
+                if (c < C && live) {
+                    const float* pp = a.sef_part + (size_t)(img0 + im) * nblk * C + c;
+                    for (int b0 = 0; b0 < nblk; b0 += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)min(b0 + u, nblk - 1) * C];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t += (b0 + u < nblk) ? v[u] : 0.f;
+                    }
+                }
+                s_mean[im * 128 + c] = t * a.sef_inv;
+            }
+            __syncthreads();
+            {
+                const int sl = (tid >> 5) & 3, j = tid & 31;
+                const int per = (C + 3) >> 2, i0 = sl * per, i1 = min(C, i0 + per);
+                float t = 0.f;
+                if (j < sq && live) {
+                    for (int ib = i0; ib < i1; ib += 8) {
+                        half_t v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = a.sef_w1t[(size_t)min(ib + u, i1 - 1) * sq + j];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t += (ib + u < i1) ? (float)v[u] * s_mean[im * 128 + ib + u] : 0.f;
+                    }
+                }
+                s_p[(im * 4 + sl) * 32 + j] = t;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int i2 = tid >> 5, j = tid & 31;
+                float z = 0.f;
+                if (j < sq) z = fmaxf(a.sef_b1[j] + s_p[(i2 * 4 + 0) * 32 + j] + s_p[(i2 * 4 + 1) * 32 + j] + s_p[(i2 * 4 + 2) * 32 + j] + s_p[(i2 * 4 + 3) * 32 + j], 0.f);
+                s_z[i2 * 32 + j] = z;
+            }
+            __syncthreads();
+            {
+                const int i = tid & 127;
+                float t = 0.f;
+                if (i < C && live) {
+                    t = a.sef_b2[i];
+                    for (int jb = 0; jb < sq; jb += 8) {
+                        half_t v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = a.sef_w2t[(size_t)min(jb + u, sq - 1) * C + i];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t += (jb + u < sq) ? (float)v[u] * s_z[im * 32 + jb + u] : 0.f;
+                    }
+                    t = fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                }
+                s_scale[im * 128 + i] = t;
+            }
+            __syncthreads();
+        }
+        store_from(px[0], pwt[0], 0, 0);
         __syncthreads();
         PW_STAMP(1);
         for (int kt0 = 0; kt0 < KT; kt0 += PF) {
@@ -209,7 +287,7 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
                 if (kt < KT) {
                     mfma_stage(kt & 1, kt);
                     // slot (j+1)%PF holds stage kt+1; slot j (stage kt, already in LDS) is free for stage kt+PF
-                    if (kt + 1 < KT) store_from(px[(j + 1) % PF], pwt[(j + 1) % PF], (kt + 1) & 1);
+                    if (kt + 1 < KT) store_from(px[(j + 1) % PF], pwt[(j + 1) % PF], (kt + 1) & 1, (kt + 1) * BK);
                     if (kt + PF < KT) load_into(px[j], pwt[j], (kt + PF) * BK);
                     __syncthreads();
                 }
@@ -427,11 +505,11 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
     PW_STAMP(3);
 }
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false>
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a, int tiles) {
     int m0, mend, by;
     if (!pw_tile_rows<BP>(a, blockIdx.x, tiles, m0, mend, by)) return;
-    pw_body<BP, BC, WP, WC, CONV, BK, PF>(a, m0, mend, by);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF, SEF>(a, m0, mend, by);
 }
 
 // Grouped launch: up to 12 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
@@ -647,17 +725,18 @@ int launch_xs(const PwArgs& a, hipStream_t s) {
     return DN_OK;
 }
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK, int PF = 1>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK, int PF = 1, bool SEF = false>
 int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
     const int tiles = pw_row_tiles(a, BP);
     dim3 grid((a.xq > 0 ? 8 * tiles : tiles) * dn_cdiv(a.cout, BC));
     size_t halfs = (size_t)nbuf * (BP + BC) * (BK + 8);
     const size_t otile = (a.out_fp32 || a.residual) ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);     // epilogue staging tile, in halfs (fp32 for head rows and for residual layers)
     if (otile > halfs) halfs = otile;
-    const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
-    if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK, PF>)));
-    dn_note_kernel(PF > 1 ? "pw_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK, PF);
-    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK, PF>), grid, dim3(256), lds, s, a, tiles);
+    const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float) + (SEF ? 832 * sizeof(float) : 0);
+    if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK, PF, SEF>)));
+    dn_note_kernel(SEF ? "pw_kernel<%d,%d,%d,%d,%s,%d,%d,true>" : PF > 1 ? "pw_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC,
+                   CONV ? "true" : "false", BK, PF);
+    hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK, PF, SEF>), grid, dim3(256), lds, s, a, tiles);
     return DN_OK;
 }
 
@@ -701,6 +780,9 @@ int launch_select(const PwArgs& a, hipStream_t s) {
             const int shortk = dn_knob("DN_PW_SHORTK", 1);
             if (shortk && a.cin > 32 && a.cin <= 128) {       // 2..4 K stages: all loads up front
                 const_cast<PwArgs&>(a).stamps = g_pw_stamps;
+                if constexpr (!CONV) {
+                    if (a.sef_part) return launch_bk<64, 64, 2, 2, CONV, 32, 4, true>(a, s, 2);     // squeeze-excitation folded in (pw_se_fold_supported)
+                }
                 if (a.cout <= 32) return launch_bk<128, 32, 4, 1, CONV, 32, 4>(a, s, 2);
                 return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
             }
@@ -796,13 +878,20 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     return conv ? launch_group_cfg<64, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
 }
 
+// the squeeze-excitation of a projection can be computed in the projection kernel's prologue (SEF variant of the 64 x 64 tile)
+bool pw_se_fold_supported(int cin, int cout, int squeeze, int hw) {
+    return dn_knob("DN_SE_FOLD", 1) != 0 && dn_knob("DN_PW_SHORTK", 1) != 0 && cin > 32 && cin <= 128 && cin % 8 == 0 && squeeze <= 32 && hw >= 64 &&
+           (cin < 256 || cout < 128);
+}
+
 int launch_pointwise(const PwArgs& a, hipStream_t s) {
+    DN_REQUIRE(!a.sef_part || (!a.se && pw_se_fold_supported(a.cin, a.cout, a.sef_sq, a.hw)), "pointwise: squeeze-excitation fold not supported for this shape");
     DN_REQUIRE(a.cin % 8 == 0, "pointwise: cin=%d must be a multiple of 8", a.cin);
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
     const int xs_mode = dn_knob("DN_PW_XS", 1);
     if (g_pw_tile == 8 && a.wfrag) return launch_xs<32>(a, s);
-    if (xs_mode && !g_pw_tile && a.wfrag && a.cin % 16 == 0 && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&      // (K % 16 == 8: measured slower than the tiled kernel)
+    if (xs_mode && !g_pw_tile && !a.sef_part && a.wfrag && a.cin % 16 == 0 && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&      // (K % 16 == 8: measured slower than the tiled kernel)
         ((a.cin >= 64 && a.m <= 8192) || (a.cin >= 160 && a.m <= 16384))) {
         // measured (tools/tune_pw.py): the strip kernel wins where the tiled kernel cannot fill the chip -- M <= ~8k rows, or
         // M <= ~16k rows when K is long (the tiled kernel pays one exposed round trip per 32-deep K stage)

@@ -1,18 +1,22 @@
 #!/bin/bash
-# Round artifacts on the GPU box: headline bench line, per-op table, rocprofv3 kernel stats of the same command,
-# FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only).   usage: tools/round_profile.sh <tag>
-TAG=${1:-r01}
+# Round artifacts on the GPU box for one bench configuration: the bench line (+ per-op table), the rocprofv3 kernel stats of the same
+# command, FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only) and one SQ pass for the matrix-core counters.
+#   usage: tools/round_profile.sh <tag> [bench args]        e.g.  tools/round_profile.sh r02            (headline config)
+#                                                                  tools/round_profile.sh r02_vgg512 --model ssd512_vgg16 --batch 32
+TAG=${1:-r02}; shift
 export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
-python3 bench.py --per-op $OUT/per_op.txt > $OUT/bench.json 2> $OUT/bench.err
-tail -c 2500 $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+python3 bench.py --per-op $OUT/per_op.txt "$@" > $OUT/bench.json 2> $OUT/bench.err
+tail -c 1200 $OUT/bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline "$@" > $OUT/stats.log 2>&1
+cp $(find /tmp/rp_$TAG/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc/$c -o $c -- python3 bench.py --steps 3 --warmup 2 --eager --no-cpu-baseline --no-roofline > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$TAG/pmc/$c -o $c -- python3 bench.py --steps 3 --warmup 2 --eager --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_$c.log 2>&1
 done
-find $OUT -name "*kernel_stats.csv" | head -2
-python3 tools/pmc_traffic.py $OUT/pmc $OUT/hbm_traffic.json
-# keep the merge-back small: the raw traces are large
-find $OUT -name "*kernel_trace.csv" -size +20M -delete
+PMC_CMD="bench.py --steps 3 --warmup 2 --eager $*" python3 tools/pmc_traffic.py /tmp/rp_$TAG/pmc $OUT/hbm_traffic.json
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/rp_$TAG/sq -o sq -- python3 bench.py --steps 3 --warmup 2 --eager --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_sq.log 2>&1
+python3 tools/pmc_mfma.py /tmp/rp_$TAG/sq $OUT/mfma_util.json $OUT/kernel_stats.csv
+rm -rf /tmp/rp_$TAG
+ls $OUT
