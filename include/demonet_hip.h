@@ -97,7 +97,9 @@ DN_API int dn_forward(dn_plan* plan, const float* images_dev, int n, int h, int 
 
 /* The same with the decoder's output as input -- the step just before the path: images_dev = [n][h][w][3] uint8, HWC,
  * RGB. x/255 (ToTensor), the bilinear resize of transform.py:27-53 and the HWC -> planar conversion run as one pass ahead of the
- * stem (which normalises on load); results are identical to dn_forward on float(images)/255 in NCHW. */
+ * stem (which normalises on load); results are identical to dn_forward on float(images)/255 in NCHW.
+ * The call marks the plan's current input as uint8 for its duration (shared plan state): like dn_forward, one plan serves one host
+ * thread at a time. */
 DN_API int dn_forward_u8(dn_plan* plan, const uint8_t* images_dev, int n, int h, int w,
                   float* boxes_dev, float* scores_dev, int64_t* labels_dev, int32_t* counts_dev,
                   void* workspace_dev, size_t workspace_bytes, void* stream);

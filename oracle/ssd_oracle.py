@@ -8,7 +8,7 @@ fails loudly if its HIP library is missing.
 Pinning status:
   * network, anchors, softmax, box decode, per-class threshold/top-k: PINNED against the real
     reference run in the authoring container (oracle/run_reference.py; goldens in tests/golden/,
-    test in tests/test_oracle_vs_reference.py).
+    test in tests/test_oracle.py).
   * clip_boxes_to_image / nms / batched_nms live in torchvision (third-party, unpinned version,
     absent from /root/reference and from this image): restated from the published algorithm
     (per-class greedy NMS, IoU = inter/(a+b-inter), suppress when IoU > thr, kept indices in
