@@ -344,6 +344,8 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
 
 template <int K, int S>
 int launch_ks(const ExpDwArgs& a, int oh, int ow, hipStream_t s) {
+    if (oh == 4) return launch_t<K, S, 4, 8>(a, s);
+    if (oh == 8 && ow == 8) return launch_t<K, S, 8, 8>(a, s);
     if (oh == 8) {
         if constexpr (S == 1) return launch_t<K, S, 8, 16>(a, s);
         else return launch_t<K, S, 8, 8>(a, s);
@@ -356,6 +358,9 @@ int launch_ks(const ExpDwArgs& a, int oh, int ow, hipStream_t s) {
 }  // namespace
 
 void expdw_tile(int Ho, int Wo, int stride, int* oh, int* ow) {
+    // dev knob: DN_EXPDW_TILE = 48 / 88 forces the 4 x 8 / 8 x 8 output tile on the large maps (tile-size experiments)
+    const int force = dn_knob("DN_EXPDW_TILE", 0);
+    if (force && Wo >= 32 && Ho >= 32) { *oh = force / 10; *ow = force % 10; return; }
     if (Wo <= 5 && Ho <= 5) { *oh = 5; *ow = 5; }
     else if (Wo <= 10) { *oh = 5; *ow = 10; }
     else if (Wo < 32 && Wo % 16 != 0) {                     // 19x19 / 20x20 maps: 10-wide tiles waste nothing

@@ -1,0 +1,37 @@
+"""dev tool: the fused expand + depthwise + project blocks of the 160^2 / 80^2 maps (b2, b3): time per launch and per-workgroup phase
+stamps (s_memrealtime, 100 MHz): 0 start, 1 input staged, 2 first chunk expanded, 3 first chunk done (dw + project), 4 end."""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from demonet_amd import _lib
+L = _lib.lib()
+L.dn_debug_expdw_stamps.argtypes = [C.c_void_p]
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+SHAPES = [(160, 16, 64, 24, 3, 2, 0), (80, 24, 72, 24, 3, 1, 1)]
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for (h, cin, cexp, cout, k, s, res) in SHAPES:
+    ho = (h + 2 * ((k - 1) // 2) - k) // s + 1
+    R = 4
+    xs = [torch.randn(N, h, h, cin, device="cuda").half() for _ in range(R)]
+    outs = [torch.empty(N, ho, ho, cout, device="cuda", dtype=torch.half) for _ in range(R)]
+    w1 = (torch.randn(cexp, cin, device="cuda") / cin ** 0.5).half(); b1 = torch.randn(cexp, device="cuda")
+    wd = (torch.randn(k * k, cexp, device="cuda") / k).half(); bd = torch.randn(cexp, device="cuda")
+    w3 = (torch.randn(cout, cexp, device="cuda") / cexp ** 0.5).half(); b3 = torch.randn(cout, device="cuda")
+    call = lambda i: _lib.check(L.dn_expand_depthwise(P(xs[i % R]), P(w1), P(b1), P(wd), P(bd), P(w3), P(b3), P(outs[i % R]), None, N, h, h, cin, cexp, cout, k, s, 1, 1, res, stream))
+    call(0); call(1)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(10): call(i)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    st = torch.zeros(8 * 200000, dtype=torch.int64, device="cuda")
+    L.dn_debug_expdw_stamps(C.c_void_p(st.data_ptr())); call(0); torch.cuda.synchronize(); L.dn_debug_expdw_stamps(None)
+    t = st.cpu().numpy().reshape(-1, 8)[:, :5].astype(np.float64)
+    t = t[t[:, 0] > 0]
+    d = np.diff(t, axis=1) * 0.01
+    print(f"{h:3d}x{h:<3d} {cin:3d}->{cexp:3d}->{cout} k{k}s{s}: {us:6.1f} us/launch WGs {len(t):5d} | stage-x {d[:,0].mean():5.2f} "
+          f"expand(1st chunk) {d[:,1].mean():5.2f} dw+proj(1st chunk) {d[:,2].mean():5.2f} rest {d[:,3].mean():5.2f} | life {d.sum(1).mean():5.2f} "
+          f"span {(t[:,4].max() - t[:,0].min()) * 0.01:6.1f}  concurrent WGs ~{d.sum(1).sum() / ((t[:,4].max() - t[:,0].min()) * 0.01):.0f}", flush=True)
