@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdemonet_hip.so")
-SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "trunk.hip"]
+SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "trunk.hip", "pwdirect.hip"]
 EXTRA = {"postprocess.hip": ["-ffp-contract=off"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

@@ -117,6 +117,9 @@ struct PwArgs {
     int xq = 0;             // XCD grouping: images per group (0: plain mapping); see xcd_images_per_group
 };
 int launch_pointwise(const PwArgs& a, hipStream_t s);
+// register-direct schedule for short reductions (pwdirect.hip)
+bool pw_direct_supported(const PwArgs& a);
+int launch_pw_direct(const PwArgs& a, hipStream_t s);
 bool pw_se_fold_supported(int cin, int cout, int squeeze, int hw);
 int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t s);
 // 256x256-tile implicit GEMM for the MFMA-bound dense convs (convbig.hip)

@@ -21,12 +21,13 @@
 
 static long long* g_xd_stamps = nullptr;     // dev hook (tools/probe_expdw.py): per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_expdw_stamps(void* dev_ptr) { g_xd_stamps = (long long*)dev_ptr; }
-#define XD_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define XD_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 namespace {
 
-constexpr int EW = 72;          // halfs per E row in LDS: 64 channels + 8 pad (144 B = 9 x 16 B)
-constexpr int XKS = 8;          // max 16-deep K steps of the expand (cin <= 128)
+constexpr int EW = 72;          // halfs per E row in LDS: 64 channels + 8 pad (144 B = 9 x 16 B). The pad is real storage: a LAST chunk of
+                                // exactly 72 channels (the 24 -> 72 -> 24 block) is taken whole, columns 64..71 holding its last 8 channels
+constexpr int XKS = 8;          // max full 16-deep K steps of the expand (cin <= 128)
 constexpr int NT = 512;         // threads per workgroup: 8 waves; two workgroups per CU give 4 waves per SIMD to hide LDS/L2 latency
 
 template <int K, int S, int OH, int OW>
@@ -35,118 +36,149 @@ struct ExpDwGeom {
     static constexpr int RT = (NPIX + 31) / 32, ROWS = RT * 32;
 };
 
-template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ>
-__global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int zsplit) {
+// one uniform switch per 16 / 8 values instead of a select chain per element (these kernels are VALU-issue bound: tools/valu.sh)
+template <typename V, int N>
+__device__ __forceinline__ void act_n(V& v, int act) {
+    if (act == DN_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (act == DN_ACT_RELU6) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+    } else if (act == DN_ACT_HSWISH) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+}
+
+// Instruction diet (the kernel is VALU-issue bound, tools/valu.sh: a wave64 VALU instruction holds its SIMD for 4 cycles):
+//   * 3-D grid [8 XCD groups x tiles_x][tiles_y (x chunk split)][image slot]: no integer division to find the tile;
+//   * XW8 > 0: the X row width is a compile-time constant (XW8 16-byte chunks), so staging divides by constants only;
+//   * the expand's bias rides in the reduction: column `cin` of every X row holds 1.0 for pixels inside the image (0 outside, 0 in
+//     the row padding) and the weight fragment holds (hi, lo) = the fp32 bias split into two fp16 values there
+//     (|b - hi - lo| <= 2^-22 |b|). A pixel outside the image then expands to act(0) = 0 -- exactly the zero padding the
+//     depthwise needs -- without a per-element inside test, bias add or select;
+//   * activations: one uniform switch per accumulator (act_n);
+//   * every global load is unconditional with a clamped address (a predicated load costs a branch and a conservative wait).
+template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 2 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
-    static_assert(K * K * 8 <= NT, "one 16-byte piece of the chunk's depthwise weights per thread");
+    constexpr bool WIDE = PROJ && EXP && KSM <= 2;          // may take a last chunk of 72 channels whole
+    static_assert(K * K * 9 <= NT, "one 16-byte piece of the chunk's depthwise weights per thread");
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
-    const int XW = a.xw;                                    // halfs per X row: round16(cin) + 8
-    half_t* Xs = lds;                                       // [ROWS][XW]
-    half_t* Es = Xs + ROWS * XW;                            // [ROWS][EW]
-    half_t* Wd = Es + (EXP ? ROWS * EW : 0);                // [K*K][64]   depthwise weights of the chunk
-    float* Bd = reinterpret_cast<float*>(Wd + K * K * 64);  // [64]        depthwise bias of the chunk
-    float* Ps = Bd + 64;                                    // [NT/64][64] pooled-sum scratch (one row per wave)
+    const int XW = XW8 > 0 ? XW8 * 8 : a.xw;                // halfs per X row: round16(cin) + 8
+    half_t* Xs = lds;                                       // [ROWS][XW] + 8 zero halfs (the last K step of the last row reads past its end)
+    half_t* Es = Xs + ROWS * XW + 8;                        // [ROWS][EW]
+    half_t* Wd = Es + (EXP ? ROWS * EW : 0);                // [K*K][72]   depthwise weights of the chunk
+    float* Bd = reinterpret_cast<float*>(Wd + K * K * EW);  // [72]        depthwise bias of the chunk
+    float* Ps = Bd + EW;                                    // [NT/64][64] pooled-sum scratch (one row per wave)
     half_t* Ds = reinterpret_cast<half_t*>(Ps + NT / 64 * 64);   // [DROWS][EW] depthwise output of the chunk (PROJ only)
     constexpr int DROWS = (OH * OW + 31) / 32 * 32;
+    float* B3s = reinterpret_cast<float*>(Ds + (PROJ ? DROWS * EW : 0));   // [256] project bias (PROJ only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    // flat 1-D grid [image slot][chunk split z][tile]; XCD grouping (common.h): the workgroups with equal (index % 8) share the
-    // images of one group of a.xq images
-    int n, rem;
-    {
-        const int per_image = tiles * zsplit;
-        if (a.xq > 0) {
-            const int g = blockIdx.x & 7, w = blockIdx.x >> 3;
-            const int j = w / per_image;
-            rem = w - j * per_image;
-            n = g * a.xq + j;
-        } else {
-            n = blockIdx.x / per_image;
-            rem = blockIdx.x - n * per_image;
-        }
-        if (n >= a.n) return;
+    int n, tx, ty, zblk = 0;
+    if (a.xq > 0) {                                         // XCD grouping (common.h): blockIdx.x % 8 = the group of a.xq images
+        n = (blockIdx.x & 7) * a.xq + blockIdx.z;
+        tx = blockIdx.x >> 3;
+    } else {
+        n = blockIdx.z;
+        tx = blockIdx.x;
     }
-    const int zblk = rem / tiles, tile = rem - zblk * tiles;
-    const int tiles_x = (a.Wo + OW - 1) / OW;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    if (n >= a.n) return;
+    ty = blockIdx.y;
+    if (zsplit > 1) { zblk = ty / tiles_y; ty -= zblk * tiles_y; }
+    const int tile = ty * tiles_x + tx, tiles = tiles_x * tiles_y;
     const int oy0 = ty * OH, ox0 = tx * OW;
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
     const int cin = a.cin, cexp = a.cexp;
-    const int KS = (cin + 15) >> 4;
+    const int KSF = cin >> 4;                               // full K steps; then ONE last step: the K tail (cin % 16 == 8) and the bias columns
     const int c_begin = zblk * a.chunks_per_wg * 64;
     const int c_end = min(cexp, c_begin + a.chunks_per_wg * 64);
 
-    // Per-chunk operands that come from global memory, requested one phase ahead of their use so that their latency hides
-    // under the staging / depthwise work: this wave's A fragments (channel tile t = wave & 1) and bias of the expand, and
-    // this thread's 16-byte piece of the chunk's depthwise weights / bias (written to LDS at the top of the chunk).
+    // Per-chunk operands from global memory, requested one phase ahead of their use: this wave's A fragments of the expand
+    // (channel tile t = wave & 1; with a 72-wide chunk also those of the third tile) and this thread's 16-byte piece of the
+    // chunk's depthwise weights / bias (written to LDS at the top of the chunk). Unconditional loads, clamped addresses.
     const int t = wave & 1;
-    half8 wf[KSM];
-    float4 bv[4];
+    half8 wf[KSM], wl, wf2[WIDE ? KSM : 1], wl2;
+    float b1v = 0.f, b1v2 = 0.f;
     uint4 wdreg = make_uint4(0, 0, 0, 0);
     float bdreg = 0.f;
-    auto request_chunk = [&](int c0) {
+    const int kb = KSF * 16 + hh * 8;                       // this lane's columns of the last step
+    const int kcl = min(kb, cin - 8);
+    auto request_chunk = [&](int c0, bool wide) {
         if constexpr (EXP) {
-            const int ch = c0 + t * 32 + r;
+            const int ch = min(c0 + t * 32 + r, cexp - 1);
+            const half_t* wrow = a.w1 + (size_t)ch * cin;
 #pragma unroll
-            for (int ks = 0; ks < KSM; ++ks) {
-                const int k = ks * 16 + hh * 8;
-                half8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ks < KS && ch < cexp && k < cin) w = *reinterpret_cast<const half8*>(a.w1 + (size_t)ch * cin + k);
-                wf[ks] = w;
-            }
+            for (int ks = 0; ks < KSM; ++ks)
+                if (ks < KSF) wf[ks] = *reinterpret_cast<const half8*>(wrow + ks * 16 + hh * 8);
+            wl = *reinterpret_cast<const half8*>(wrow + kcl);
+            b1v = a.b1[ch];
+            if constexpr (WIDE) {
+                if (wide) {
+                    const int ch2 = min(c0 + 64 + r, cexp - 1);
+                    const half_t* wrow2 = a.w1 + (size_t)ch2 * cin;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = c0 + t * 32 + 8 * g + 4 * hh;
-                bv[g] = (c < cexp) ? *reinterpret_cast<const float4*>(a.b1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int ks = 0; ks < KSM; ++ks)
+                        if (ks < KSF) wf2[ks] = *reinterpret_cast<const half8*>(wrow2 + ks * 16 + hh * 8);
+                    wl2 = *reinterpret_cast<const half8*>(wrow2 + kcl);
+                    b1v2 = a.b1[ch2];
+                }
             }
         }
-        wdreg = make_uint4(0, 0, 0, 0);
-        if (tid < K * K * 8 && c0 + (tid & 7) * 8 < cexp)
-            wdreg = *reinterpret_cast<const uint4*>(a.wd + (size_t)(tid >> 3) * cexp + c0 + (tid & 7) * 8);
-        bdreg = (tid < 64 && c0 + tid < cexp) ? a.bd[c0 + tid] : 0.f;
+        const int wrow_i = tid / 9, wc8 = tid - wrow_i * 9;
+        wdreg = *reinterpret_cast<const uint4*>(a.wd + (size_t)min(wrow_i, K * K - 1) * cexp + min(c0 + wc8 * 8, cexp - 8));
+        bdreg = a.bd[min(c0 + min(tid, EW - 1), cexp - 1)];
     };
+    // last-step fragment: data columns as loaded, the bias pair at column cin, zero beyond
+    auto last_frag = [&](const half8& w, float b) {
+        const half_t hi = (half_t)b;
+        const half_t lo = (half_t)(b - (float)hi);
+        const half8 bw = {hi, lo, 0, 0, 0, 0, 0, 0};
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        return kb < cin ? w : (kb == cin ? bw : zero8);
+    };
+    half8 w3f[PROJ ? (WIDE ? 5 : 4) : 1];
 
     XD_STAMP(0);
-    // ---- 1. input region -> LDS (zeros outside the image, in the K padding and in the row padding)
+    // ---- 1. input region -> LDS (zeros outside the image, in the K padding and in the row padding; 1.0 in column cin inside the image)
     {
         const int c8 = cin >> 3, xc8 = XW >> 3;
         const half_t* xin = a.x + (size_t)n * a.H * a.W * cin;
-        for (int i0 = tid; i0 < ROWS * xc8; i0 += NT * 4) {
+        if (tid == 0) *reinterpret_cast<uint4*>(&Xs[ROWS * XW]) = make_uint4(0, 0, 0, 0);
+        for (int i0 = tid; i0 == tid || i0 < ROWS * xc8; i0 += NT * 4) {     // (every thread runs the first pass: it requests the chunk operands)
             uint4 v[4];
             int dst[4];
+            bool ok[4], one[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = i0 + NT * u;
                 const int pix = idx / xc8, q = idx - pix * xc8;
                 const int py = pix / IW, px = pix - py * IW;
                 const int gy = iy0 + py, gx = ix0 + px;
-                v[u] = make_uint4(0, 0, 0, 0);
+                const bool inside = idx < ROWS * xc8 && pix < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 dst[u] = idx < ROWS * xc8 ? pix * XW + q * 8 : -1;
-                if (idx < ROWS * xc8 && pix < NPIX && q < c8 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v[u] = *reinterpret_cast<const uint4*>(xin + ((size_t)gy * a.W + gx) * cin + q * 8);
+                ok[u] = inside && q < c8;
+                one[u] = EXP && inside && q == c8;
+                v[u] = *reinterpret_cast<const uint4*>(xin + (ok[u] ? ((size_t)gy * a.W + gx) * cin + q * 8 : (size_t)0));
             }
-            if (i0 == tid) request_chunk(c_begin);      // behind the first batch of region loads (memory returns in order)
+            float b3reg = 0.f;
+            if (i0 == tid) {
+                request_chunk(c_begin, WIDE && c_end - c_begin == EW);       // behind the first batch of region loads (memory returns in order)
+                if constexpr (PROJ) b3reg = a.b3[min(tid & 255, a.cout - 1)];
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) *reinterpret_cast<uint4*>(&Xs[dst[u]]) = v[u];
+                if (dst[u] >= 0) *reinterpret_cast<uint4*>(&Xs[dst[u]]) = ok[u] ? v[u] : make_uint4(one[u] ? 0x3c003c00u : 0u, 0, 0, 0);
+            if constexpr (PROJ) { if (i0 == tid && tid < 256) B3s[tid] = tid < a.cout ? b3reg : 0.f; }
         }
     }
-    // which of this lane's MFMA pixels (row r of every row tile) lie inside the image: bit rt
-    unsigned inside_bits = 0;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int pix = rt * 32 + r;
-        const int py = pix / IW, px = pix - py * IW;
-        const int gy = iy0 + py, gx = ix0 + px;
-        if (pix < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) inside_bits |= 1u << rt;
-    }
-    static_assert(RT <= 32, "row-tile mask is 32 bits");
     __syncthreads();
     XD_STAMP(1);
 
-    const int cg = tid & 7;                 // this thread's 8-channel group in the depthwise stage (NT % 8 == 0)
     // project stage (PROJ): wave = one (32-pixel row tile, 32-channel tile) unit of the [OH*OW][cout] output; its accumulator
     // lives across the chunk loop (the projection sums over all expanded channels)
     constexpr int PRT = DROWS / 32;
@@ -156,39 +188,69 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int z
     floatx16 pacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
-    for (int c0 = c_begin; c0 < c_end; c0 += 64) {
-        if (tid < K * K * 8) *reinterpret_cast<uint4*>(&Wd[(tid >> 3) * 64 + (tid & 7) * 8]) = wdreg;
-        if (tid < 64) Bd[tid] = bdreg;
+    for (int c0 = c_begin; c0 < c_end;) {
+        const bool wide = WIDE && c_end - c0 == EW;         // the last 72 channels in one go
+        const int cw = wide ? EW : 64, ng = cw >> 3;
+        {
+            const int wrow_i = tid / 9, wc8 = tid - wrow_i * 9;
+            const bool wok = tid < K * K * 9 && wc8 < ng && c0 + wc8 * 8 < cexp;
+            if (tid < K * K * 9) *reinterpret_cast<uint4*>(&Wd[wrow_i * EW + wc8 * 8]) = wok ? wdreg : make_uint4(0, 0, 0, 0);
+            if (tid < EW) Bd[tid] = (tid < cw && c0 + tid < cexp) ? bdreg : 0.f;
+        }
         // ---- 2. expand on the matrix cores. A = weight rows (channels), B = pixel rows: the accumulator then holds, per lane,
         //         pixel (lane & 31) and channels 8g + 4*(lane >> 5) .. +3 in registers 4g .. 4g+3.
         //         wave w: channel tile t = w & 1 of the chunk, row tiles (w >> 1), (w >> 1) + 4, ...
-        for (int rt = wave >> 1; EXP && rt < RT && c0 + t * 32 < cexp; rt += NT / 128) {
-            floatx16 acc;
+        if constexpr (EXP) {
+            const half8 wlast = last_frag(wl, b1v);
+            for (int rt = wave >> 1; rt < RT && c0 + t * 32 < cexp; rt += NT / 128) {
+                floatx16 acc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            const half_t* xrow = &Xs[(rt * 32 + r) * XW + hh * 8];
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                const half_t* xrow = &Xs[(rt * 32 + r) * XW + hh * 8];
 #pragma unroll
-            for (int ks = 0; ks < KSM; ++ks) {
-                if (ks < KS) {
-                    const half8 xf = *reinterpret_cast<const half8*>(xrow + ks * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf, acc, 0, 0, 0);
+                for (int ks = 0; ks < KSM; ++ks)
+                    if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
+                act_n<floatx16, 16>(acc, a.act1);
+                half_t* erow = &Es[(rt * 32 + r) * EW + t * 32 + 4 * hh];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[4 * g + e];
+                    *reinterpret_cast<half4*>(erow + 8 * g) = hv;
                 }
             }
-            const bool inside = (inside_bits >> rt) & 1u;
-            half_t* erow = &Es[(rt * 32 + r) * EW + t * 32 + 4 * hh];
+            if constexpr (WIDE) {
+                if (wide) {                                 // third channel tile: only its first 8 channels exist (columns 64..71)
+                    const half8 wlast2 = last_frag(wl2, b1v2);
+                    for (int rt = wave; rt < RT; rt += NT / 64) {
+                        floatx16 acc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                half4 hv = {0, 0, 0, 0};
-                if (inside) {
-                    hv[0] = (half_t)dn_act(acc[4 * g + 0] + bv[g].x, a.act1);
-                    hv[1] = (half_t)dn_act(acc[4 * g + 1] + bv[g].y, a.act1);
-                    hv[2] = (half_t)dn_act(acc[4 * g + 2] + bv[g].z, a.act1);
-                    hv[3] = (half_t)dn_act(acc[4 * g + 3] + bv[g].w, a.act1);
+                        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                        const half_t* xrow = &Xs[(rt * 32 + r) * XW + hh * 8];
+#pragma unroll
+                        for (int ks = 0; ks < KSM; ++ks)
+                            if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf2[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast2, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
+                        float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+                        act_n<float[4], 4>(v4, a.act1);
+                        half4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)v4[e];
+                        *reinterpret_cast<half4*>(&Es[(rt * 32 + r) * EW + 64 + 4 * hh]) = hv;
+                    }
                 }
-                *reinterpret_cast<half4*>(erow + 8 * g) = hv;
             }
         }
-        if (c0 + 64 < c_end) request_chunk(c0 + 64);       // lands under the depthwise stage
+        const int cnext = c0 + cw;
+        if (cnext < c_end) request_chunk(cnext, WIDE && c_end - cnext == EW);       // lands under the depthwise stage
+        if constexpr (PROJ) {
+            const int co = min(pc * 32 + r, a.cout - 1);
+#pragma unroll
+            for (int ks = 0; ks < (WIDE ? 5 : 4); ++ks)
+                w3f[ks] = *reinterpret_cast<const half8*>(a.w3 + (size_t)co * cexp + min(c0 + ks * 16 + hh * 8, cexp - 8));
+        }
         __syncthreads();
         if (c0 == c_begin) XD_STAMP(2);
 
@@ -196,9 +258,10 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int z
         float psum[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) psum[e] = 0.f;
-        const bool cvalid = c0 + cg * 8 < cexp;
-        for (int item = tid; cvalid && item < OH * OW * 8; item += NT) {
-            const int opix = item >> 3;
+        for (int item = tid; item < OH * OW * ng; item += NT) {
+            const int opix = (WIDE && wide) ? item / 9 : item >> 3;
+            const int cg = item - opix * ng;                 // (8 groups: the same group in every pass -- the pooled sums below rely on it)
+            if (c0 + cg * 8 >= cexp) continue;
             const int oy = opix / OW, ox = opix - oy * OW;
             float acc[8];
             {
@@ -214,17 +277,17 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int z
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
                     const uint4 ev = *reinterpret_cast<const uint4*>(ebase + (ky * IW + kx) * SW);
-                    const uint4 wv = *reinterpret_cast<const uint4*>(&Wd[(ky * K + kx) * 64 + cg * 8]);
+                    const uint4 wv = *reinterpret_cast<const uint4*>(&Wd[(ky * K + kx) * EW + cg * 8]);
                     fma_mix_h8(acc, ev, wv);
                 }
             const int gy = oy0 + oy, gx = ox0 + ox;
             if (PROJ || (gy < a.Ho && gx < a.Wo)) {
+                act_n<float[8], 8>(acc, a.act2);
                 half8 hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = dn_act(acc[e], a.act2);
-                    psum[e] += v;
-                    hv[e] = (half_t)v;
+                    psum[e] += acc[e];
+                    hv[e] = (half_t)acc[e];
                 }
                 if constexpr (PROJ) *reinterpret_cast<half8*>(&Ds[opix * EW + cg * 8]) = hv;     // B operand rows of the projection
                 else *reinterpret_cast<half8*>(a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * cexp + c0 + cg * 8) = hv;
@@ -254,24 +317,27 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int z
         }
         if constexpr (PROJ) {
             // channel groups of a partial last chunk that the depthwise stage skipped must read as zero
-            if (c0 + 64 > cexp)
+            if (c0 + cw > cexp)
                 for (int item = tid; item < DROWS * 8; item += NT)
                     if (c0 + (item & 7) * 8 >= cexp) *reinterpret_cast<uint4*>(&Ds[(item >> 3) * EW + (item & 7) * 8]) = make_uint4(0, 0, 0, 0);
             __syncthreads();
             if (punit) {
-                const int co = pc * 32 + r;
+                const bool cok = pc * 32 + r < a.cout;
+                const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int k = c0 + ks * 16 + hh * 8;
-                    half8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (co < a.cout && k < cexp) w = *reinterpret_cast<const half8*>(a.w3 + (size_t)co * cexp + k);
-                    const half8 df = *reinterpret_cast<const half8*>(&Ds[(prt * 32 + r) * EW + ks * 16 + hh * 8]);
+                for (int ks = 0; ks < (WIDE ? 5 : 4); ++ks) {
+                    if (ks == 4 && !wide) break;
+                    const bool ok = cok && c0 + ks * 16 + hh * 8 < cexp && ks * 16 + hh * 8 < cw;
+                    const half8 w = ok ? w3f[ks] : zero8;
+                    half8 df = *reinterpret_cast<const half8*>(&Ds[(prt * 32 + r) * EW + ks * 16 + hh * 8]);
+                    if (ks == 4) df = hh ? zero8 : df;      // columns 72..79 are the next row
                     pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, df, pacc, 0, 0, 0);
                 }
             }
         }
         __syncthreads();        // Es / Wd / Bd / Ps / Ds are rewritten by the next chunk
         if (c0 == c_begin) XD_STAMP(3);
+        c0 = cnext;
     }
     if constexpr (PROJ) {
         // lane = output pixel (row tile prt, row r), registers 4g..4g+3 = channels pc*32 + 8g + 4hh .. +3
@@ -280,15 +346,14 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int z
         const int gy = oy0 + oy, gx = ox0 + ox;
         if (punit && opix < OH * OW && gy < a.Ho && gx < a.Wo) {
             half_t* orow = a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * a.cout;
-            const half_t* xrow = a.x + (((size_t)n * a.H + gy) * a.W + gx) * cin;      // residual (stride 1, cout == cin)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = pc * 32 + 8 * g + 4 * hh;
                 if (c < a.cout) {           // cout % 8 == 0: the 4-channel group is entirely in range
-                    const float4 b = *reinterpret_cast<const float4*>(a.b3 + c);
+                    const float4 b = *reinterpret_cast<const float4*>(&B3s[c]);
                     float v[4] = {pacc[4 * g + 0] + b.x, pacc[4 * g + 1] + b.y, pacc[4 * g + 2] + b.z, pacc[4 * g + 3] + b.w};
-                    if (a.has_res) {
-                        const half4 rr = *reinterpret_cast<const half4*>(xrow + c);
+                    if (a.has_res) {        // residual (stride 1, cout == cin): the block's input at the same pixel
+                        const half4 rr = *reinterpret_cast<const half4*>(&Xs[((oy * S + a.pad) * IW + ox * S + a.pad) * XW + c]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
                     }
@@ -303,13 +368,12 @@ __global__ __launch_bounds__(NT) void expdw_kernel(ExpDwArgs a, int tiles, int z
     XD_STAMP(4);
 }
 
-template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ>
-int launch_k(const ExpDwArgs& a, dim3 grid3, size_t lds, hipStream_t s) {
-    const int tiles = grid3.x, zsplit = grid3.z;
-    const dim3 grid((unsigned)tiles * zsplit * (a.xq > 0 ? 8 * a.xq : a.n));
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>)));
+template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8>
+int launch_k(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
+    const dim3 grid(a.xq > 0 ? 8 * tiles_x : tiles_x, tiles_y * zsplit, a.xq > 0 ? a.xq : a.n);
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8>)));
     dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
-    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ>), grid, dim3(NT), lds, s, a, tiles, zsplit);
+    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
     return DN_OK;
 }
 
@@ -319,27 +383,31 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     ExpDwArgs a = a0;
     const bool proj = a.w3 != nullptr, exp = a.w1 != nullptr;
     constexpr int DROWS = (OH * OW + 31) / 32 * 32;
-    const size_t lds = ((size_t)G::ROWS * a.xw + (exp ? (size_t)G::ROWS * EW : 0) + K * K * 64 + (proj ? (size_t)DROWS * EW : 0)) * sizeof(half_t) +
-                       (64 + NT / 64 * 64) * sizeof(float);
+    const size_t lds = ((size_t)G::ROWS * a.xw + 8 + (exp ? (size_t)G::ROWS * EW : 0) + K * K * EW + (proj ? (size_t)DROWS * EW : 0)) * sizeof(half_t) +
+                       (EW + NT / 64 * 64 + (proj ? 256 : 0)) * sizeof(float);
     DN_REQUIRE(lds <= 160 * 1024, "expand+depthwise: LDS %zu B exceeds 160 KB", lds);
-    // split the 64-channel chunks over grid.z until there are enough workgroups to fill the chip a few times over
+    // split the 64-channel chunks over grid.y until there are enough workgroups to fill the chip a few times over
     // (not with a project stage: it sums over all chunks inside the workgroup)
-    const int tiles = dn_cdiv(a.Ho, OH) * dn_cdiv(a.Wo, OW), chunks = dn_cdiv(a.cexp, 64);
+    const int tiles_x = dn_cdiv(a.Wo, OW), tiles_y = dn_cdiv(a.Ho, OH), tiles = tiles_x * tiles_y, chunks = dn_cdiv(a.cexp, 64);
     const int want = dn_knob("DN_EXPDW_WGS", 1024);
     int cpw = chunks;
     while (!proj && cpw > 1 && (long)tiles * a.n * dn_cdiv(chunks, cpw) < want) --cpw;
     a.chunks_per_wg = cpw;
     a.stamps = g_xd_stamps;
-    const dim3 grid(tiles, a.n, dn_cdiv(chunks, cpw));
+    const int zsplit = dn_cdiv(chunks, cpw);
+    DN_REQUIRE((long)tiles_y * zsplit <= 65535 && a.n <= 65535, "expand+depthwise: grid too large");
     if (proj) DN_REQUIRE((DROWS / 32) * dn_cdiv(a.cout, 32) <= NT / 64, "expand+depthwise+project: %d output units for %d waves", (DROWS / 32) * dn_cdiv(a.cout, 32), NT / 64);
-    // the A fragments of the expand live in registers: 2 K steps cover cin <= 32 (fewer registers -> more waves), else 8
-    if (!exp) return proj ? launch_k<K, S, OH, OW, 2, false, true>(a, grid, lds, s) : DN_E_UNSUPPORTED;
+    // the A fragments of the expand live in registers: 2 full K steps + the tail/bias step cover cin <= 40 (fewer registers -> more
+    // waves), else 8. The block shapes of the backbones (cin 16 / 24 + project) get compile-time X row widths.
+    if (!exp) return proj ? launch_k<K, S, OH, OW, 2, false, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s) : DN_E_UNSUPPORTED;
     if (proj) {
-        if (a.cin <= 32) return launch_k<K, S, OH, OW, 2, true, true>(a, grid, lds, s);
-        return launch_k<K, S, OH, OW, XKS, true, true>(a, grid, lds, s);
+        if (a.xw == 24) return launch_k<K, S, OH, OW, 2, true, true, 3>(a, tiles_x, tiles_y, zsplit, lds, s);
+        if (a.xw == 40 && a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, true, 5>(a, tiles_x, tiles_y, zsplit, lds, s);
+        if (a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
+        return launch_k<K, S, OH, OW, XKS, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
     }
-    if (a.cin <= 32) return launch_k<K, S, OH, OW, 2, true, false>(a, grid, lds, s);
-    return launch_k<K, S, OH, OW, XKS, true, false>(a, grid, lds, s);
+    if (a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, false, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
+    return launch_k<K, S, OH, OW, XKS, true, false, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
 }
 
 template <int K, int S>

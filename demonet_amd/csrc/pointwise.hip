@@ -889,6 +889,7 @@ int launch_pointwise(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.cin % 8 == 0, "pointwise: cin=%d must be a multiple of 8", a.cin);
     DN_REQUIRE(a.out_fp32 || a.cout % 4 == 0, "pointwise: fp16 cout=%d must be a multiple of 4", a.cout);
     DN_REQUIRE(a.m > 0 && a.hw > 0, "pointwise: empty problem");
+    if (!g_pw_tile && pw_direct_supported(a)) return launch_pw_direct(a, s);
     const int xs_mode = dn_knob("DN_PW_XS", 1);
     if (g_pw_tile == 8 && a.wfrag) return launch_xs<32>(a, s);
     if (xs_mode && !g_pw_tile && !a.sef_part && a.wfrag && a.cin % 16 == 0 && a.cin <= 1024 && a.cout <= 160 && !(a.act >> 8) &&      // (K % 16 == 8: measured slower than the tiled kernel)

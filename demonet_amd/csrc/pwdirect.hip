@@ -1,0 +1,213 @@
+// Pointwise (1x1) convolution for short reductions (cin <= 256), register-direct: no LDS, no barriers.
+//
+// reference ops replaced: the expand / project ConvBNActivation 1x1 convs of InvertedResidual (mobilenetv3.py:72-95, BN folded),
+//   the 1x1 convs of _extra_block (ssd_mobilenetv3.py:39-54) and of the V2 ExtraBlocks (backbone.py:100-111) -- the same layers
+//   pointwise.hip's tiled kernel serves; this file is only a different schedule for them.
+//
+// Why: on these layers the tiled kernel is not bound by HBM or by the matrix cores but by VALU issue (tools/valu.sh: ~400 vector
+// instructions per wave for 1024 outputs -- staging addresses, guards, the LDS round trips of operands and of the output tile, a
+// bias add and an activation select per element; a wave64 VALU instruction holds its SIMD for 4 cycles). Here a wave owns 32
+// pixels x (32 * TC) channels and
+//   * both MFMA operands go from global memory / L2 straight into registers in fragment order (lane (r, hh) of
+//     v_mfma_f32_32x32x16_f16 needs 16 contiguous bytes of row r: one global_load_dwordx4 with an immediate offset per K step,
+//     every load of the wave requested before the first use -- ONE exposed memory round trip);
+//   * the bias rides in the reduction: two extra K columns hold (1, 1) on the pixel side and (hi, lo) = the fp32 bias split into
+//     two fp16 values on the weight side (|b - hi - lo| <= 2^-22 |b|), so the accumulator starts life as conv + bias;
+//   * the activation is ONE uniform switch per 16-value accumulator, not a select per element;
+//   * v_permlane32_swap turns the accumulator layout (4 channels per lane and register group) into 16 contiguous channels per
+//     lane: the tile leaves as two 16-byte stores per lane, 64 contiguous bytes per pixel, without an LDS transpose.
+// The residual (fp16, NHWC) is requested up front in the accumulator layout and added in fp32 before the single rounding
+// (mobilenetv3.py:97-99 computes act(conv + bias) + x).
+#include "common.h"
+
+namespace {
+
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void act16(floatx16& v, int act) {
+    if (act == DN_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (act == DN_ACT_RELU6) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+    } else if (act == DN_ACT_HSWISH) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+}
+
+// KSM: 16-deep K steps held in registers (cin <= 16 * KSM); TC: 32-channel tiles per wave.
+// Workgroup = 4 waves = (4 >> wc_log) row tiles of 32 pixels x (1 << wc_log) channel blocks of 32 * TC channels.
+template <int KSM, int TC>
+__global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int wc_log) {
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wc = wave & ((1 << wc_log) - 1), wp = wave >> wc_log;
+    const int BP = 32 * (4 >> wc_log), BC = (32 * TC) << wc_log;
+    const int K = a.cin, NC = a.cout;
+    // row tile / channel block of this workgroup; XCD grouping as in pointwise.hip (pw_tile_rows): the workgroups with equal
+    // (flat index % 8) own the rows of one group of a.xq images
+    int m0, mend, by;
+    {
+        const int flat = blockIdx.x;
+        if (a.xq > 0) {
+            const int g = flat & 7, w = flat >> 3;
+            by = w / tiles;
+            const int t = w - by * tiles;
+            const int r0 = g * a.xq * a.hw;
+            mend = min(a.m, r0 + a.xq * a.hw);
+            m0 = r0 + t * BP;
+        } else {
+            by = flat / tiles;
+            m0 = (flat - by * tiles) * BP;
+            mend = a.m;
+        }
+    }
+    const int mrow0 = m0 + wp * 32;
+    const int n_base = by * BC + wc * 32 * TC;
+    if (mrow0 >= mend || n_base >= NC) return;            // wave-uniform
+    const int row = mrow0 + r;
+    const int rowc = min(row, mend - 1);
+    const int KSF = K >> 4;                                 // full 16-deep steps; then ONE last step: the K tail (cin % 16 == 8) and the bias columns
+
+    // ---- every load of the wave, up front
+    const half_t* xp = a.x + (size_t)rowc * K + hh * 8;
+    const half_t* wpt[TC];
+    int nrow[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        nrow[i] = min(n_base + i * 32 + r, NC - 1);
+        wpt[i] = a.w + (size_t)nrow[i] * K + hh * 8;
+    }
+    half8 xf[KSM], wf[TC][KSM];
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+        if (ks < KSF) {
+            xf[ks] = *reinterpret_cast<const half8*>(xp + ks * 16);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i][ks] = *reinterpret_cast<const half8*>(wpt[i] + ks * 16);
+        }
+    }
+    // last step: this lane's columns kb .. kb+7; kb < K: data (address clamped, value selected below); kb == K: the bias columns
+    const int kb = KSF * 16 + hh * 8;
+    const int kcl = min(kb, K - 8) - hh * 8;
+    half8 xl = *reinterpret_cast<const half8*>(xp + kcl);
+    half8 wl[TC];
+    float bl[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        wl[i] = *reinterpret_cast<const half8*>(wpt[i] + kcl);
+        bl[i] = a.bias[nrow[i]];
+    }
+    uint2 rres[TC][4];
+    const bool has_res = a.residual != nullptr;
+    if (has_res) {
+        const half_t* rp = a.residual + (size_t)rowc * NC;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                rres[i][g] = *reinterpret_cast<const uint2*>(rp + min(n_base + i * 32 + 8 * g + 4 * hh, NC - 4));
+    }
+    {
+        const bool data = kb < K, bcol = kb == K;
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const half8 ones = {(half_t)1.f, (half_t)1.f, 0, 0, 0, 0, 0, 0};
+        xl = data ? xl : (bcol ? ones : zero8);
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const half_t hi = (half_t)bl[i];
+            const half_t lo = (half_t)(bl[i] - (float)hi);
+            const half8 bw = {hi, lo, 0, 0, 0, 0, 0, 0};
+            wl[i] = data ? wl[i] : (bcol ? bw : zero8);
+        }
+    }
+
+    // ---- the reduction
+    floatx16 acc[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+        if (ks < KSF) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][ks], xf[ks], acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xl, acc[i], 0, 0, 0);
+
+    // ---- epilogue: lane = pixel r; registers 4g .. 4g+3 of tile i = channels n_base + 32 i + 8g + 4hh .. +3
+    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 16;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int nt = n_base + i * 32;
+        if (nt >= NC) break;                               // wave-uniform
+        act16(acc[i], a.act);
+        if (has_res) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half4 rr = __builtin_bit_cast(half4, rres[i][g]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][4 * g + e] += (float)rr[e];
+            }
+        }
+        uint2v p[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[i][4 * g + e];
+            p[g] = __builtin_bit_cast(uint2v, hv);
+        }
+        // lanes r / r + 32 hold the two halves of every 8-channel group of pixel r: swap so that lane r ends up with channels
+        // 0..15 and lane r + 32 with channels 16..31 of the tile (v_permlane32_swap: upper half of the first operand <-> lower half of the second)
+        uint4 lo4, hi4;
+        {
+            const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[2][0], false, false);
+            const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[2][1], false, false);
+            const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[1][0], p[3][0], false, false);
+            const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[1][1], p[3][1], false, false);
+            lo4 = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            hi4 = make_uint4(s2[0], s3[0], s2[1], s3[1]);
+        }
+        const int c0 = nt + hh * 16;
+        if (row < mend) {
+            if (c0 < NC) *reinterpret_cast<uint4*>(orow + nt) = lo4;
+            if (c0 + 8 < NC) *reinterpret_cast<uint4*>(orow + nt + 8) = hi4;
+        }
+    }
+}
+
+template <int KSM, int TC>
+int launch_t(const PwArgs& a, int wc_log, hipStream_t s) {
+    const int BP = 32 * (4 >> wc_log), BC = (32 * TC) << wc_log;
+    const int tiles = a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, BP) : dn_cdiv(a.m, BP);
+    const dim3 grid((unsigned)(a.xq > 0 ? 8 * tiles : tiles) * dn_cdiv(a.cout, BC));
+    dn_note_kernel("pw_direct_kernel<%d,%d>", KSM, TC);
+    hipLaunchKernelGGL((pw_direct_kernel<KSM, TC>), grid, dim3(256), 0, s, a, tiles, wc_log);
+    return DN_OK;
+}
+
+}  // namespace
+
+bool pw_direct_supported(const PwArgs& a) {
+    return dn_knob("DN_PW_DIRECT", 1) != 0 && a.cv_k == 1 && !a.out_fp32 && !a.se && !a.sef_part && !a.w_b && a.cin % 8 == 0 && a.cin >= 8 &&
+           a.cin <= 256 && a.cout % 8 == 0 && a.cout >= 8 && !(a.act >> 8) && a.out_img_stride == 0 && a.out_base == 0;
+}
+
+int launch_pw_direct(const PwArgs& a, hipStream_t s) {
+    DN_REQUIRE(pw_direct_supported(a), "pointwise (direct): unsupported cin=%d cout=%d", a.cin, a.cout);
+    // One 32-channel tile per wave (TC = 1): measured faster than two on every layer of the SSDLite chains -- these launches
+    // are latency-bound, and twice the waves with half the registers overlap their single memory round trip better. The channel
+    // block of a workgroup is as wide as the layer needs, up to 128 (the 4 waves then share the x rows in L1).
+    const int ctiles = dn_cdiv(a.cout, 32);
+    const int wc_log = ctiles <= 1 ? 0 : ctiles <= 2 ? 1 : 2;
+    const int ksf = a.cin >> 4;
+    if (ksf <= 4) return launch_t<4, 1>(a, wc_log, s);
+    if (ksf <= 8) return launch_t<8, 1>(a, wc_log, s);
+    return launch_t<16, 1>(a, wc_log, s);
+}

@@ -27,9 +27,9 @@ for (h, cin, cexp, k, s) in SHAPES:
     for i in range(10): call(i)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
-    st = torch.zeros(8 * 200000, dtype=torch.int64, device="cuda")
+    st = torch.zeros(16 * 200000, dtype=torch.int64, device="cuda")
     L.dn_debug_expdw_stamps(C.c_void_p(st.data_ptr())); call(0); torch.cuda.synchronize(); L.dn_debug_expdw_stamps(None)
-    t = st.cpu().numpy().reshape(-1, 8)[:, :5].astype(np.float64)
+    t = st.cpu().numpy().reshape(-1, 16)[:, :5].astype(np.float64)
     t = t[t[:, 0] > 0]
     d = np.diff(t, axis=1) * 0.01
     mb = N * (h * h * cin + ho * ho * cexp) * 2 / 1e6

@@ -27,10 +27,17 @@ for (h, cin, cexp, cout, k, s, res) in SHAPES:
     for i in range(10): call(i)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
-    st = torch.zeros(8 * 200000, dtype=torch.int64, device="cuda")
+    st = torch.zeros(16 * 200000, dtype=torch.int64, device="cuda")
     L.dn_debug_expdw_stamps(C.c_void_p(st.data_ptr())); call(0); torch.cuda.synchronize(); L.dn_debug_expdw_stamps(None)
-    t = st.cpu().numpy().reshape(-1, 8)[:, :5].astype(np.float64)
-    t = t[t[:, 0] > 0]
+    full = st.cpu().numpy().reshape(-1, 16).astype(np.float64)
+    full = full[full[:, 0] > 0]
+    t = full[:, :5]
+    order = [0, 5, 6, 7, 8, 1, 9, 10, 2, 11, 12, 13, 3, 4]
+    names = ['start', 'loads issued', 'loads landed', 'lds written', 'inside bits', 'BARRIER', 'chunk top', 'expand done', 'BARRIER', 'dw done', 'BARRIER(Ds)', 'proj done', 'BARRIER', 'end']
+    if full[:, 5].max() > 0:
+        seq = full[:, order]
+        dd = np.diff(seq, axis=1) * 0.01
+        print('   fine (wave 0): ' + '  '.join(f'{names[i + 1]} +{dd[:, i].mean():.2f}' for i in range(dd.shape[1])))
     d = np.diff(t, axis=1) * 0.01
     print(f"{h:3d}x{h:<3d} {cin:3d}->{cexp:3d}->{cout} k{k}s{s}: {us:6.1f} us/launch WGs {len(t):5d} | stage-x {d[:,0].mean():5.2f} "
           f"expand(1st chunk) {d[:,1].mean():5.2f} dw+proj(1st chunk) {d[:,2].mean():5.2f} rest {d[:,3].mean():5.2f} | life {d.sum(1).mean():5.2f} "
