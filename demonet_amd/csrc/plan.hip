@@ -109,9 +109,15 @@ struct dn_plan {
     bool multi_stream = false;
     int split = 2;                          // sub-batch branches per forward (see batch_split)
     bool ws_reuse = true;                   // DN_WS_REUSE=0: one private block per tensor (every intermediate stays readable after the forward)
-    bool chain_graphs = false;              // DN_CHAIN_GRAPHS=1: one single-chain graph per sub-batch on its own stream (default: branches of ONE graph)
+    int chain_graphs = -1;                  // DN_CHAIN_GRAPHS: 1 = one single-chain graph per sub-batch on its own stream, 0 = branches of ONE graph, -1 = by batch size
     bool xcd = true;                        // XCD grouping of every kernel's workgroups by image (common.h; DN_XCD, read in dn_create)
     hipStream_t branch_stream[3] = {nullptr, nullptr, nullptr};
+    // early heads: the head launches of the first `head_early` pyramid levels leave the chain as soon as their feature map exists
+    // and run on a side stream of the chain (a parallel branch of the graph) while the backbone goes on; joined before the post-process
+    int head_early = 0;
+    int head_fork_op = -1;                  // op whose output is the last early level's feature map
+    hipStream_t head_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_head_fork[4] = {}, ev_head_join[4] = {};
     hipEvent_t ev_fork = nullptr, ev_branch[3] = {nullptr, nullptr, nullptr};
     std::map<std::pair<int, int>, Layout> sub_layouts;
     float* packed_out = nullptr;
@@ -224,6 +230,13 @@ static const Layout& get_layout(dn_plan* p, int n) {
             dies[o.out] = std::max(dies[o.out], when[i]);
             if (o.pool >= 0) { if (born[o.pool] < 0) born[o.pool] = when[i]; dies[o.pool] = std::max(dies[o.pool], when[i]); }
         }
+        if (p->head_early > 0 && p->head_fork_op >= 0)
+            // early head launches run beside the backbone from the fork on: what they write must not alias anything alive there
+            for (int i = p->head_first; i < NO; ++i) {
+                const dn_op_desc& o = p->ops[i];
+                const int lv = o.head ? o.level : p->op_wait_level[i];
+                if (lv >= 0 && lv < p->head_early && born[o.out] >= 0) born[o.out] = std::min(born[o.out], when[p->head_fork_op]);
+            }
         const int t_end = NO + 2;
         for (int l = 0; l < p->d.n_levels; ++l) dies[p->d.level_tensor[l]] = t_end;      // read back by tests / callers after the forward
         struct Blk { size_t off, bytes; int born, dies; };
@@ -330,7 +343,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
                 expdw_supported(a.cin, a.cout, d.k, d.stride)) {
                 const dn_tensor_desc& to = p->tensors[d.out];
                 if (to.h * to.w > max_hw || to.h * to.w < min_hw) continue;
-                if (i + 2 < desc->n_ops && a.cin <= 32 && proj_ok(p->ops[i + 2], d, a.in)) {
+                if (i + 2 < desc->n_ops && a.cin <= dn_knob("DN_EXPDW_PROJ_MAXCIN", 32) && proj_ok(p->ops[i + 2], d, a.in)) {
                     p->fused_len[i] = 3; p->fused_kind[i] = 3; i += 2;
                 } else {
                     p->fused_len[i] = 2; p->fused_kind[i] = 1; i += 1;
@@ -546,9 +559,32 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     }
     p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
     p->xcd = getenv("DN_XCD") ? atoi(getenv("DN_XCD")) != 0 : true;
-    p->chain_graphs = dn_knob("DN_CHAIN_GRAPHS", 0) != 0;
+    p->chain_graphs = dn_knob("DN_CHAIN_GRAPHS", -1);      // -1: auto (forward_impl)
     p->ws_reuse = dn_knob("DN_WS_REUSE", 1) != 0 && !p->multi_stream;      // (head chains on side streams overlap the backbone: no reuse)
     p->split = getenv("DN_SPLIT") ? atoi(getenv("DN_SPLIT")) : 2;
+    {
+        // early heads (DN_HEAD_EARLY = number of leading levels, default 0 = off): level 0 carries ~85 % of the head work of the SSDLite
+        // models and its feature map exists two thirds into the backbone; its two launches could overlap the rest of the chain
+        // instead of extending it. MEASURED and left off: a fork inside a chain's graph costs far more than the ~80 us of head
+        // launches it hides -- batch 64: 1.13 -> 1.44 ms (level 0), 1.33 ms (levels 0-1); batch 32: 0.78 -> 1.13 ms. (A fork inside
+        // a forked branch of one graph also crashes hipStreamEndCapture on ROCm 7.2, hence per-chain graphs in this mode.)
+        const int want = dn_knob("DN_HEAD_EARLY", 0);
+        p->head_early = 0;
+        p->head_fork_op = -1;
+        if (want > 0 && want < desc->n_levels && p->head_first >= 0 && !p->multi_stream) {
+            int fo = -1;
+            bool ok = true;
+            for (int l = 0; l < want && ok; ++l) {
+                int prod = -1;
+                for (int i = 0; i < p->head_first; ++i) if (p->ops[i].out == desc->level_tensor[l]) prod = i;
+                ok = prod >= 0;
+                fo = std::max(fo, prod);
+            }
+            if (ok && p->tail_first >= 0 && fo >= p->tail_first) ok = false;        // produced inside the tail launch: nothing left to overlap
+            if (ok && fo + 1 >= p->head_first) ok = false;
+            if (ok) { p->head_early = want; p->head_fork_op = fo; }
+        }
+    }
     if (p->split < 1) p->split = 1;
     if (p->split > 4) p->split = 4;
     // anchor offsets per level
@@ -581,6 +617,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->branch_stream[i], hipStreamNonBlocking);
     for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_branch[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_head_fork[i], hipEventDisableTiming);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_head_join[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         dn_set_error("dn_create: stream/event creation failed: %s", hipGetErrorString(e));
         return fail(DN_E_HIP);
@@ -601,6 +640,9 @@ extern "C" void dn_destroy(dn_plan* p) {
     for (int i = 0; i < 3; ++i) if (p->branch_stream[i]) (void)hipStreamDestroy(p->branch_stream[i]);
     for (int i = 0; i < 3; ++i) if (p->ev_branch[i]) (void)hipEventDestroy(p->ev_branch[i]);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    for (int i = 0; i < 4; ++i) if (p->head_stream[i]) (void)hipStreamDestroy(p->head_stream[i]);
+    for (int i = 0; i < 4; ++i) if (p->ev_head_fork[i]) (void)hipEventDestroy(p->ev_head_fork[i]);
+    for (int i = 0; i < 4; ++i) if (p->ev_head_join[i]) (void)hipEventDestroy(p->ev_head_join[i]);
     for (auto ev : p->events) (void)hipEventDestroy(ev);
     if (p->weights_dev) (void)hipFree(p->weights_dev);
     if (p->anchors_dev) (void)hipFree(p->anchors_dev);
@@ -654,7 +696,7 @@ static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
 // ---------------------------------------------------------------------------------------------------------
 static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
                    int32_t* counts, unsigned char* ws, const Layout& L, bool heads_only, hipStream_t s, bool record,
-                   float* packed, int ev0 = 0) {
+                   float* packed, int ev0 = 0, int chain = 0) {
     const dn_model_desc& d = p->d;
     auto tptr = [&](int tid) -> void* { return ws + L.toff[tid]; };
     const float* net_in = images;
@@ -756,6 +798,103 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     };
     int ev = ev0;
     hipStream_t const main_stream = s;
+    const bool branch = !record && p->head_early > 0 && p->head_fork_op >= 0 && chain >= 0 && chain < 4;
+    bool forked = false;
+    // head launches of the pyramid levels [lv0, lv1): the depthwise group, then the 1x1 / dense group(s), on stream hs
+    auto launch_heads = [&](int lv0, int lv1, hipStream_t hs, bool rec, size_t& seg) -> int {
+        int rc = DN_OK;
+        auto hnote = [&](size_t op, size_t owner) {
+            if (!rec) return;
+            p->prof_kernel[op] = dn_last_kernel();
+            p->prof_owner[op] = (int)owner;
+        };
+        std::vector<int> h_dw, h_cls, h_reg;
+        for (int q : p->head_dw) if (p->op_wait_level[q] >= lv0 && p->op_wait_level[q] < lv1) h_dw.push_back(q);
+        for (int q : p->head_cls) if (p->ops[q].level >= lv0 && p->ops[q].level < lv1) h_cls.push_back(q);
+        for (int q : p->head_reg) if (p->ops[q].level >= lv0 && p->ops[q].level < lv1) h_reg.push_back(q);
+        if (!h_dw.empty()) {
+            DwArgs arr[12];
+            for (size_t q = 0; q < h_dw.size(); ++q) arr[q] = make_dw(p->ops[h_dw[q]]);
+            rc = launch_depthwise_group(arr, (int)h_dw.size(), hs);
+            if (rc != DN_OK) return rc;
+            for (int q : h_dw) hnote(q, seg);
+            ++seg;
+            if (rec) (void)hipEventRecord(p->events[ev++], hs);
+        }
+        // box and class heads of all levels in ONE launch when they fit (a dependent launch costs ~4.5 us even when empty, and
+        // the narrow box heads then share the class heads' tile instead of running as a launch of their own)
+        const bool merge_heads = dn_knob("DN_HEAD_MERGE", 1) != 0;
+        const bool one = merge_heads && !h_reg.empty() && !h_cls.empty() && h_reg.size() + h_cls.size() <= 12 &&
+                         p->ops[h_reg[0]].type == p->ops[h_cls[0]].type;
+        for (int kind = 0; kind < 2; ++kind) {
+            std::vector<int> lst = kind ? h_cls : h_reg;
+            if (one) {
+                if (kind == 1) break;
+                lst.insert(lst.end(), h_cls.begin(), h_cls.end());
+            }
+            if (lst.empty()) continue;
+            PwArgs arr[12];
+            const bool conv = p->ops[lst[0]].type == DN_OP_CONV;
+            int cnt = 0;
+            std::vector<int> grouped;
+            std::set<int> taken;
+            // wide heads first, so that a box head that rides along is known before the groups are formed
+            std::stable_sort(lst.begin(), lst.end(), [&](int x, int y) { return p->ops[x].cout > p->ops[y].cout; });
+            for (size_t q = 0; q < lst.size(); ++q) {
+                PwArgs pa = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
+                if (conv && taken.count(lst[q])) continue;          // rides in another head's launch
+                if (conv && conv_head_big_supported(pa)) {
+                    // the wide dense heads of the large levels: MFMA-bound, each on the run-staged 256x256 tile. The box head of the
+                    // same level (same input, 16 / 24 channels) fits in the idle part of its last channel tile.
+                    int rider = -1;
+                    for (size_t u = 0; u < lst.size() && rider < 0; ++u) {
+                        const dn_op_desc &ou = p->ops[lst[u]], &oq = p->ops[lst[q]];
+                        if (u != q && !taken.count(lst[u]) && ou.in == oq.in && ou.type == oq.type && ou.k == oq.k && ou.stride == oq.stride &&
+                            ou.pad == oq.pad && ou.dil == oq.dil && ou.act == oq.act && ou.cout < oq.cout &&
+                            dn_cdiv(oq.cout + ou.cout, 256) == dn_cdiv(oq.cout, 256))
+                            rider = (int)u;
+                    }
+                    if (rider >= 0) {
+                        const PwArgs pb = conv_to_pw(make_conv(p->ops[lst[rider]]));
+                        pa.w_b = pb.w; pa.bias_b = pb.bias; pa.out_b = pb.out; pa.cout_b = pb.cout;
+                        pa.out_b_img_stride = pb.out_img_stride; pa.out_b_base = pb.out_base;
+                        taken.insert(lst[rider]);
+                    }
+                    rc = launch_conv_head_big(pa, hs);
+                    if (rc != DN_OK) return rc;
+                    hnote(lst[q], seg);
+                    if (rider >= 0) hnote(lst[rider], seg);
+                    ++seg;
+                    if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
+                    continue;
+                }
+                arr[cnt++] = pa;
+                grouped.push_back(lst[q]);
+            }
+            if (cnt == 0) continue;
+            // once the wide heads have left, the narrow box heads (16 / 24 channels) would pay the wide tile of the remaining
+            // class heads: dense-conv groups are split into a narrow and a wide launch
+            const bool split_narrow = conv && cnt < (int)lst.size();
+            for (int pass = 0; pass < (split_narrow ? 2 : 1); ++pass) {
+                PwArgs sub[12];
+                std::vector<int> ids;
+                int nsub = 0;
+                for (int q = 0; q < cnt; ++q) {
+                    const bool narrow = arr[q].cout <= 32;
+                    if (split_narrow && narrow != (pass == 0)) continue;
+                    sub[nsub++] = arr[q];
+                    ids.push_back(grouped[q]);
+                }
+                if (nsub == 0) continue;
+                rc = launch_pointwise_group(sub, nsub, conv, hs);
+                if (rc != DN_OK) return rc;
+                for (int q : ids) hnote(q, seg);
+                ++seg;
+                if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
+            }
+        }
+        return DN_OK;
+    };
     const bool ms = p->multi_stream && !record;
     bool side_used[2] = {false, false};
     for (size_t i = 0; i < p->ops.size(); ++i) {
@@ -777,90 +916,24 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             p->prof_kernel[op] = dn_last_kernel();
             p->prof_owner[op] = (int)owner;
         };
+        if (branch && !forked && (int)i > p->head_fork_op && (int)i < p->head_first) {
+            // the early levels' feature maps exist: their head launches leave the chain here
+            DN_HIP_CHECK(hipEventRecord(p->ev_head_fork[chain], main_stream));
+            DN_HIP_CHECK(hipStreamWaitEvent(p->head_stream[chain], p->ev_head_fork[chain], 0));
+            size_t seg_side = 0;
+            int hrc = launch_heads(0, p->head_early, p->head_stream[chain], false, seg_side);
+            if (hrc != DN_OK) return hrc;
+            forked = true;
+        }
         if ((int)i == p->head_first) {
             // all remaining ops are head ops of the pyramid levels: three grouped launches instead of up to 28.
             // Profiling: the three launches take the event segments of ops i, i+1, i+2 (prof_owner maps members to them).
             size_t seg = i;
-            if (!p->head_dw.empty()) {
-                DwArgs arr[12];
-                for (size_t q = 0; q < p->head_dw.size(); ++q) arr[q] = make_dw(p->ops[p->head_dw[q]]);
-                rc = launch_depthwise_group(arr, (int)p->head_dw.size(), s);
-                if (rc != DN_OK) return rc;
-                for (int q : p->head_dw) note(q, seg);
-                ++seg;
-                if (record) (void)hipEventRecord(p->events[ev++], s);
-            }
-            // box and class heads of all levels in ONE launch when they fit (a dependent launch costs ~4.5 us even when empty, and
-            // the narrow box heads then share the class heads' tile instead of running as a launch of their own)
-            const bool merge_heads = dn_knob("DN_HEAD_MERGE", 1) != 0;
-            const bool one = merge_heads && !p->head_reg.empty() && !p->head_cls.empty() && p->head_reg.size() + p->head_cls.size() <= 12 &&
-                             p->ops[p->head_reg[0]].type == p->ops[p->head_cls[0]].type;
-            for (int kind = 0; kind < 2; ++kind) {
-                std::vector<int> lst = kind ? p->head_cls : p->head_reg;
-                if (one) {
-                    if (kind == 1) break;
-                    lst.insert(lst.end(), p->head_cls.begin(), p->head_cls.end());
-                }
-                if (lst.empty()) continue;
-                PwArgs arr[12];
-                const bool conv = p->ops[lst[0]].type == DN_OP_CONV;
-                int cnt = 0;
-                std::vector<int> grouped;
-                std::set<int> taken;
-                // wide heads first, so that a box head that rides along is known before the groups are formed
-                std::stable_sort(lst.begin(), lst.end(), [&](int x, int y) { return p->ops[x].cout > p->ops[y].cout; });
-                for (size_t q = 0; q < lst.size(); ++q) {
-                    PwArgs pa = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
-                    if (conv && taken.count(lst[q])) continue;          // rides in another head's launch
-                    if (conv && conv_head_big_supported(pa)) {
-                        // the wide dense heads of the large levels: MFMA-bound, each on the run-staged 256x256 tile. The box head of the
-                        // same level (same input, 16 / 24 channels) fits in the idle part of its last channel tile.
-                        int rider = -1;
-                        for (size_t u = 0; u < lst.size() && rider < 0; ++u) {
-                            const dn_op_desc &ou = p->ops[lst[u]], &oq = p->ops[lst[q]];
-                            if (u != q && !taken.count(lst[u]) && ou.in == oq.in && ou.type == oq.type && ou.k == oq.k && ou.stride == oq.stride &&
-                                ou.pad == oq.pad && ou.dil == oq.dil && ou.act == oq.act && ou.cout < oq.cout &&
-                                dn_cdiv(oq.cout + ou.cout, 256) == dn_cdiv(oq.cout, 256))
-                                rider = (int)u;
-                        }
-                        if (rider >= 0) {
-                            const PwArgs pb = conv_to_pw(make_conv(p->ops[lst[rider]]));
-                            pa.w_b = pb.w; pa.bias_b = pb.bias; pa.out_b = pb.out; pa.cout_b = pb.cout;
-                            pa.out_b_img_stride = pb.out_img_stride; pa.out_b_base = pb.out_base;
-                            taken.insert(lst[rider]);
-                        }
-                        rc = launch_conv_head_big(pa, s);
-                        if (rc != DN_OK) return rc;
-                        note(lst[q], seg);
-                        if (rider >= 0) note(lst[rider], seg);
-                        ++seg;
-                        if (record && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], s);
-                        continue;
-                    }
-                    arr[cnt++] = pa;
-                    grouped.push_back(lst[q]);
-                }
-                if (cnt == 0) continue;
-                // once the wide heads have left, the narrow box heads (16 / 24 channels) would pay the wide tile of the remaining
-                // class heads: dense-conv groups are split into a narrow and a wide launch
-                const bool split_narrow = conv && cnt < (int)lst.size();
-                for (int pass = 0; pass < (split_narrow ? 2 : 1); ++pass) {
-                    PwArgs sub[12];
-                    std::vector<int> ids;
-                    int nsub = 0;
-                    for (int q = 0; q < cnt; ++q) {
-                        const bool narrow = arr[q].cout <= 32;
-                        if (split_narrow && narrow != (pass == 0)) continue;
-                        sub[nsub++] = arr[q];
-                        ids.push_back(grouped[q]);
-                    }
-                    if (nsub == 0) continue;
-                    rc = launch_pointwise_group(sub, nsub, conv, s);
-                    if (rc != DN_OK) return rc;
-                    for (int q : ids) note(q, seg);
-                    ++seg;
-                    if (record && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], s);
-                }
+            rc = launch_heads(forked ? p->head_early : 0, 1 << 20, s, record, seg);
+            if (rc != DN_OK) return rc;
+            if (forked) {
+                DN_HIP_CHECK(hipEventRecord(p->ev_head_join[chain], p->head_stream[chain]));
+                DN_HIP_CHECK(hipStreamWaitEvent(main_stream, p->ev_head_join[chain], 0));
             }
             for (size_t q = seg + 1; q < p->ops.size(); ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
@@ -1079,7 +1152,7 @@ static int enqueue_all(dn_plan* p, const float* images, int n, int h, int w, flo
                                               : images + n0 * 3 * (size_t)h * w;
         int rc = enqueue(p, sub_images, ns, h, w, boxes ? boxes + n0 * D * 4 : nullptr, scores ? scores + n0 * D : nullptr,
                          labels ? labels + n0 * D : nullptr, counts ? counts + n0 : nullptr, ws, V, heads_only, bs, record,
-                         p->packed_out ? p->packed_out + n0 * (D + 1) * 6 : nullptr, k * ev_stride);
+                         p->packed_out ? p->packed_out + n0 * (D + 1) * 6 : nullptr, k * ev_stride, k);
         if (rc) return rc;
         if (!record && k > 0) DN_HIP_CHECK(hipEventRecord(p->ev_branch[k - 1], bs));
         n0 += ns;
@@ -1101,7 +1174,7 @@ static int enqueue_chain(dn_plan* p, const float* images, int n, int h, int w, f
                                           : images + n0 * 3 * (size_t)h * w;
     return enqueue(p, sub_images, ns, h, w, boxes ? boxes + n0 * D * 4 : nullptr, scores ? scores + n0 * D : nullptr,
                    labels ? labels + n0 * D : nullptr, counts ? counts + n0 : nullptr, ws, V, heads_only, s, false,
-                   p->packed_out ? p->packed_out + n0 * (D + 1) * 6 : nullptr, 0);
+                   p->packed_out ? p->packed_out + n0 * (D + 1) * 6 : nullptr, 0, k);
 }
 
 static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
@@ -1150,7 +1223,12 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     // another; on the real chain the two forms measure the same at two chains (1.25 vs 1.24 ms) and per-chain graphs lose
     // badly at three or four (1.9 ms): kept as an opt-in for that measurement only.
     const int S = batch_split(p, n);
-    const bool per_chain = S > 1 && p->chain_graphs;
+    // (early heads: a fork inside a forked branch crashes hipStreamEndCapture on ROCm 7.2 -- with them every chain is a graph of its own)
+    // Measured (batch 32 = 2 x 16, 12 runs each): per-chain graphs 0.78 ms every time, one graph with two branches 0.785 ms in
+    // two runs of three and 0.82 - 0.85 ms in the third (the placement of the branches differs from process to process); at batch
+    // 64 one graph is 0.7 % faster (1.127 vs 1.135 ms). Default: per-chain graphs below 64 images.
+    const bool want_chains = p->chain_graphs < 0 ? n < 64 : p->chain_graphs != 0;
+    const bool per_chain = S > 1 && (want_chains || (p->head_early > 0 && p->head_fork_op >= 0));
     const int flags = (heads_only ? 1 : 0) | (p->input_u8 ? 2 : 0);
     auto capture = [&](const GraphKey& key, hipGraphExec_t* out) -> int {
         hipGraph_t g = nullptr;

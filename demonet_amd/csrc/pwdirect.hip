@@ -37,10 +37,11 @@ __device__ __forceinline__ void act16(floatx16& v, int act) {
     }
 }
 
-// KSM: 16-deep K steps held in registers (cin <= 16 * KSM); TC: 32-channel tiles per wave.
+// KSF: full 16-deep K steps (cin >> 4, exact: no guards in the load / MFMA sequences); TC: 32-channel tiles per wave.
 // Workgroup = 4 waves = (4 >> wc_log) row tiles of 32 pixels x (1 << wc_log) channel blocks of 32 * TC channels.
-template <int KSM, int TC>
+template <int KSF, int TC>
 __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int wc_log) {
+    constexpr int KSM = KSF > 0 ? KSF : 1;
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wc = wave & ((1 << wc_log) - 1), wp = wave >> wc_log;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
     if (mrow0 >= mend || n_base >= NC) return;            // wave-uniform
     const int row = mrow0 + r;
     const int rowc = min(row, mend - 1);
-    const int KSF = K >> 4;                                 // full 16-deep steps; then ONE last step: the K tail (cin % 16 == 8) and the bias columns
+    // KSF full 16-deep steps; then ONE last step: the K tail (cin % 16 == 8) and the bias columns
 
     // ---- every load of the wave, up front
     const half_t* xp = a.x + (size_t)rowc * K + hh * 8;
@@ -82,12 +83,10 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
     }
     half8 xf[KSM], wf[TC][KSM];
 #pragma unroll
-    for (int ks = 0; ks < KSM; ++ks) {
-        if (ks < KSF) {
-            xf[ks] = *reinterpret_cast<const half8*>(xp + ks * 16);
+    for (int ks = 0; ks < KSF; ++ks) {
+        xf[ks] = *reinterpret_cast<const half8*>(xp + ks * 16);
 #pragma unroll
-            for (int i = 0; i < TC; ++i) wf[i][ks] = *reinterpret_cast<const half8*>(wpt[i] + ks * 16);
-        }
+        for (int i = 0; i < TC; ++i) wf[i][ks] = *reinterpret_cast<const half8*>(wpt[i] + ks * 16);
     }
     // last step: this lane's columns kb .. kb+7; kb < K: data (address clamped, value selected below); kb == K: the bias columns
     const int kb = KSF * 16 + hh * 8;
@@ -131,11 +130,9 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KSM; ++ks) {
-        if (ks < KSF) {
+    for (int ks = 0; ks < KSF; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][ks], xf[ks], acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < TC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][ks], xf[ks], acc[i], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < TC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xl, acc[i], 0, 0, 0);
@@ -182,13 +179,13 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
     }
 }
 
-template <int KSM, int TC>
+template <int KSF, int TC>
 int launch_t(const PwArgs& a, int wc_log, hipStream_t s) {
     const int BP = 32 * (4 >> wc_log), BC = (32 * TC) << wc_log;
     const int tiles = a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, BP) : dn_cdiv(a.m, BP);
     const dim3 grid((unsigned)(a.xq > 0 ? 8 * tiles : tiles) * dn_cdiv(a.cout, BC));
-    dn_note_kernel("pw_direct_kernel<%d,%d>", KSM, TC);
-    hipLaunchKernelGGL((pw_direct_kernel<KSM, TC>), grid, dim3(256), 0, s, a, tiles, wc_log);
+    dn_note_kernel("pw_direct_kernel<%d,%d>", KSF, TC);
+    hipLaunchKernelGGL((pw_direct_kernel<KSF, TC>), grid, dim3(256), 0, s, a, tiles, wc_log);
     return DN_OK;
 }
 
@@ -206,8 +203,11 @@ int launch_pw_direct(const PwArgs& a, hipStream_t s) {
     // block of a workgroup is as wide as the layer needs, up to 128 (the 4 waves then share the x rows in L1).
     const int ctiles = dn_cdiv(a.cout, 32);
     const int wc_log = ctiles <= 1 ? 0 : ctiles <= 2 ? 1 : 2;
-    const int ksf = a.cin >> 4;
-    if (ksf <= 4) return launch_t<4, 1>(a, wc_log, s);
-    if (ksf <= 8) return launch_t<8, 1>(a, wc_log, s);
-    return launch_t<16, 1>(a, wc_log, s);
+    switch (a.cin >> 4) {
+#define DN_PWD_CASE(k) case k: return launch_t<k, 1>(a, wc_log, s);
+        DN_PWD_CASE(0) DN_PWD_CASE(1) DN_PWD_CASE(2) DN_PWD_CASE(3) DN_PWD_CASE(4) DN_PWD_CASE(5) DN_PWD_CASE(6) DN_PWD_CASE(7) DN_PWD_CASE(8)
+        DN_PWD_CASE(9) DN_PWD_CASE(10) DN_PWD_CASE(11) DN_PWD_CASE(12) DN_PWD_CASE(13) DN_PWD_CASE(14) DN_PWD_CASE(15) DN_PWD_CASE(16)
+#undef DN_PWD_CASE
+    }
+    return DN_E_UNSUPPORTED;
 }
