@@ -89,6 +89,39 @@ __device__ __forceinline__ bool xcd_image_of(int flat, int per_image, int xq, in
     return img < n;
 }
 static inline int xcd_image_slots(int xq, int n) { return xq > 0 ? 8 * xq : n; }     // image slots of such a launch
+// 2-D form of the same mapping without the integer division (a runtime division costs ~25 VALU instructions, and the small
+// kernels of the chain are VALU-issue bound): grid.x = [per_image indices] x 8 interleaved groups, grid.y = image slot of the
+// group. Workgroups are dispatched x-fastest, so (blockIdx.x % 8) is still the XCD.
+static inline dim3 xcd_grid2(int per_image, int xq, int n) { return xq > 0 ? dim3(8u * per_image, xq) : dim3(per_image, n); }
+__device__ __forceinline__ bool xcd_image_of2(int xq, int n, int& img, int& idx) {
+    if (xq > 0) {
+        img = (blockIdx.x & 7) * xq + blockIdx.y;
+        idx = blockIdx.x >> 3;
+    } else {
+        img = blockIdx.y;
+        idx = blockIdx.x;
+    }
+    return img < n;
+}
+// Division by a launch-invariant divisor: q = umulhi(x, m), m = ceil(2^32 / d); exact for x * d * d < 2^32 (fd_ok).
+struct FastDiv { unsigned d, m; };
+static inline FastDiv fastdiv(unsigned d) { return FastDiv{d, d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u}; }
+static inline bool fd_ok(unsigned long long xmax, unsigned d) { return xmax * d * d < 0x100000000ull; }
+__device__ __forceinline__ unsigned fd_div(unsigned x, FastDiv f) { return f.d > 1 ? __umulhi(x, f.m) : x; }
+// activation of N values behind ONE uniform switch (a select chain per element costs ~8 VALU instructions each)
+template <typename V, int N>
+__device__ __forceinline__ void dn_act_n(V& v, int act) {
+    if (act == DN_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (act == DN_ACT_RELU6) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+    } else if (act == DN_ACT_HSWISH) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+}
 
 // launchers implemented by the per-kernel translation units (used by plan.hip and by the single-op C entry points)
 struct PwArgs {
@@ -137,7 +170,15 @@ struct DwArgs {
     int n, h, w_, c, k, stride, pad, act, ho, wo;
     float* pool = nullptr;      // optional: [n][blocks][c] fp32 per-workgroup sums of the outputs (SE squeeze)
     int xq = 0;                 // XCD grouping: images per group (0: plain mapping)
+    FastDiv fd_c8{1, 0}, fd_xs{1, 0};      // filled by the launcher: divisions by c / 8 and by the x strips per row
+    // squeeze-excitation FCs in the tail of the pooling launch (depthwise.hip, dw_se_tail): the workgroup of an image that finishes
+    // last turns the partial sums into scale[n][c]. se_counter: one zero-initialised unsigned per image, left at zero again.
+    const half_t* se_w1t = nullptr; const float* se_b1 = nullptr;      // fc1 transposed [c][sq] fp16, bias [sq]
+    const half_t* se_w2t = nullptr; const float* se_b2 = nullptr;      // fc2 transposed [sq][c] fp16, bias [c]
+    float* se_scale = nullptr; unsigned* se_counter = nullptr;
+    int se_sq = 0; float se_inv = 0.f;                                 // squeeze width, 1 / pooled pixels
 };
+bool depthwise_se_tail_supported(int c, int squeeze);
 int launch_depthwise(const DwArgs& a, hipStream_t s);
 int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s);
 int depthwise_pool_blocks(const DwArgs& a);       // workgroups per image == partial-sum rows per image
@@ -150,6 +191,7 @@ struct StemArgs {
     int n, h, w_, cout, k, stride, pad, act, ho, wo;
     float mean[3], inv_std[3];
     int xq = 0;             // XCD grouping: images per group (0: plain mapping)
+    unsigned* zero_u32 = nullptr; int zero_count = 0;      // optional: words the first workgroup clears (the chain's SE counters)
 };
 int launch_stem(const StemArgs& a, hipStream_t s);
 

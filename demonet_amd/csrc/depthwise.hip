@@ -12,22 +12,89 @@ extern "C" __attribute__((visibility("default"))) void dn_debug_se_stamps(void* 
 
 namespace {
 
-// each thread: TW consecutive output pixels of one row x 8 channels; sliding input window kept in registers
-template <int K, int S, int TW>
+__device__ const uint4 g_dw_zero16 = {0u, 0u, 0u, 0u};      // what an out-of-image tap reads (pointer select instead of a predicated load)
+
+// each thread: TW consecutive output pixels of one row x 8 channels; sliding input window kept in registers.
+// Instruction diet (tools/valu.sh: these launches are VALU-issue bound): divisions by launch invariants through FastDiv, the image
+// from a 2-D grid, unconditional loads (an out-of-image tap reads a zero line through a selected pointer -- a predicated load
+// costs a branch and a conservative wait), one uniform activation switch per output pixel, pooled sums only in the POOL variant.
+// Squeeze-excitation FCs (mobilenetv3.py:31-36: mean -> fc1 + ReLU -> fc2 + Hardsigmoid) computed by the LAST workgroup of an
+// image's pooling launch instead of a launch of their own (a dependent launch of 32 workgroups cost 10 - 15 us, five times per
+// chain). 256 threads; a thread owns 8 adjacent outputs (one 16-byte load per weight row) and a slice of the reduction axis, the
+// slices are combined through LDS in a fixed order; loads in batches of 16 rows. sh: >= c + sq + 2048 floats.
+__device__ __forceinline__ void dw_se_tail(const DwArgs& a, const int n, const int nblk, float* sh) {
+    const int c = a.c, sq = a.se_sq, tid = threadIdx.x;
+    float* mean = sh;               // [c]
+    float* z = sh + c;              // [sq]
+    float* part = z + sq;           // [256][8]
+    {   // pooled mean: thread = channel (c <= 1024: up to 4 per thread), all partial rows of the image in a fixed order
+        const float* p0 = a.pool + (size_t)n * nblk * c;
+        for (int ic = tid; ic < c; ic += 256) {
+            float t = 0.f;
+            for (int b0 = 0; b0 < nblk; b0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = p0[(size_t)min(b0 + u, nblk - 1) * c + ic];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t += (b0 + u < nblk) ? v[u] : 0.f;
+            }
+            mean[ic] = t * a.se_inv;
+        }
+    }
+    __syncthreads();
+    auto fc = [&](const half_t* wt, const float* bias, const float* in, int nin, int nout, float* out, bool hsig) {
+        // out[j] = f(bias[j] + sum_i wt[i][j] * in[i]); thread = (8-output group og, K slice ks)
+        const int OG = (nout + 7) >> 3;
+        int ogp = 1;
+        while (ogp < OG) ogp <<= 1;                     // groups padded to a power of two <= 256
+        const int KS = 256 / ogp;
+        const int og = tid & (ogp - 1), ks = tid / ogp;
+        const int per = (nin + KS - 1) / KS, i0 = ks * per, i1 = min(nin, i0 + per);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (og < OG && i0 < i1) {
+            const half_t* wp = wt + (size_t)og * 8;
+            for (int ib = i0; ib < i1; ib += 16) {
+                uint4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint4*>(wp + (size_t)min(ib + u, i1 - 1) * nout);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float m = (ib + u < i1) ? in[ib + u] : 0.f;
+                    const half8 h = *reinterpret_cast<const half8*>(&v[u]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] * m;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[tid * 8 + e] = acc[e];
+        __syncthreads();
+        for (int j = tid; j < nout; j += 256) {
+            float t = bias[j];
+            const int g = j >> 3, e = j & 7;
+            for (int q = 0; q < KS; ++q) t += part[(q * ogp + g) * 8 + e];
+            out[j] = hsig ? fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f) : fmaxf(t, 0.f);
+        }
+        __syncthreads();
+    };
+    fc(a.se_w1t, a.se_b1, mean, c, sq, z, false);
+    fc(a.se_w2t, a.se_b2, z, sq, c, a.se_scale + (size_t)n * c, true);
+}
+
+template <int K, int S, int TW, bool POOL>
 __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int nblocks, const int n) {
     constexpr int NIN = (TW - 1) * S + K;
     extern __shared__ float red[];            // [256][8], only when pooling
-    const int C8 = a.c >> 3;
-    const int XS = (a.wo + TW - 1) / TW;
-    int idx = bx * 256 + threadIdx.x;
-    const int cg = idx % C8;
-    idx /= C8;
-    const int xs = idx % XS;
-    const int oy = idx / XS;
-    const bool valid = oy < a.ho;
-    if (!valid && !a.pool) return;
+    const unsigned C8 = a.c >> 3;
+    const unsigned idx0 = bx * 256 + threadIdx.x;
+    const unsigned q1 = fd_div(idx0, a.fd_c8);
+    const unsigned cg = idx0 - q1 * C8;
+    const unsigned oy = fd_div(q1, a.fd_xs);
+    const unsigned xs = q1 - oy * a.fd_xs.d;
+    const bool valid = (int)oy < a.ho;
+    if (!valid && !POOL) return;
     const int ox0 = xs * TW;
-    const int c0 = cg * 8;
+    const unsigned c0 = cg * 8;
     float psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (valid) {
 
@@ -42,10 +109,14 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
         }
     }
     const int ix0 = ox0 * S - a.pad;
+    typedef const __attribute__((address_space(1))) half8* gp8;     // explicit global pointers: the selected pointer must not degrade to a flat load
+    const gp8 zero = (gp8)(&g_dw_zero16);
     // RP kernel rows are requested together before their first use: hipcc otherwise waits for each row's loads before
     // issuing the next row's (vmcnt(0) per row), i.e. K dependent memory round trips per thread. 3x3 takes all rows at once;
     // 5x5 two at a time (all five would need 260 VGPRs of staging).
     constexpr int RP = (K == 3) ? 3 : 2;
+    const half_t* const wbase = a.w + c0;
+    const half_t* const xbase = a.x + (size_t)n * a.h * a.w_ * a.c + c0;
 #pragma unroll
     for (int ky0 = 0; ky0 < K; ky0 += RP) {
         half8 wv[RP][K];
@@ -54,17 +125,16 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
         for (int rr = 0; rr < RP; ++rr) {
             const int ky = ky0 + rr;
             if (ky >= K) continue;
-            const int iy = oy * S - a.pad + ky;
+            const int iy = (int)oy * S - a.pad + ky;
             const bool yok = iy >= 0 && iy < a.h;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) wv[rr][kx] = *reinterpret_cast<const half8*>(a.w + (size_t)(ky * K + kx) * a.c + c0);
-            const half_t* rowp = a.x + ((size_t)(n * a.h + (yok ? iy : 0)) * a.w_) * a.c + c0;
+            for (int kx = 0; kx < K; ++kx) wv[rr][kx] = *reinterpret_cast<const half8*>(wbase + (unsigned)((ky * K + kx) * a.c));
+            const half_t* rowp = xbase + (unsigned)((yok ? iy : 0) * a.w_ * a.c);
 #pragma unroll
             for (int i = 0; i < NIN; ++i) {
                 const int ix = ix0 + i;
-                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (yok && ix >= 0 && ix < a.w_) v = *reinterpret_cast<const half8*>(rowp + (size_t)ix * a.c);
-                xin[rr][i] = v;
+                const bool ok = yok && ix >= 0 && ix < a.w_;
+                xin[rr][i] = *(ok ? (gp8)(rowp + (unsigned)(ix * a.c)) : zero);
             }
         }
 #pragma unroll
@@ -81,44 +151,64 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
         if (ox0 + t >= a.wo) break;
+        dn_act_n<float[8], 8>(acc[t], a.act);
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = dn_act(acc[t][e], a.act);
-            psum[e] += v;
-            o[e] = (half_t)v;
+            if constexpr (POOL) psum[e] += acc[t][e];
+            o[e] = (half_t)acc[t][e];
         }
-        *reinterpret_cast<half8*>(orow + (size_t)(ox0 + t) * a.c) = o;
+        *reinterpret_cast<half8*>(orow + (unsigned)((ox0 + t) * a.c)) = o;
     }
     }   // valid
-    if (a.pool) {
+    if constexpr (POOL) {
         // SE squeeze (mobilenetv3.py:32 adaptive_avg_pool2d) fused as deterministic per-workgroup partial sums:
         // threads with equal channel group sit C8 apart; thread t < C8 adds them in a fixed order.
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = psum[e];
         __syncthreads();
-        if ((int)threadIdx.x < C8) {
-            const int cgp = (bx * 256 + threadIdx.x) % C8;
+        if (threadIdx.x < C8) {
+            const unsigned i1 = bx * 256 + threadIdx.x;
+            const unsigned cgp = i1 - fd_div(i1, a.fd_c8) * C8;
             float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int u = threadIdx.x; u < 256; u += C8)
+            for (unsigned u = threadIdx.x; u < 256; u += C8)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t8[e] += red[u * 8 + e];
             float* dst = a.pool + ((size_t)n * nblocks + bx) * a.c + cgp * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) dst[e] = t8[e];
         }
+        if (a.se_scale) {
+            // last workgroup of the image (threadfence + counter, the classic "last block" reduction): its partial sums and
+            // everybody else's are visible after the fences; the counter goes back to zero for the next launch
+            // (ONE fence per workgroup, by the thread that signals: the barrier orders the other threads' stores before it and the
+            // device-scope release is cumulative. A fence per thread is an L2 write-back per wave: 100 us per launch, measured.)
+            __shared__ int s_last;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                s_last = atomicAdd(&a.se_counter[n], 1u) == (unsigned)(nblocks - 1);
+                if (s_last) __threadfence();
+            }
+            __syncthreads();
+            if (s_last) {
+                dw_se_tail(a, n, nblocks, red);
+                if (threadIdx.x == 0) a.se_counter[n] = 0u;
+            }
+        }
     }
 }
 
-template <int K, int S, int TW>
+template <int K, int S, int TW, bool POOL>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, int nblocks) {
     int img, bx;
-    if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, img, bx)) return;
-    dw_body<K, S, TW>(a, bx, nblocks, img);
+    if (!xcd_image_of2(a.xq, a.n, img, bx)) return;
+    dw_body<K, S, TW, POOL>(a, bx, nblocks, img);
 }
 
 // Grouped launch: up to 12 independent depthwise problems of the same (k, stride) and batch in ONE launch (the head
-// depthwise convs of all pyramid levels, both heads). blockIdx.x is flat over the problems' per-image block counts.
+// depthwise convs of all pyramid levels, both heads). blockIdx.x is flat over the problems' per-image block counts (x 8 with the
+// XCD grouping: every problem's range starts at a multiple of 8), blockIdx.y is the image slot.
 struct DwGroup {
     int count;
     int start[13];
@@ -132,10 +222,22 @@ __global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
 #pragma unroll
     for (int i = 1; i < 12; ++i)
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
-    // start[] counts workgroups over all images of a problem (multiples of 8 with the XCD grouping: all problems share n)
+    const DwArgs& a = g.a[p];
+    const int rel = blockIdx.x - g.start[p];
     int img, bx;
-    if (!xcd_image_of(blockIdx.x - g.start[p], g.nblocks[p], g.a[p].xq, g.a[p].n, img, bx)) return;
-    dw_body<K, S, TW>(g.a[p], bx, g.nblocks[p], img);
+    if (a.xq > 0) { img = (rel & 7) * a.xq + blockIdx.y; bx = rel >> 3; }
+    else { img = blockIdx.y; bx = rel; }
+    if (img >= a.n) return;
+    dw_body<K, S, TW, false>(a, bx, g.nblocks[p], img);
+}
+
+template <int K, int S, int TW>
+bool dw_fill(DwArgs& a) {
+    const unsigned c8 = a.c / 8, xs = (a.wo + TW - 1) / TW;
+    a.fd_c8 = fastdiv(c8);
+    a.fd_xs = fastdiv(xs);
+    const unsigned long long threads = (unsigned long long)a.ho * xs * c8 + 256;
+    return fd_ok(threads, c8) && fd_ok(threads / c8 + 1, xs) && (unsigned long long)a.h * a.w_ * a.c < 0x80000000ull;
 }
 
 template <int K, int S, int TW>
@@ -145,22 +247,29 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
     int acc = 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
+        DN_REQUIRE((dw_fill<K, S, TW>(g.a[i])), "depthwise group: problem %d outside the index range of the kernel", i);
+        DN_REQUIRE(!arr[i].pool && arr[i].n == arr[0].n && arr[i].xq == arr[0].xq, "depthwise group: problems must share the batch and have no pooled output");
         g.start[i] = acc;
         g.nblocks[i] = dn_cdiv((long)arr[i].ho * ((arr[i].wo + TW - 1) / TW) * (arr[i].c / 8), 256);
-        acc += g.nblocks[i] * (arr[i].xq > 0 ? 8 * arr[i].xq : arr[i].n);
+        acc += g.nblocks[i] * (arr[i].xq > 0 ? 8 : 1);
     }
     g.start[count] = acc;
     dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
-    hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
     return DN_OK;
 }
 
 template <int K, int S, int TW>
-int launch_dw(const DwArgs& a, hipStream_t s) {
+int launch_dw(const DwArgs& a0, hipStream_t s) {
+    DwArgs a = a0;
+    DN_REQUIRE((dw_fill<K, S, TW>(a)), "depthwise: %d x %d x %d outside the index range of the kernel", a.ho, a.wo, a.c);
     const long threads = (long)a.ho * ((a.wo + TW - 1) / TW) * (a.c / 8);       // per image
     dn_note_kernel("dw_kernel<%d,%d,%d>", K, S, TW);
     const int nblocks = dn_cdiv(threads, 256);
-    hipLaunchKernelGGL((dw_kernel<K, S, TW>), dim3(nblocks * (a.xq > 0 ? 8 * a.xq : a.n)), dim3(256), a.pool ? 256 * 8 * 4 : 0, s, a, nblocks);
+    if (a.se_scale) DN_REQUIRE(a.pool && a.se_counter && depthwise_se_tail_supported(a.c, a.se_sq), "depthwise: squeeze-excitation tail needs the pooled output and c <= 1024, squeeze <= 256, both multiples of 8");
+    const size_t pool_lds = a.se_scale ? (size_t)(a.c + a.se_sq + 2048) * 4 : (size_t)256 * 8 * 4;
+    if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, true>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), pool_lds, s, a, nblocks);
+    else hipLaunchKernelGGL((dw_kernel<K, S, TW, false>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), 0, s, a, nblocks);
     return DN_OK;
 }
 
@@ -298,6 +407,8 @@ template <int COUT, int K>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a, int nblocks) {
     const float* __restrict__ wts = a.w;
     const float* __restrict__ bias = a.bias;
+    if (a.zero_u32 && blockIdx.x == 0)       // the chain's squeeze-excitation counters (DwArgs::se_counter): cleared once per forward, ahead of every pooling launch
+        for (int i = threadIdx.x; i < a.zero_count; i += 256) a.zero_u32[i] = 0u;
     int n, bx;
     if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, n, bx)) return;
     int idx = bx * 256 + threadIdx.x;
@@ -353,6 +464,8 @@ __global__ __launch_bounds__(256) void stem3s2_kernel(StemArgs a, int nblocks) {
     __shared__ float taps[27][256];     // this thread's 27 normalised taps, parked in its own LDS column between the phases
     const float* __restrict__ wts = a.w;
     const float* __restrict__ bias = a.bias;
+    if (a.zero_u32 && blockIdx.x == 0)       // the chain's squeeze-excitation counters (DwArgs::se_counter): cleared once per forward, ahead of every pooling launch
+        for (int i = threadIdx.x; i < a.zero_count; i += 256) a.zero_u32[i] = 0u;
     int n, bx;
     if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, n, bx)) return;
     const int idx = bx * 256 + threadIdx.x;
@@ -422,6 +535,8 @@ __global__ __launch_bounds__(256) void stem3s2_kernel(StemArgs a, int nblocks) {
 // straight from the planar fp32 image (32 consecutive pixels per tap: whole 128-B lines). No LDS on the input side. The 32 x 64
 // result tile goes through a per-wave LDS slab so that every lane writes 16-byte row-contiguous chunks of the NHWC fp16 output.
 __global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_per_image, int tiles_per_wave, int nblocks) {
+    if (a.zero_u32 && blockIdx.x == 0)       // the chain's squeeze-excitation counters (DwArgs::se_counter): cleared once per forward, ahead of every pooling launch
+        for (int i = threadIdx.x; i < a.zero_count; i += 256) a.zero_u32[i] = 0u;
     __shared__ __attribute__((aligned(16))) half_t slab[4][32 * 72];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -556,6 +671,8 @@ int depthwise_pool_blocks(const DwArgs& a) {
     if (a.k == 5 && a.stride == 1) return dw_blocks<5, 1, 4>(a);
     return dw_blocks<5, 2, 2>(a);
 }
+
+bool depthwise_se_tail_supported(int c, int squeeze) { return c % 8 == 0 && squeeze % 8 == 0 && c <= 1024 && squeeze <= 256 && c >= 8 && squeeze >= 8; }
 
 int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b1, const void* w2t, const float* b2, float* scale,
                  int n, int c, int squeeze, int pool_pixels, hipStream_t s, int xq) {

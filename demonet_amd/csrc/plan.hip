@@ -74,6 +74,7 @@ struct Layout {
     size_t arena = 0;
     int chain_n = 0;
     size_t trunk_off = 0;       // [n][trunk_scratch_halfs] fp16
+    size_t secnt_off = 0;       // [n_se_in_dw][n] unsigned: last-workgroup counters of the squeeze-excitation tails
 };
 
 struct GraphKey {
@@ -128,6 +129,9 @@ struct dn_plan {
     // run of tiny backbone layers [tail_first, tail_end) executed by one per-image workgroup (tail.hip); -1: none
     int tail_first = -1, tail_end = -1;
     // run of inverted-residual blocks on the small maps executed by one per-image workgroup (trunk.hip): ops [trunk_first, trunk_end)
+    std::vector<int> se_in_dw;              // per op: DW op -> index of the SE op whose FCs run in its tail (depthwise.hip dw_se_tail), SE op -> -2, else -1
+    int n_se_in_dw = 0;                     // such pairs; slot q of the counter block belongs to the q-th
+    std::vector<int> se_slot;               // per op (DW op of a pair): q
     std::vector<int> se_fold;               // per op: PW op -> index of the SE op whose FCs run in its prologue (pointwise.hip SEF), SE op -> -2, else -1
     int trunk_first = -1, trunk_end = -1;
     std::vector<int> trunk_block_op;        // first op of every block of the run
@@ -230,6 +234,11 @@ static const Layout& get_layout(dn_plan* p, int n) {
             dies[o.out] = std::max(dies[o.out], when[i]);
             if (o.pool >= 0) { if (born[o.pool] < 0) born[o.pool] = when[i]; dies[o.pool] = std::max(dies[o.pool], when[i]); }
         }
+        for (int i = 0; i < NO; ++i)
+            if (p->se_in_dw[i] >= 0) {      // the scale vector is written by the depthwise launch itself (dw_se_tail)
+                const int t = p->ops[p->se_in_dw[i]].out;
+                if (born[t] >= 0) born[t] = std::min(born[t], when[i]);
+            }
         if (p->head_early > 0 && p->head_fork_op >= 0)
             // early head launches run beside the backbone from the fork on: what they write must not alias anything alive there
             for (int i = p->head_first; i < NO; ++i) {
@@ -273,6 +282,8 @@ static const Layout& get_layout(dn_plan* p, int n) {
     off += align256((size_t)n * 2 * 4);
     L.trunk_off = off;
     off += align256((size_t)n * p->trunk_scratch_halfs * 2);
+    L.secnt_off = off;
+    off += align256((size_t)n * p->n_se_in_dw * 4 + 4);
     L.post_off = off;
     {
         const int S = batch_split(p, n);          // one private post-process scratch slice per sub-batch branch
@@ -465,6 +476,32 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (users == 1 && pw_se_fold_supported(pj.cin, pj.cout, so.squeeze, ti.h * ti.w)) {
             p->se_fold[i] = -2;
             p->se_fold[i + 1] = i;
+        }
+    }
+    // ---- the other squeeze-excitations (opt-in, DN_SE_IN_DW=1): their FCs run in the tail of the depthwise launch that pools for
+    //      them (the last workgroup of an image to finish; depthwise.hip dw_se_tail) instead of a 32-workgroup launch of their own.
+    //      Needs the plain depthwise launch (not the fused expand+depthwise, tail or trunk runs) and the stem launch, which clears
+    //      the counters. MEASURED and left off: the FCs of the large blocks stream 230 - 450 KB of weights into ONE compute unit
+    //      per image, a 256-thread workgroup needs ~14 dependent memory round trips for that (the 1024-thread se_fc_kernel
+    //      three), and the tail sits on the critical path of the chain: the 20 x 20 depthwise launches go from 10 to 50 us,
+    //      batch 64 from 1.12 to 1.32 ms.
+    p->se_in_dw.assign(desc->n_ops, -1);
+    p->se_slot.assign(desc->n_ops, -1);
+    p->n_se_in_dw = 0;
+    if (dn_knob("DN_SE_IN_DW", 0) != 0 && p->ops[0].type == DN_OP_STEM) {
+        for (int i = 1; i < desc->n_ops; ++i) {
+            const dn_op_desc& so = p->ops[i];
+            if (so.type != DN_OP_SE || p->se_fold[i] == -2) continue;
+            int j = -1;
+            for (int q = 0; q < i; ++q) if (p->ops[q].type == DN_OP_DW && p->ops[q].pool == so.in) j = q;
+            if (j < 1 || !depthwise_se_tail_supported(so.cin, so.squeeze)) continue;
+            bool plain = p->fused_len[j] == 0 && !(p->fused_len[j - 1] >= 2);
+            if (j >= 2 && p->fused_len[j - 2] >= 3) plain = false;
+            if (p->trunk_first >= 0 && j >= p->trunk_first && j < p->trunk_end) plain = false;
+            if (!plain) continue;
+            p->se_in_dw[j] = i;
+            p->se_in_dw[i] = -2;
+            p->se_slot[j] = p->n_se_in_dw++;
         }
     }
     // partial-sum rows of every pooled tensor = workgroups per image of its producing depthwise op
@@ -684,6 +721,7 @@ static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
     V.reg_off = L.reg_off + (size_t)n0 * p->d.num_anchors * 16;
     V.scale_off = L.scale_off + (size_t)n0 * 8;
     V.trunk_off = L.trunk_off + (size_t)n0 * p->trunk_scratch_halfs * 2;
+    V.secnt_off = L.secnt_off + (size_t)n0 * p->n_se_in_dw * 4;
     const size_t slice = L.post_bytes / (size_t)S;
     V.post_off = L.post_off + (size_t)k * slice;
     V.post_bytes = slice;
@@ -771,6 +809,16 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.ho = to.h; a.wo = to.w;
         a.pool = o.pool >= 0 ? reinterpret_cast<float*>(tptr(o.pool)) : nullptr;
         a.xq = xq;
+        const int oi = (int)(&o - p->ops.data());
+        if (oi >= 0 && oi < (int)p->ops.size() && p->se_in_dw[oi] >= 0) {
+            const dn_op_desc& so = p->ops[p->se_in_dw[oi]];
+            a.se_w1t = reinterpret_cast<const half_t*>(Wb + so.w_off); a.se_b1 = reinterpret_cast<const float*>(Wb + so.b_off);
+            a.se_w2t = reinterpret_cast<const half_t*>(Wb + so.w2_off); a.se_b2 = reinterpret_cast<const float*>(Wb + so.b2_off);
+            a.se_scale = reinterpret_cast<float*>(tptr(so.out));
+            a.se_counter = reinterpret_cast<unsigned*>(ws + L.secnt_off) + (size_t)p->se_slot[oi] * n;
+            a.se_sq = so.squeeze;
+            a.se_inv = 1.0f / (float)so.pool_pixels;
+        }
         return a;
     };
     auto make_conv = [&](const dn_op_desc& o) {
@@ -1063,6 +1111,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 a.ho = to.h; a.wo = to.w;
                 for (int c = 0; c < 3; ++c) { a.mean[c] = d.mean[c]; a.inv_std[c] = 1.0f / d.std[c]; }
                 a.xq = xq;
+                if (p->n_se_in_dw > 0) { a.zero_u32 = reinterpret_cast<unsigned*>(ws + L.secnt_off); a.zero_count = p->n_se_in_dw * n; }
                 rc = launch_stem(a, s);
                 break;
             }
@@ -1074,6 +1123,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 break;
             case DN_OP_SE: {
                 if (p->se_fold[i] == -2) { dn_note_kernel("(se folded into the projection)"); break; }
+                if (p->se_in_dw[i] == -2) { dn_note_kernel("(se in the tail of the depthwise launch)"); break; }
                 rc = launch_se_fc(reinterpret_cast<const float*>(tptr(o.in)), p->pool_blocks[o.in], W + o.w_off,
                                   reinterpret_cast<const float*>(W + o.b_off), W + o.w2_off,
                                   reinterpret_cast<const float*>(W + o.b2_off), reinterpret_cast<float*>(tptr(o.out)), n,
