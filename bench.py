@@ -32,8 +32,12 @@ C4_GLOBAL_BATCH = 256                                                  # BASELIN
 
 
 def _norm_kernel(name):
-    """rocprofv3 spells defaulted template arguments out (conv_halo_kernel<3,4,4,false>), the library's labels do not."""
+    """rocprofv3 spells defaulted template arguments out (conv_halo_kernel<3,4,4,false>), the library's labels do not. The
+    register-direct 1x1 kernel (pwdirect.hip) is ONE kernel instantiated per reduction length (pw_direct_kernel<cin / 16, 1>): its
+    instantiations are accounted as one family, launch-weighted."""
     name = name.replace(" ", "")
+    if name.startswith("pw_direct_kernel<"):
+        return "pw_direct_kernel"
     while name.endswith(",false>"):
         name = name[:-7] + ">"
     return name
@@ -321,7 +325,7 @@ def main():
                 costs[i]["bytes"] = ext / len(mem)
         owners = {}
         for i, c in enumerate(costs):
-            a = agg.setdefault(c["kernel"], dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+            a = agg.setdefault(_norm_kernel(c["kernel"]) if c["kernel"].startswith("pw_direct_kernel<") else c["kernel"], dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
             a["bytes"] += c["bytes"]
             a["flops"] += c["flops"]
             if c["owner"] not in owners:
@@ -366,9 +370,14 @@ def main():
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_hbm_traffic.json")), reverse=True):
                 with open(path) as f:
                     tk = json.load(f)["kernels"]
-                tk = {_norm_kernel(k): v for k, v in tk.items()}
-                if _norm_kernel(dom) in tk:
-                    traffic, traffic_src = tk[_norm_kernel(dom)]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                fam = {}
+                for k, v in tk.items():         # launch-weighted over the instantiations of a family
+                    e = fam.setdefault(_norm_kernel(k), [0.0, 0])
+                    e[0] += v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1)
+                    e[1] += v.get("launches_sampled", 1)
+                if _norm_kernel(dom) in fam:
+                    e = fam[_norm_kernel(dom)]
+                    traffic, traffic_src = round(e[0] / max(e[1], 1)), os.path.relpath(path, ROOT)
                     break
         rocprof_avg = None
         if prof_tag is not None:
@@ -377,13 +386,16 @@ def main():
             # an eager pass, which adds the ~3 us dispatch gap to every launch
             import csv, glob, re
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_kernel_stats.csv")), reverse=True):
+                tot_ns, calls = 0.0, 0
                 with open(path) as f:
                     for r in csv.DictReader(f):
                         nm = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
                         nm = re.sub(r"\(.*$", "", nm).replace("void ", "").replace(", ", ",").strip()
                         if _norm_kernel(nm) == _norm_kernel(dom):
-                            rocprof_avg = round(float(r["AverageNs"]) / 1e3, 2)
-                if rocprof_avg is not None:
+                            tot_ns += float(r["TotalDurationNs"])
+                            calls += int(r["Calls"])
+                if calls:
+                    rocprof_avg = round(tot_ns / calls / 1e3, 2)
                     break
         result["roofline"] = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,

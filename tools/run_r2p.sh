@@ -1,8 +1,8 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2p
-timeout 1500 python3 -m pytest tests -m gpu -q -s -k "map_on_fixed" > gpurun_out/r2p/pytest.txt 2>&1; grep -E "mAP|passed|failed|classes whose|DEBUG" gpurun_out/r2p/pytest.txt | cut -c1-3000 | head -30
-timeout 900 python3 -m pytest tests -m gpu -q -x -k "other_model or vgg or full_size or dense" > gpurun_out/r2p/pytest_vgg.txt 2>&1; tail -3 gpurun_out/r2p/pytest_vgg.txt
-for m in "ssd512_vgg16 --batch 32" "ssd300_vgg16 --batch 64"; do
-python3 bench.py --no-cpu-baseline --no-roofline --no-latency --steps 30 --warmup 5 --model $m 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$m', d['value'], d['ms_per_step'])"
-DN_CONV_POOL=0 python3 bench.py --no-cpu-baseline --no-roofline --no-latency --steps 30 --warmup 5 --model $m 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('nopoolfuse $m', d['value'], d['ms_per_step'])"
-done
+mkdir -p gpurun_out/r02b
+python3 bench.py > gpurun_out/r02b/bench.json 2> gpurun_out/r02b/bench.err; tail -c 1800 gpurun_out/r02b/bench.json; echo
+python3 bench.py --model ssd512_vgg16 --batch 32 --steps 20 --warmup 5 > gpurun_out/r02b/vgg512_bench.json 2>/dev/null
+python3 bench.py --model ssd300_vgg16 --batch 64 --steps 20 --warmup 5 > gpurun_out/r02b/vgg300_bench.json 2>/dev/null
+python3 bench.py --model ssd_lite_mobilenet_v2 --image-size 300 --batch 128 --steps 20 --warmup 5 > gpurun_out/r02b/v2_300_bench.json 2>/dev/null
+python3 bench.py --batch 32 > gpurun_out/r02b/b32_bench.json 2>/dev/null
+for f in vgg512 vgg300 v2_300 b32; do tail -c 300 gpurun_out/r02b/${f}_bench.json | head -c 300; echo; done
