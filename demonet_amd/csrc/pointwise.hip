@@ -865,6 +865,8 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     if (!conv && maxc > 64 && gt == 5) return launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
     if (!conv && maxc > 64 && gt == 6) return launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
     if (!conv && maxc > 64 && gt == 7) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
+    if (!conv && maxc > 64 && gt == 8) return launch_group_cfg<64, 128, 2, 2, false, 64>(arr, count, s);
+    if (!conv && maxc > 64 && gt == 9) return launch_group_cfg<128, 128, 2, 2, false, 64>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
     if (wg128 >= 1500 && conv) {

@@ -593,7 +593,9 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------------------
 // P3: per image
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ keptScore, const int* __restrict__ keptAnchor,
+template <int MT>       // threads per workgroup: 1024 sorts fastest, 256 is scheduled at once beside the other chain's kernels (a 1024-thread
+                        // workgroup waits for 16 free wave slots on ONE compute unit)
+__global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ keptScore, const int* __restrict__ keptAnchor,
                                                     const int* __restrict__ keptCount, const float4* __restrict__ boxes,
                                                     const float* __restrict__ scale_xy, int A, int Km1, int topk, int D,
                                                     float* __restrict__ oboxes, float* __restrict__ oscores,
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
     const float* ks = keptScore + (size_t)n * F;
     const int* ka = keptAnchor + (size_t)n * F;
     if (tid < 40) sh[tid] = 0;
-    for (int c = tid; c < Km1; c += 1024) ccount[c] = keptCount[(size_t)n * Km1 + c];
+    for (int c = tid; c < Km1; c += MT) ccount[c] = keptCount[(size_t)n * Km1 + c];
     __syncthreads();
     if (tid < 64) {
         unsigned t = 0;
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (int e = tid; e < (int)total; e += 1024) {
+            for (int e = tid; e < (int)total; e += MT) {
                 const unsigned k = __float_as_uint(ks[slot_of(e)]);
                 if (shift == 24 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
             }
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
     {
         unsigned base_gt = 0, base_eq = 0;
         const unsigned g_total = (total > (unsigned)D) ? (unsigned)D - quota : total;
-        for (int e0i = 0; e0i < (int)total; e0i += 1024) {
+        for (int e0i = 0; e0i < (int)total; e0i += MT) {
             const int e = e0i + tid;
             unsigned k = 0, f = 0;
             if (e < (int)total) {
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
             const bool gt = (k > T);
             const bool eq = (T != 0u) && (k == T);
             unsigned e0, e1, t0, t1;
-            block_scan2<1024>(gt, eq, sh, e0, e1, t0, t1);
+            block_scan2<MT>(gt, eq, sh, e0, e1, t0, t1);
             const unsigned long long kv = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - f);
             if (gt) fin[base_gt + e0] = kv;
             if (eq && base_eq + e1 < quota) fin[g_total + base_eq + e1] = kv;
@@ -704,10 +706,10 @@ __global__ __launch_bounds__(1024) void merge_kernel(const float* __restrict__ k
         }
     }
     __syncthreads();
-    rank_sort_desc<1024>(fin, fin2, M);
+    rank_sort_desc<MT>(fin, fin2, M);
     float sx = 1.f, sy = 1.f;
     if (scale_xy) { sx = scale_xy[2 * n]; sy = scale_xy[2 * n + 1]; }
-    for (int i = tid; i < D; i += 1024) {
+    for (int i = tid; i < D; i += MT) {
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         float s = 0.f;
         long long lab = 0;
@@ -849,8 +851,12 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
         else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
-        hipLaunchKernelGGL(merge_kernel, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed, a.n, a.xq);
+        if (dn_knob("DN_MERGE_THREADS", 1024) == 256)
+            hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                               (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed, a.n, a.xq);
+        else
+            hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                               (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed, a.n, a.xq);
     }
     const int* flag = fast ? needFull : nullptr;
     if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
@@ -860,8 +866,13 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
     if (rc != DN_OK) return rc;
     if (ev) (void)hipEventRecord(ev[2], s);
-    hipLaunchKernelGGL(merge_kernel, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                       (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull, a.packed, a.n, a.xq);
+    // the merge after the full pass: with the fast path on it only works for flagged images (usually none): 256 threads, scheduled at once
+    if (fast && dn_knob("DN_MERGE1_THREADS", 256) == 256)
+        hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 1, tauKey, needFull, a.packed, a.n, a.xq);
+    else
+        hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
+                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull, a.packed, a.n, a.xq);
     if (ev) (void)hipEventRecord(ev[3], s);
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;
