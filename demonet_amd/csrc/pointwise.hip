@@ -808,6 +808,12 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         if (wgs(128, 64) >= 1500) return launch_cfg<128, 64, 4, 1, CONV>(a, s);
         return launch_cfg<64, 64, 2, 2, CONV>(a, s);
     }
+    if constexpr (CONV) {
+        // small dense convs (the extras of the VGG models: <= 16 x 16 maps, K = 9 cin up to 4608): a few workgroups walking 70 - 140
+        // K stages, each an exposed memory round trip with the plain double buffer (60 - 130 us per layer for < 1 us of MFMA work):
+        // request the stages 4 ahead through the register ring of the short-K pointwise variant
+        if (dn_knob("DN_CONV_SMALL_PF", 1) && a.cout > 32 && wgs(64, 64) < dn_knob("DN_CONV_SMALL_WGS", 512)) return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
+    }
     const int t128 = dn_knob("DN_CONV_T128", 300);      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
     if (wgs(128, 128) >= (CONV ? t128 : 1500)) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
     if (wgs(128, 64) >= 1500 || a.cout % 128 > 64 || a.cout % 128 == 0) {
@@ -817,11 +823,11 @@ int launch_select(const PwArgs& a, hipStream_t s) {
 }
 
 namespace {
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int GPF_ = 0>
 int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     // head 1x1 convs have long K (21 stages at level 0): loads run 3 stages ahead (the dense-conv heads of the VGG models are
-    // MFMA-bound at 184 VGPRs and keep the plain double buffer)
-    constexpr int GPF = CONV ? 1 : 3;
+    // MFMA-bound at 184 VGPRs and keep the plain double buffer -- except the small levels, below)
+    constexpr int GPF = GPF_ ? GPF_ : (CONV ? 1 : 3);
     PwGroup g{};
     g.count = count;
     int acc = 0;
@@ -867,6 +873,7 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     if (!conv && maxc > 64 && gt == 7) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
     if (!conv && maxc > 64 && gt == 8) return launch_group_cfg<64, 128, 2, 2, false, 64>(arr, count, s);
     if (!conv && maxc > 64 && gt == 9) return launch_group_cfg<128, 128, 2, 2, false, 64>(arr, count, s);
+    if (maxc <= 32 && conv && wg128 < 256 && dn_knob("DN_CONV_SMALL_PF", 1)) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
     if (wg128 >= 1500 && conv) {
@@ -877,6 +884,8 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         if (all64) return launch_group_cfg<128, 128, 2, 2, true, 64>(arr, count, s);
     }
     if (wg128 >= 1500) return conv ? launch_group_cfg<128, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
+    // the dense heads of the small levels (a few dozen workgroups, 72 - 144 K stages): latency-bound, stages requested 3 ahead
+    if (conv && wg128 < 256 && dn_knob("DN_CONV_SMALL_PF", 1)) return launch_group_cfg<64, 128, 2, 2, true, 32, 3>(arr, count, s);
     return conv ? launch_group_cfg<64, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
 }
 
