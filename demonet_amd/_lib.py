@@ -60,6 +60,8 @@ _SIGNATURES = {
     "dn_dense_conv": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 10 + [C.c_void_p]),
     "dn_expand_depthwise": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 11 + [C.c_void_p]),
     "dn_expand_depthwise_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dn_ssd_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dn_ssd_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_float] + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dn_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "dn_set_packed_output": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dn_profile_begin": (C.c_int, [C.c_void_p]),

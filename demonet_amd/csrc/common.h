@@ -127,6 +127,7 @@ __device__ __forceinline__ void dn_act_n(V& v, int act) {
 struct PwArgs {
     // implicit-GEMM geometry (dense kxk conv); pointwise uses k=1: x rows are then simply [m][cin]
     int cv_k = 1, cv_stride = 1, cv_pad = 0, cv_dil = 1, cv_h = 0, cv_w = 0, cv_ho = 0, cv_wo = 0, cv_cin = 0;
+    FastDiv fd_cin32{1, 0}, fd_k{1, 0};     // conv_to_pw: (k0 / 32) / (cv_cin / 32) and tap / cv_k without a hardware division per K stage
     const half_t* zeros = nullptr;   // optional: >= 16 zero bytes on the device (dense convs)
     // optional second head on the same input (convbig.hip, head kernel): output channels [cout, cout + cout2) use these
     const half_t* w_b = nullptr; const float* bias_b = nullptr; void* out_b = nullptr;

@@ -87,27 +87,33 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     uint4 sx[NX], sw[NWc];
-    int cvn[NX], cvy[NX], cvx[NX];      // CONV: image, top-left input coordinate of the output pixel of each staged row
+    int cvy[NX], cvx[NX];               // CONV: top-left input coordinate of the output pixel of each staged row
+    long cvo[NX];                       //       and the element offset of that (possibly out-of-image) pixel's chunk in x
     if constexpr (CONV) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int m = m0 + (tid + 256 * i) / CPR;
+            const int c = tid + 256 * i;
+            const int m = m0 + c / CPR;
             const int img = m / a.hw, rem = m - img * a.hw;
             const int oy = rem / a.cv_wo, ox = rem - oy * a.cv_wo;
-            cvn[i] = img;
             cvy[i] = oy * a.cv_stride - a.cv_pad;
             cvx[i] = ox * a.cv_stride - a.cv_pad;
+            cvo[i] = (((long)img * a.cv_h + cvy[i]) * a.cv_w + cvx[i]) * a.cv_cin + (c % CPR) * 8;
         }
     }
 
     auto load_into = [&](uint4 (&sx)[NX], uint4 (&sw)[NWc], int k0) {
-        int tap_c0 = 0, dy = 0, dx = 0;
+        int dy = 0, dx = 0;
+        long soff = 0;                  // CONV: element offset of this stage's tap and channel slice (uniform)
         if constexpr (CONV) {
-            const int tap = k0 / a.cv_cin;
-            tap_c0 = k0 - tap * a.cv_cin;
-            const int ky = tap / a.cv_k;
+            // per K stage and uniform: mul-hi divisions (k0 and cv_cin are multiples of 32) -- the hardware-division sequences were a
+            // good part of a stage of the small dense convs, which run one wave per SIMD with nothing to hide them behind
+            const int tap = (int)fd_div((unsigned)k0 >> 5, a.fd_cin32);
+            const int tap_c0 = k0 - tap * a.cv_cin;
+            const int ky = (int)fd_div((unsigned)tap, a.fd_k);
             dy = ky * a.cv_dil;
             dx = (tap - ky * a.cv_k) * a.cv_dil;
+            soff = ((long)dy * a.cv_w + dx) * a.cv_cin + tap_c0;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -118,7 +124,7 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             if constexpr (CONV) {
                 const int iy = cvy[i] + dy, ix = cvx[i] + dx;
                 if (m < M && k < K && iy >= 0 && iy < a.cv_h && ix >= 0 && ix < a.cv_w)
-                    v = *reinterpret_cast<const uint4*>(a.x + ((size_t)(cvn[i] * a.cv_h + iy) * a.cv_w + ix) * a.cv_cin + tap_c0 + q * 8);
+                    v = *reinterpret_cast<const uint4*>(a.x + (cvo[i] + soff));
             } else if (m < M && k < K && !(dbg & 2)) {
                 v = *reinterpret_cast<const uint4*>(a.x + (size_t)m * K + k);
                 if (a.se) {
@@ -916,6 +922,8 @@ PwArgs conv_to_pw(const ConvArgs& c) {
     PwArgs a;
     a.cv_k = c.k; a.cv_stride = c.stride; a.cv_pad = c.pad; a.cv_dil = c.dil; a.cv_h = c.h; a.cv_w = c.w_;
     a.cv_ho = c.ho; a.cv_wo = c.wo; a.cv_cin = c.cin;
+    a.fd_cin32 = fastdiv((unsigned)(c.cin >> 5));
+    a.fd_k = fastdiv((unsigned)c.k);
     a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out; a.zeros = c.zeros;
     a.hw = c.ho * c.wo;
     a.m = c.n * a.hw;
@@ -931,6 +939,8 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     PwArgs a;
     a.cv_k = c.k; a.cv_stride = c.stride; a.cv_pad = c.pad; a.cv_dil = c.dil; a.cv_h = c.h; a.cv_w = c.w_;
     a.cv_ho = c.ho; a.cv_wo = c.wo; a.cv_cin = c.cin;
+    a.fd_cin32 = fastdiv((unsigned)(c.cin >> 5));
+    a.fd_k = fastdiv((unsigned)c.k);
     a.x = c.x; a.w = c.w; a.bias = c.bias; a.residual = nullptr; a.se = nullptr; a.out = c.out; a.zeros = c.zeros;
     a.hw = c.ho * c.wo;
     a.m = c.n * a.hw;
@@ -938,5 +948,17 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
     a.xq = c.xq;
     DN_REQUIRE(a.m > 0, "conv: empty problem");
+    if (c.k == 1 && c.stride == 1 && c.pad == 0 && !c.out_fp32 && dn_knob("DN_CONV_1X1_AS_PW", 1)) {
+        // a 1x1 dense conv IS a pointwise conv: unless it is big enough for the 256 x 256-tile kernel, the pointwise path serves it
+        // (register-direct kernel up to cin = 256, 4-stage prefetch ring beyond; the implicit-GEMM body walks it one exposed stage at a time)
+        const long wg256 = (long)dn_cdiv(a.m, 256) * dn_cdiv(a.cout, 256);
+        if (!(dn_knob("DN_CONV_BIG", 1) && conv_big_supported(a) && wg256 >= dn_knob("DN_CONV_BIG_MIN", 40))) {
+            PwArgs b;
+            b.x = c.x; b.w = c.w; b.bias = c.bias; b.residual = nullptr; b.se = nullptr; b.out = c.out;
+            b.hw = a.hw; b.m = a.m; b.cin = c.cin; b.cout = c.cout; b.act = c.act; b.out_fp32 = 0; b.out_img_stride = 0; b.out_base = 0;
+            b.xq = c.xq;
+            return launch_pointwise(b, s);
+        }
+    }
     return launch_select<true>(a, s);
 }

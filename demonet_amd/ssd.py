@@ -262,11 +262,36 @@ class SSD(nn.Module):
         off = p.value - b["ws"].data_ptr()
         return b["ws"][off:off + sz.value].view(torch.float16).view(n, t.h, t.w, t.c).clone()
 
+    def compute_loss(self, targets: List[Dict[str, Tensor]], head_outputs: Dict[str, Tensor], anchors=None, matched_idxs=None,
+                     iou_thresh: float = 0.5, positive_fraction: float = 0.25) -> Dict[str, Tensor]:
+        """The VALUE of the training loss (generalized_ssd.py:210-269 on the matching of :316-330), computed on the GPU by
+        dn_ssd_loss (demonet_amd/loss.py); no gradients -- training itself stays out of scope. `anchors` defaults to the model's
+        own default boxes; `matched_idxs`, which the reference's forward computes and passes in, is recomputed here and, when
+        given, checked against."""
+        from .loss import ssd_loss
+        dev = head_outputs["cls_logits"].device
+        if anchors is None:
+            self._plan(dev)
+            anchors = torch.from_numpy(self._lowered.anchors).to(dev)
+        losses, matched = ssd_loss(head_outputs, anchors, targets, iou_thresh, (1.0 - positive_fraction) / positive_fraction)
+        if matched_idxs is not None:
+            given = torch.stack(list(matched_idxs)).to(matched.device)
+            if not torch.equal(given, matched):
+                raise ValueError("compute_loss: matched_idxs differ from the SSDMatcher result for these targets and anchors")
+        return losses
+
+    def loss(self, images: Tensor, targets: List[Dict[str, Tensor]]) -> Dict[str, Tensor]:
+        """Backbone + heads (forward_heads) -> compute_loss: the loss values a reference model in train mode would return for this
+        batch with the same (eval-mode, BN folded) weights. images: [N,3,H,W] at the network size."""
+        logits, reg = self.forward_heads(images)
+        return self.compute_loss(targets, {"cls_logits": logits, "bbox_regression": reg})
+
     def forward(self, images, targets: Optional[List[Dict[str, Tensor]]] = None):
         if self.training:
             if targets is None:
                 raise ValueError("In training mode, targets should be passed")     # generalized_ssd.py:273-274
-            raise NotImplementedError("demonet_amd implements the inference path only (SURVEY.md section 8)")
+            raise NotImplementedError("demonet_amd implements the inference path only (SURVEY.md section 8); the loss VALUE of a batch "
+                                      "is available through SSD.loss(images, targets) / compute_loss (no gradients)")
         legacy = isinstance(images, Tensor) and images.dim() == 4                   # hub call form model(x[1,3,S,S], shapes)
         if legacy:
             images = list(images.unbind(0))

@@ -175,6 +175,20 @@ DN_API int dn_set_packed_output(dn_plan* plan, float* packed_dev);
  * chain). Every kernel then runs once per sub-batch on ~n/split images; results are identical to the unsplit forward. */
 DN_API int dn_batch_split(const dn_plan* plan, int n);
 
+/* SSD training loss, forward value only (no gradients). Replaces, per batch: the matching of
+ * generalized_ssd.py:316-330 (torchvision box_iou -> SSDMatcher, _utils.py:264-294,348-362) and SSD.compute_loss
+ * (generalized_ssd.py:210-269: encode_boxes _utils.py:100-133, smooth_l1_loss(sum), cross_entropy(none), hard negative mining with
+ * neg_to_pos_ratio * (#label > 0) negatives per image, both sums / max(1, #matched anchors)).
+ * cls_logits [n][A][K] fp32, bbox_regression [n][A][4] fp32, anchors [A][4] fp32 xyxy (the same for every image, as
+ * DefaultBoxGenerator produces them), gt_boxes [n][gmax][4] fp32 xyxy / gt_labels [n][gmax] int64 padded, gt_counts [n] int32
+ * (0 = an image without boxes: all background). matched_idxs_dev (optional, [n][A] int64) receives the matched gt index or -1;
+ * losses_dev [2] = {bbox_regression, classification}. All pointers are device pointers; asynchronous on `stream`. */
+DN_API size_t dn_ssd_loss_workspace_bytes(int n, int num_anchors);
+DN_API int dn_ssd_loss(const float* cls_logits_dev, const float* bbox_regression_dev, const float* anchors_dev,
+                       const float* gt_boxes_dev, const int64_t* gt_labels_dev, const int32_t* gt_counts_dev,
+                       int n, int num_anchors, int num_classes, int gmax, float iou_thresh, float neg_to_pos_ratio,
+                       int64_t* matched_idxs_dev, float* losses_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 DN_API const char* dn_last_error(void);
 DN_API int dn_abi_version(void);
 

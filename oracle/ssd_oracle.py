@@ -608,3 +608,73 @@ def selection_margins(softmax: np.ndarray, decoded: np.ndarray, score_thresh, nm
     if allk.size >= 2:
         out["final_gap"] = float(np.min((allk[:-1] - allk[1:]) / allk[:-1]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# training loss, forward value -- restated from generalized_ssd.py:210-269,316-330 and _utils.py:100-133,264-294,348-362
+# ---------------------------------------------------------------------------------------------
+def box_iou_t(boxes1: torch.Tensor, boxes2: torch.Tensor) -> torch.Tensor:
+    """torchvision.ops.boxes.box_iou (third-party, published formula; called at generalized_ssd.py:326)."""
+    a1 = (boxes1[:, 2] - boxes1[:, 0]) * (boxes1[:, 3] - boxes1[:, 1])
+    a2 = (boxes2[:, 2] - boxes2[:, 0]) * (boxes2[:, 3] - boxes2[:, 1])
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return inter / (a1[:, None] + a2 - inter)
+
+
+def ssd_match(gt_boxes: torch.Tensor, anchors: torch.Tensor, iou_thresh: float = 0.5) -> torch.Tensor:
+    """SSDMatcher on box_iou (generalized_ssd.py:318-327; _utils.py:264-294 with low == high threshold, then :348-362: every gt
+    claims the anchor it overlaps most, in gt order). Explicit loops where the reference relies on index_put_ with duplicate
+    indices (the CPU kernel applies them in order: the last gt wins)."""
+    A = anchors.shape[0]
+    if gt_boxes.numel() == 0:
+        return torch.full((A,), -1, dtype=torch.int64)
+    q = box_iou_t(gt_boxes, anchors)                        # [G, A]
+    vals, matches = q.max(dim=0)                            # first maximum over the gts
+    matches = matches.clone()
+    matches[vals < iou_thresh] = -1
+    best_anchor = q.max(dim=1)[1]                           # first maximum over the anchors
+    for g in range(gt_boxes.shape[0]):
+        matches[int(best_anchor[g])] = g
+    return matches
+
+
+def encode_boxes_t(gt: torch.Tensor, anchors: torch.Tensor, weights=(10.0, 10.0, 5.0, 5.0)) -> torch.Tensor:
+    """_utils.py:100-133 (reference_boxes = gt, proposals = anchors)."""
+    ew, eh = anchors[:, 2] - anchors[:, 0], anchors[:, 3] - anchors[:, 1]
+    ecx, ecy = anchors[:, 0] + 0.5 * ew, anchors[:, 1] + 0.5 * eh
+    gw, gh = gt[:, 2] - gt[:, 0], gt[:, 3] - gt[:, 1]
+    gcx, gcy = gt[:, 0] + 0.5 * gw, gt[:, 1] + 0.5 * gh
+    return torch.stack([weights[0] * (gcx - ecx) / ew, weights[1] * (gcy - ecy) / eh,
+                        weights[2] * torch.log(gw / ew), weights[3] * torch.log(gh / eh)], dim=1)
+
+
+def ssd_loss_oracle(cls_logits: torch.Tensor, bbox_regression: torch.Tensor, anchors: torch.Tensor, targets,
+                    iou_thresh: float = 0.5, neg_to_pos_ratio: float = 3.0):
+    """generalized_ssd.py:210-269 after the matching of :316-330. Returns ({'bbox_regression', 'classification'}, matched [N, A])."""
+    import torch.nn.functional as F
+    n, A, K = cls_logits.shape
+    matched = torch.stack([ssd_match(t["boxes"].float(), anchors, iou_thresh) for t in targets])
+    num_foreground, bbox_loss, cls_targets = 0, [], []
+    for i, t in enumerate(targets):
+        fg = torch.where(matched[i] >= 0)[0]
+        mi = matched[i][fg]
+        num_foreground += mi.numel()
+        target_reg = encode_boxes_t(t["boxes"].float()[mi], anchors[fg])
+        bbox_loss.append(F.smooth_l1_loss(bbox_regression[i][fg], target_reg, reduction="sum"))
+        ct = torch.zeros((A,), dtype=torch.int64)
+        ct[fg] = t["labels"][mi]
+        cls_targets.append(ct)
+    cls_targets = torch.stack(cls_targets)
+    cls_loss = F.cross_entropy(cls_logits.reshape(-1, K), cls_targets.reshape(-1), reduction="none").view(n, A)
+    fgm = cls_targets > 0
+    num_negative = neg_to_pos_ratio * fgm.sum(1, keepdim=True)
+    neg = cls_loss.clone()
+    neg[fgm] = -float("inf")
+    _, idx = neg.sort(dim=1, descending=True, stable=True)
+    bgm = idx.sort(1)[1] < num_negative
+    N = max(1, num_foreground)
+    return ({"bbox_regression": torch.stack(bbox_loss).sum() / N,
+             "classification": (cls_loss[fgm].sum() + cls_loss[bgm].sum()) / N}, matched)
