@@ -39,6 +39,16 @@ def test_coco_records_follow_prepare_for_coco_detection():
     assert set(r) == {"image_id", "category_id", "bbox", "score"}
 
 
+def test_coco_records_equal_reference_function_output():
+    """tests/golden/coco_records.json: padded detections and the records the REAL CocoEvaluator.prepare_for_coco_detection
+    (data/coco_eval.py:76-98,162-164) built from them (make_coco_records_golden.py) -- same dicts, same order, same float values."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coco_records.json")))
+    recs = evalrec.coco_detection_records(np.array(g["boxes"], np.float32), np.array(g["scores"], np.float32), np.array(g["labels"], np.int64),
+                                          np.array(g["counts"], np.int32), g["image_ids"])
+    assert recs == g["records"]
+
+
 def test_voc_matching_rules():
     """voc_eval.py:116-153: confidence order, +1 pixel IoU, one claim per ground truth, 'difficult' ignored."""
     gt = {"a": (np.array([[10, 10, 50, 50], [100, 100, 150, 150]]), np.array([False, True])),
