@@ -663,6 +663,19 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
         }
         return lo * topk + (e - cpre[lo]);
     };
+    // The survivors' (score, slot) keys are fetched ONCE into LDS when they fit (a few thousand at most with the cut-off path): the
+    // four radix passes and the compaction then run out of LDS instead of repeating a binary search and a dependent global load
+    // per entry and pass (the kernel was five exposed memory round trips long: 20 us per launch at any batch size).
+    constexpr int LCAP = 3072;
+    __shared__ unsigned long long lkey[LCAP];
+    const bool in_lds = total <= (unsigned)LCAP;
+    if (in_lds) {
+        for (int e = tid; e < (int)total; e += MT) {
+            const unsigned f = (unsigned)slot_of(e);
+            lkey[e] = ((unsigned long long)__float_as_uint(ks[f]) << 32) | (unsigned long long)(0xFFFFFFFFu - f);
+        }
+        __syncthreads();
+    }
     unsigned T = 0, quota = 0;
     if (total > (unsigned)D) {
         unsigned prefix = 0, need = D;
@@ -670,7 +683,7 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             for (int e = tid; e < (int)total; e += MT) {
-                const unsigned k = __float_as_uint(ks[slot_of(e)]);
+                const unsigned k = in_lds ? (unsigned)(lkey[e] >> 32) : __float_as_uint(ks[slot_of(e)]);
                 if (shift == 24 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
             }
             __syncthreads();
@@ -691,8 +704,14 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
             const int e = e0i + tid;
             unsigned k = 0, f = 0;
             if (e < (int)total) {
-                f = (unsigned)slot_of(e);
-                k = __float_as_uint(ks[f]);
+                if (in_lds) {
+                    const unsigned long long kv0 = lkey[e];
+                    k = (unsigned)(kv0 >> 32);
+                    f = 0xFFFFFFFFu - (unsigned)(kv0 & 0xFFFFFFFFull);
+                } else {
+                    f = (unsigned)slot_of(e);
+                    k = __float_as_uint(ks[f]);
+                }
             }
             const bool gt = (k > T);
             const bool eq = (T != 0u) && (k == T);
