@@ -198,12 +198,22 @@ bool pw_direct_supported(const PwArgs& a) {
 
 int launch_pw_direct(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(pw_direct_supported(a), "pointwise (direct): unsupported cin=%d cout=%d", a.cin, a.cout);
-    // One 32-channel tile per wave (TC = 1): measured faster than two on every layer of the SSDLite chains -- these launches
-    // are latency-bound, and twice the waves with half the registers overlap their single memory round trip better. The channel
-    // block of a workgroup is as wide as the layer needs, up to 128 (the 4 waves then share the x rows in L1).
+    // One 32-channel tile per wave (TC = 1) on the narrow layers: these launches are latency-bound, and twice the waves with half the
+    // registers overlap their single memory round trip better. Wide expansions (cout >= DN_PW_DIRECT_TC2, short reductions) take two
+    // tiles per wave: every wave re-reads its x rows once per channel tile, and at 21 tiles (112 -> 672) that is most of the traffic
+    // (measured: threshold 400 -> batch 64 1.115 -> 1.107 ms, batch 32 0.79 -> 0.77 ms; 200 and 600 in between).
     const int ctiles = dn_cdiv(a.cout, 32);
+    const int ksf = a.cin >> 4;
+    if (ksf <= 8 && a.cout >= dn_knob("DN_PW_DIRECT_TC2", 400)) {
+        const int wc_log = ctiles <= 2 ? 0 : ctiles <= 4 ? 1 : 2;
+        switch (ksf) {
+#define DN_PWD_CASE2(k) case k: return launch_t<k, 2>(a, wc_log, s);
+            DN_PWD_CASE2(0) DN_PWD_CASE2(1) DN_PWD_CASE2(2) DN_PWD_CASE2(3) DN_PWD_CASE2(4) DN_PWD_CASE2(5) DN_PWD_CASE2(6) DN_PWD_CASE2(7) DN_PWD_CASE2(8)
+#undef DN_PWD_CASE2
+        }
+    }
     const int wc_log = ctiles <= 1 ? 0 : ctiles <= 2 ? 1 : 2;
-    switch (a.cin >> 4) {
+    switch (ksf) {
 #define DN_PWD_CASE(k) case k: return launch_t<k, 1>(a, wc_log, s);
         DN_PWD_CASE(0) DN_PWD_CASE(1) DN_PWD_CASE(2) DN_PWD_CASE(3) DN_PWD_CASE(4) DN_PWD_CASE(5) DN_PWD_CASE(6) DN_PWD_CASE(7) DN_PWD_CASE(8)
         DN_PWD_CASE(9) DN_PWD_CASE(10) DN_PWD_CASE(11) DN_PWD_CASE(12) DN_PWD_CASE(13) DN_PWD_CASE(14) DN_PWD_CASE(15) DN_PWD_CASE(16)
