@@ -256,7 +256,8 @@ def main():
         "config": {"workload": (f"{args.model} fp16, global batch {B * world} image-sharded over {world} GPUs ({B} per GPU), " if scaling == "strong"
                                 else f"{args.model} fp16, batch {B} per GPU, ") + f"{H}x{W} synthetic images, K={ncls}, "
                                f"synthetic weights seed 0, post-process incl. per-class top-{g.post['topk_candidates']} + hard NMS",
-                   "global_batch": B * world, "launch": ("eager" if args.eager else "hipGraph replay") + f", {model.batch_split(B)} sub-batch branch(es)",
+                   "global_batch": B * world, "launch": ("eager" if args.eager else "hipGraph replay") + (f", {model.batch_split(B)} sub-batch chains" + (
+                       " as branches of one graph" if B >= 64 or os.environ.get("DN_CHAIN_GRAPHS") == "0" else " as one graph each on its own stream") if model.batch_split(B) > 1 else ", one chain"),
                    "parallelism": f"image-sharded x{world}, RCCL all_gather of detections (windows of {gatherer.K} steps)" if distributed else "single GPU",
                    "input": "NCHW fp32 in [0,1], device-resident" if args.input == "f32" else "NHWC uint8 (decoder output), device-resident",
                    "mean_detections": float(counts.float().mean().item())},
