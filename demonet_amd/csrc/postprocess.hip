@@ -318,8 +318,32 @@ __device__ __forceinline__ void nms_serial_phase(const unsigned long long* cand,
             // testing l = 0..nvalid-1 one by one.
             const unsigned vmask_lo = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
             const unsigned vmask_hi = nvalid >= 64 ? 0xFFFFFFFFu : (nvalid > 32 ? ((1u << (nvalid - 32)) - 1u) : 0u);
+            // Fixed-point form first: removed = external | OR of the rows of the not-removed candidates. The mask is strictly upper
+            // triangular (a row only suppresses later candidates), so bit l of any fixed point is determined by the bits below l: the
+            // fixed point is unique and IS the greedy result; iteration t fixes the candidates of dependency depth < t. With little
+            // suppression inside a chunk (random boxes: depth 2 - 3) that is a few wave-wide ORs instead of 64 dependent
+            // readlane steps (15 -> 4 us for a class with top-k candidates); deep chains fall through to the sequential walk.
+            bool settled = false;
+            {
+                unsigned cur_lo = rem_lo, cur_hi = rem_hi;
+#pragma unroll 1
+                for (int it = 0; it < 6; ++it) {
+                    const bool alive = lane < nvalid && !(((lane < 32 ? cur_lo : cur_hi) >> (lane & 31)) & 1u);
+                    unsigned o_lo = alive ? lo : 0u, o_hi = alive ? hi : 0u;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) {
+                        o_lo |= __shfl_xor(o_lo, d);
+                        o_hi |= __shfl_xor(o_hi, d);
+                    }
+                    const unsigned n_lo = __builtin_amdgcn_readfirstlane(o_lo) | rem_lo, n_hi = __builtin_amdgcn_readfirstlane(o_hi) | rem_hi;
+                    if (n_lo == cur_lo && n_hi == cur_hi) { settled = true; break; }
+                    cur_lo = n_lo;
+                    cur_hi = n_hi;
+                }
+                if (settled) { rem_lo = cur_lo; rem_hi = cur_hi; }
+            }
             unsigned done_lo = 0u, done_hi = 0u;          // candidates already visited
-            while (true) {
+            while (!settled) {
                 const unsigned cur_lo = ~(rem_lo | done_lo) & vmask_lo, cur_hi = ~(rem_hi | done_hi) & vmask_hi;
                 if ((cur_lo | cur_hi) == 0u) break;
                 const int l = cur_lo ? __builtin_ctz(cur_lo) : 32 + __builtin_ctz(cur_hi);
