@@ -13,7 +13,9 @@ Pinning status:
     absent from /root/reference and from this image): restated from the published algorithm
     (per-class greedy NMS, IoU = inter/(a+b-inter), suppress when IoU > thr, kept indices in
     global score-descending order). PARITY UNPINNED for that step; fixtures assert tie-freeness
-    and an IoU margin so any faithful torchvision would agree.
+    and an IoU margin (3e-6 .. 2e-5), so any torchvision that runs NMS as a per-class loop would agree;
+    the coordinate-offset form of batched_nms (offsets up to ~29 000 px cost ~2e-3 px of float32
+    resolution) is outside those margins.
 
 All `reference:` citations are relative to /root/reference/demonet/models/.
 """
