@@ -61,7 +61,7 @@ __device__ __forceinline__ void act_n(V& v, int act) {
 //   * activations: one uniform switch per accumulator (act_n);
 //   * every global load is unconditional with a clamped address (a predicated load costs a branch and a conservative wait).
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 2 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 5 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
     constexpr bool WIDE = PROJ && EXP && KSM <= 2;          // may take a last chunk of 72 channels whole
@@ -403,7 +403,10 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     if (proj) {
         if (a.xw == 24) return launch_k<K, S, OH, OW, 2, true, true, 3>(a, tiles_x, tiles_y, zsplit, lds, s);
         if (a.xw == 40 && a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, true, 5>(a, tiles_x, tiles_y, zsplit, lds, s);
+        if (a.xw == 56) return launch_k<K, S, OH, OW, 2, true, true, 7>(a, tiles_x, tiles_y, zsplit, lds, s);        // cin 40
         if (a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
+        if (a.xw == 88) return launch_k<K, S, OH, OW, 5, true, true, 11>(a, tiles_x, tiles_y, zsplit, lds, s);       // cin 80: the 20 x 20 blocks
+        if (a.cin <= 88) return launch_k<K, S, OH, OW, 5, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
         return launch_k<K, S, OH, OW, XKS, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
     }
     if (a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, false, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
@@ -425,7 +428,7 @@ int launch_ks(const ExpDwArgs& a, int oh, int ow, hipStream_t s) {
 
 }  // namespace
 
-void expdw_tile(int Ho, int Wo, int stride, int* oh, int* ow) {
+void expdw_tile(int Ho, int Wo, int stride, int* oh, int* ow, int proj_cout = 0) {
     // dev knob: DN_EXPDW_TILE = 48 / 88 forces the 4 x 8 / 8 x 8 output tile on the large maps (tile-size experiments)
     const int force = dn_knob("DN_EXPDW_TILE", 0);
     if (force && Wo >= 32 && Ho >= 32) { *oh = force / 10; *ow = force % 10; return; }
@@ -433,6 +436,8 @@ void expdw_tile(int Ho, int Wo, int stride, int* oh, int* ow) {
     else if (Wo <= 10) { *oh = 5; *ow = 10; }
     else if (Wo < 32 && Wo % 16 != 0) {                     // 19x19 / 20x20 maps: 10-wide tiles waste nothing
         if (stride == 1) { *oh = 10; *ow = 10; } else { *oh = 5; *ow = 10; }
+        // with a project stage the (pixel tile x channel tile) units must fit the 8 waves: 100 pixels x 80 channels = 12 units, 50 x 80 = 6
+        if (proj_cout > 0 && ((*oh * *ow + 31) / 32) * ((proj_cout + 31) / 32) > NT / 64) { *oh = 5; *ow = 10; }
     }
     else { *oh = 8; *ow = (stride == 1) ? 16 : 8; }
 }
@@ -450,7 +455,7 @@ bool expdw_supported(int cin, int cexp, int k, int stride) {
 // the project stage keeps one MFMA accumulator per wave: (pixels of the tile / 32) x (cout / 32) units must fit the 8 waves
 bool expdw_project_supported(int cexp, int cout, int Ho, int Wo, int stride) {
     int oh, ow;
-    expdw_tile(Ho, Wo, stride, &oh, &ow);
+    expdw_tile(Ho, Wo, stride, &oh, &ow, cout);
     return cexp % 8 == 0 && cout % 8 == 0 && ((oh * ow + 31) / 32) * ((cout + 31) / 32) <= NT / 64;
 }
 
@@ -465,7 +470,7 @@ int launch_expdw(const ExpDwArgs& a0, hipStream_t s) {
     DN_REQUIRE(a.n > 0 && a.H > 0 && a.W > 0 && a.Ho > 0 && a.Wo > 0, "expand+depthwise: empty problem");
     a.xw = ((a.cin + 15) / 16) * 16 + 8;
     int oh, ow;
-    expdw_tile(a.Ho, a.Wo, a.stride, &oh, &ow);
+    expdw_tile(a.Ho, a.Wo, a.stride, &oh, &ow, a.w3 ? a.cout : 0);
     if (a.k == 3 && a.stride == 1) return launch_ks<3, 1>(a, oh, ow, s);
     if (a.k == 3 && a.stride == 2) return launch_ks<3, 2>(a, oh, ow, s);
     if (a.k == 5 && a.stride == 1) return launch_ks<5, 1>(a, oh, ow, s);

@@ -336,14 +336,17 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             if (o.se >= 0) uses[o.se]++;
         }
         for (int l = 0; l < desc->n_levels; ++l) uses[desc->level_tensor[l]] += 100;    // features must be materialised
-        // project stage only where the map is large (one workgroup must own all expanded channels) and the expand's A fragments
-        // fit the small register variant (cin <= 32); measured: wins on the 160^2 / 80^2 blocks
-        const int proj_min_hw = getenv("DN_EXPDW_PROJ_MINHW") ? atoi(getenv("DN_EXPDW_PROJ_MINHW")) : 6400;
+        // project stage (whole inverted-residual block in one launch) down to the 20 x 20 maps: one workgroup owns all expanded channels
+        // of its pixel tile (chunk loop), the expand's A fragments fit the register variants up to cin = 88, and the (pixel tile x
+        // channel tile) units of the projection must fit the 8 waves (5 x 10 pixel tiles there). Measured: the 160^2 / 80^2 blocks
+        // -20 % each (round 1); the four blocks without squeeze-excitation on the 20 x 20 maps (40->240->80 stride 2, 80->200->80,
+        // 2 x 80->184->80: three launches of 5 - 11 us each become one of 11 - 17 us) batch 64 1.10 -> 1.055 ms, batch 32 0.765 -> 0.74
+        const int proj_min_hw = getenv("DN_EXPDW_PROJ_MINHW") ? atoi(getenv("DN_EXPDW_PROJ_MINHW")) : 400;
         auto plain_pw = [&](const dn_op_desc& o) { return o.type == DN_OP_PW && !o.head && o.se < 0; };
         auto dw_ok = [&](const dn_op_desc& o) { return o.type == DN_OP_DW && !o.head && o.dil == 1; };
         auto proj_ok = [&](const dn_op_desc& pj, const dn_op_desc& d, int block_in) {
             const dn_tensor_desc& to = p->tensors[d.out];
-            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= 128 &&
+            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= dn_knob("DN_EXPDW_PROJ_MAXCEXP", 256) &&
                    to.h * to.w >= proj_min_hw && expdw_project_supported(d.cin, pj.cout, to.h, to.w, d.stride) &&
                    (pj.residual < 0 || (pj.residual == block_in && d.stride == 1 && pj.cout == p->tensors[block_in].c));
         };
@@ -353,8 +356,10 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             if (plain_pw(a) && a.residual < 0 && uses[a.out] == 1 && dw_ok(d) && d.in == a.out && p->tensors[a.in].kind == DN_T_ACT &&
                 expdw_supported(a.cin, a.cout, d.k, d.stride)) {
                 const dn_tensor_desc& to = p->tensors[d.out];
-                if (to.h * to.w > max_hw || to.h * to.w < min_hw) continue;
-                if (i + 2 < desc->n_ops && a.cin <= dn_knob("DN_EXPDW_PROJ_MAXCIN", 32) && proj_ok(p->ops[i + 2], d, a.in)) {
+                if (to.h * to.w > max_hw) continue;
+                const bool can_proj = i + 2 < desc->n_ops && a.cin <= dn_knob("DN_EXPDW_PROJ_MAXCIN", 88) && proj_ok(p->ops[i + 2], d, a.in);
+                if (to.h * to.w < min_hw && !can_proj) continue;      // below the expand+depthwise threshold only whole blocks fuse
+                if (can_proj) {
                     p->fused_len[i] = 3; p->fused_kind[i] = 3; i += 2;
                 } else {
                     p->fused_len[i] = 2; p->fused_kind[i] = 1; i += 1;
