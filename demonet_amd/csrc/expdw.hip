@@ -409,7 +409,10 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
         if (a.cin <= 88) return launch_k<K, S, OH, OW, 5, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
         return launch_k<K, S, OH, OW, XKS, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
     }
+    if (a.xw == 56) return launch_k<K, S, OH, OW, 2, true, false, 7>(a, tiles_x, tiles_y, zsplit, lds, s);          // cin 40
+    if (a.xw == 40 && a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, false, 5>(a, tiles_x, tiles_y, zsplit, lds, s);   // cin 24 / 32
     if (a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, false, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
+    if (a.xw == 88) return launch_k<K, S, OH, OW, 5, true, false, 11>(a, tiles_x, tiles_y, zsplit, lds, s);         // cin 80 (squeeze-excitation blocks of the 20 x 20 / 10 x 10 maps)
     return launch_k<K, S, OH, OW, XKS, true, false, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
 }
 
