@@ -341,12 +341,12 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         // channel tile) units of the projection must fit the 8 waves (5 x 10 pixel tiles there). Measured: the 160^2 / 80^2 blocks
         // -20 % each (round 1); the four blocks without squeeze-excitation on the 20 x 20 maps (40->240->80 stride 2, 80->200->80,
         // 2 x 80->184->80: three launches of 5 - 11 us each become one of 11 - 17 us) batch 64 1.10 -> 1.055 ms, batch 32 0.765 -> 0.74
-        const int proj_min_hw = getenv("DN_EXPDW_PROJ_MINHW") ? atoi(getenv("DN_EXPDW_PROJ_MINHW")) : 400;
+        const int proj_min_hw = getenv("DN_EXPDW_PROJ_MINHW") ? atoi(getenv("DN_EXPDW_PROJ_MINHW")) : 300;      // (19 x 19 maps of the 300-pixel models included)
         auto plain_pw = [&](const dn_op_desc& o) { return o.type == DN_OP_PW && !o.head && o.se < 0; };
         auto dw_ok = [&](const dn_op_desc& o) { return o.type == DN_OP_DW && !o.head && o.dil == 1; };
         auto proj_ok = [&](const dn_op_desc& pj, const dn_op_desc& d, int block_in) {
             const dn_tensor_desc& to = p->tensors[d.out];
-            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= dn_knob("DN_EXPDW_PROJ_MAXCEXP", 256) &&
+            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= dn_knob("DN_EXPDW_PROJ_MAXCEXP", 400) &&
                    to.h * to.w >= proj_min_hw && expdw_project_supported(d.cin, pj.cout, to.h, to.w, d.stride) &&
                    (pj.residual < 0 || (pj.residual == block_in && d.stride == 1 && pj.cout == p->tensors[block_in].c));
         };
