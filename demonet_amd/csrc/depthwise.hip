@@ -34,7 +34,7 @@ __device__ __forceinline__ void dw_se_tail(const DwArgs& a, const int n, const i
             for (int b0 = 0; b0 < nblk; b0 += 16) {
                 float v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = p0[(size_t)min(b0 + u, nblk - 1) * c + ic];
+                for (int u = 0; u < 16; ++u) v[u] = __hip_atomic_load(&p0[(size_t)min(b0 + u, nblk - 1) * c + ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) t += (b0 + u < nblk) ? v[u] : 0.f;
             }
@@ -175,21 +175,29 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t8[e] += red[u * 8 + e];
             float* dst = a.pool + ((size_t)n * nblocks + bx) * a.c + cgp * 8;
+            if (a.se_scale) {
+                // published for the last workgroup of the image (below): device-scope atomic stores go to the coherence point
+                // themselves, so no cache-flushing fence is needed to make them visible
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dst[e] = t8[e];
+                for (int e = 0; e < 8; ++e) __hip_atomic_store(&dst[e], t8[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e] = t8[e];
+            }
         }
         if (a.se_scale) {
             // last workgroup of the image (threadfence + counter, the classic "last block" reduction): its partial sums and
             // everybody else's are visible after the fences; the counter goes back to zero for the next launch
-            // (ONE fence per workgroup, by the thread that signals: the barrier orders the other threads' stores before it and the
-            // device-scope release is cumulative. A fence per thread is an L2 write-back per wave: 100 us per launch, measured.)
+            // Last workgroup of the image: ticket by a relaxed device-scope atomic. NO device-scope fence: on gfx950 a release at agent
+            // scope writes back the XCD's whole L2 (measured: +20 - 100 us per launch, once per workgroup). The partial sums were
+            // stored with device-scope atomics; a workgroup-scope fence (s_waitcnt: the stores are acknowledged by the coherence point)
+            // + barrier orders them before the ticket of thread 0, and the last workgroup reads them back with device-scope atomic
+            // loads. (Hardware reasoning, not the formal model: the formal release would be the flushing fence.)
             __shared__ int s_last;
+            __threadfence_block();
             __syncthreads();
-            if (threadIdx.x == 0) {
-                __threadfence();
-                s_last = atomicAdd(&a.se_counter[n], 1u) == (unsigned)(nblocks - 1);
-                if (s_last) __threadfence();
-            }
+            if (threadIdx.x == 0)
+                s_last = __hip_atomic_fetch_add(&a.se_counter[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1);
             __syncthreads();
             if (s_last) {
                 dw_se_tail(a, n, nblocks, red);

@@ -479,6 +479,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         int users = 0;
         for (int q = 0; q < desc->n_ops; ++q) users += p->ops[q].se == so.out;
         if (users == 1 && pw_se_fold_supported(pj.cin, pj.cout, so.squeeze, ti.h * ti.w)) {
+            // DN_SE_SMALL=1 (see below): these small FCs go to the tail of the pooling depthwise launch instead and the projection runs
+            // on the register-direct kernel with the scale applied to its x fragments
+            if (dn_knob("DN_SE_SMALL", 0) && (ti.h * ti.w) % 32 == 0 && pj.cin <= 128 && depthwise_se_tail_supported(so.cin, so.squeeze)) continue;
             p->se_fold[i] = -2;
             p->se_fold[i + 1] = i;
         }
@@ -486,17 +489,21 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     // ---- the other squeeze-excitations (opt-in, DN_SE_IN_DW=1): their FCs run in the tail of the depthwise launch that pools for
     //      them (the last workgroup of an image to finish; depthwise.hip dw_se_tail) instead of a 32-workgroup launch of their own.
     //      Needs the plain depthwise launch (not the fused expand+depthwise, tail or trunk runs) and the stem launch, which clears
-    //      the counters. MEASURED and left off: the FCs of the large blocks stream 230 - 450 KB of weights into ONE compute unit
-    //      per image, a 256-thread workgroup needs ~14 dependent memory round trips for that (the 1024-thread se_fc_kernel
-    //      three), and the tail sits on the critical path of the chain: the 20 x 20 depthwise launches go from 10 to 50 us,
-    //      batch 64 from 1.12 to 1.32 ms.
+    //      the counters. MEASURED and left off. With a device-scope fence per workgroup the 20 x 20 depthwise launches went from
+    //      10 to 50 us (a release at agent scope writes back the XCD's L2: batch 64 1.12 -> 1.32 ms). With the fence-free publish
+    //      (device-scope atomic stores / loads of the partial sums, relaxed ticket) the launch overhead is gone, but the FCs of the
+    //      large blocks stream 230 - 450 KB of weights into ONE compute unit per image on 256 threads: batch 64 1.063 -> 1.068 ms.
+    //      DN_SE_SMALL=1 does the same for the small squeeze-excitations only (instead of folding them into the projection's
+    //      prologue), the projection then runs on the register-direct kernel with the scale applied to its x fragments:
+    //      1.063 -> 1.054 ms at batch 64, no change at 32 / 16 -- inside the noise of the gain it would have to justify.
     p->se_in_dw.assign(desc->n_ops, -1);
     p->se_slot.assign(desc->n_ops, -1);
     p->n_se_in_dw = 0;
-    if (dn_knob("DN_SE_IN_DW", 0) != 0 && p->ops[0].type == DN_OP_STEM) {
+    if ((dn_knob("DN_SE_IN_DW", 0) != 0 || dn_knob("DN_SE_SMALL", 0) != 0) && p->ops[0].type == DN_OP_STEM) {
         for (int i = 1; i < desc->n_ops; ++i) {
             const dn_op_desc& so = p->ops[i];
             if (so.type != DN_OP_SE || p->se_fold[i] == -2) continue;
+            if (!dn_knob("DN_SE_IN_DW", 0) && !(so.cin <= 128 && so.squeeze <= 32)) continue;      // DN_SE_SMALL alone: the small ones only
             int j = -1;
             for (int q = 0; q < i; ++q) if (p->ops[q].type == DN_OP_DW && p->ops[q].pool == so.in) j = q;
             if (j < 1 || !depthwise_se_tail_supported(so.cin, so.squeeze)) continue;

@@ -88,10 +88,26 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
 #pragma unroll
         for (int i = 0; i < TC; ++i) wf[i][ks] = *reinterpret_cast<const half8*>(wpt[i] + ks * 16);
     }
+    // squeeze-excitation scale of the wave's image (a 32-row tile never straddles two images here: hw % 32 == 0, pw_direct_supported),
+    // requested with the operands: s[k] for this lane's columns of every step
+    const bool has_se = a.se != nullptr;
+    float4 sv[KSM][2], svl[2];
+    const float* sp = has_se ? a.se + (size_t)(mrow0 / a.hw) * K + hh * 8 : nullptr;
+    if (has_se) {
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) {
+            sv[ks][0] = *reinterpret_cast<const float4*>(sp + ks * 16);
+            sv[ks][1] = *reinterpret_cast<const float4*>(sp + ks * 16 + 4);
+        }
+    }
     // last step: this lane's columns kb .. kb+7; kb < K: data (address clamped, value selected below); kb == K: the bias columns
     const int kb = KSF * 16 + hh * 8;
     const int kcl = min(kb, K - 8) - hh * 8;
     half8 xl = *reinterpret_cast<const half8*>(xp + kcl);
+    if (has_se) {
+        svl[0] = *reinterpret_cast<const float4*>(sp + kcl);
+        svl[1] = *reinterpret_cast<const float4*>(sp + kcl + 4);
+    }
     half8 wl[TC];
     float bl[TC];
 #pragma unroll
@@ -108,6 +124,18 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 rres[i][g] = *reinterpret_cast<const uint2*>(rp + min(n_base + i * 32 + 8 * g + 4 * hh, NC - 4));
+    }
+    if (has_se) {
+        // (half)((float)x * s): the rounding of the tiled kernel's squeeze-excitation path (pointwise.hip load_into)
+        auto scale8 = [](half8 v, const float4& s0, const float4& s1) {
+            const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * s[e]);
+            return v;
+        };
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) xf[ks] = scale8(xf[ks], sv[ks][0], sv[ks][1]);
+        xl = scale8(xl, svl[0], svl[1]);
     }
     {
         const bool data = kb < K, bcol = kb == K;
@@ -192,7 +220,9 @@ int launch_t(const PwArgs& a, int wc_log, hipStream_t s) {
 }  // namespace
 
 bool pw_direct_supported(const PwArgs& a) {
-    return dn_knob("DN_PW_DIRECT", 1) != 0 && a.cv_k == 1 && !a.out_fp32 && !a.se && !a.sef_part && !a.w_b && a.cin % 8 == 0 && a.cin >= 8 &&
+    // squeeze-excitation scaled inputs: only where a 32-row tile lies inside one image (the 40 x 40 maps) and the reduction is short
+    if (a.se && !(a.hw % 32 == 0 && a.cin <= 128 && dn_knob("DN_PW_DIRECT_SE", 1))) return false;
+    return dn_knob("DN_PW_DIRECT", 1) != 0 && a.cv_k == 1 && !a.out_fp32 && !a.sef_part && !a.w_b && a.cin % 8 == 0 && a.cin >= 8 &&
            a.cin <= 256 && a.cout % 8 == 0 && a.cout >= 8 && !(a.act >> 8) && a.out_img_stride == 0 && a.out_base == 0;
 }
 
