@@ -61,7 +61,7 @@ __device__ __forceinline__ void act_n(V& v, int act) {
 //   * activations: one uniform switch per accumulator (act_n);
 //   * every global load is unconditional with a clamped address (a predicated load costs a branch and a conservative wait).
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 5 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
     constexpr bool WIDE = PROJ && EXP && KSM <= 2;          // may take a last chunk of 72 channels whole
@@ -407,6 +407,7 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
         if (a.cin <= 40) return launch_k<K, S, OH, OW, 2, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
         if (a.xw == 88) return launch_k<K, S, OH, OW, 5, true, true, 11>(a, tiles_x, tiles_y, zsplit, lds, s);       // cin 80: the 20 x 20 blocks
         if (a.cin <= 88) return launch_k<K, S, OH, OW, 5, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
+        if (a.xw == 104) return launch_k<K, S, OH, OW, 6, true, true, 13>(a, tiles_x, tiles_y, zsplit, lds, s);      // cin 96
         return launch_k<K, S, OH, OW, XKS, true, true, 0>(a, tiles_x, tiles_y, zsplit, lds, s);
     }
     if (a.xw == 56) return launch_k<K, S, OH, OW, 2, true, false, 7>(a, tiles_x, tiles_y, zsplit, lds, s);          // cin 40

@@ -346,7 +346,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         auto dw_ok = [&](const dn_op_desc& o) { return o.type == DN_OP_DW && !o.head && o.dil == 1; };
         auto proj_ok = [&](const dn_op_desc& pj, const dn_op_desc& d, int block_in) {
             const dn_tensor_desc& to = p->tensors[d.out];
-            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= dn_knob("DN_EXPDW_PROJ_MAXCEXP", 400) &&
+            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= dn_knob("DN_EXPDW_PROJ_MAXCEXP", 640) &&
                    to.h * to.w >= proj_min_hw && expdw_project_supported(d.cin, pj.cout, to.h, to.w, d.stride) &&
                    (pj.residual < 0 || (pj.residual == block_in && d.stride == 1 && pj.cout == p->tensors[block_in].c));
         };
@@ -357,7 +357,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
                 expdw_supported(a.cin, a.cout, d.k, d.stride)) {
                 const dn_tensor_desc& to = p->tensors[d.out];
                 if (to.h * to.w > max_hw) continue;
-                const bool can_proj = i + 2 < desc->n_ops && a.cin <= dn_knob("DN_EXPDW_PROJ_MAXCIN", 88) && proj_ok(p->ops[i + 2], d, a.in);
+                const bool can_proj = i + 2 < desc->n_ops && a.cin <= dn_knob("DN_EXPDW_PROJ_MAXCIN", 96) && proj_ok(p->ops[i + 2], d, a.in);
                 if (to.h * to.w < min_hw && !can_proj) continue;      // below the expand+depthwise threshold only whole blocks fuse
                 if (can_proj) {
                     p->fused_len[i] = 3; p->fused_kind[i] = 3; i += 2;
