@@ -406,16 +406,18 @@ def test_se_fold_matches_separate_se_kernel(n):
     assert (res["0"][1] - res["1"][1]).abs().max().item() < 4e-2
 
 
+@pytest.mark.parametrize("knob", ["DN_SE_IN_DW", "DN_SE_SMALL"])
 @pytest.mark.parametrize("n", [3, 37])
-def test_se_tail_in_depthwise_launch_matches_se_kernel(n):
+def test_se_tail_in_depthwise_launch_matches_se_kernel(n, knob):
     """DN_SE_IN_DW=1 (opt-in, measured slower -- plan.hip): the FCs of the large squeeze-excitations run in the last workgroup of
-    the pooling depthwise launch (threadfence + counter) instead of the se_fc launch. Same arithmetic up to the order of the fp32
-    sums, i.e. the decorrelation noise of test_se_fold_matches_separate_se_kernel; a second forward checks that the counters were
-    left at zero."""
+    the pooling depthwise launch (device-scope atomic publish + ticket) instead of the se_fc launch; DN_SE_SMALL=1 does that for the
+    small squeeze-excitations only (instead of the projection-prologue fold) and runs their projections on the register-direct
+    kernel with the scale applied to its x fragments. Same arithmetic up to the order of the fp32 sums, i.e. the decorrelation
+    noise of test_se_fold_matches_separate_se_kernel; a second forward checks that the counters were left at zero."""
     imgs = torch.from_numpy(synth.images(67, n, 320, 320)).cuda()
     res = {}
     for flag in ("0", "1"):
-        os.environ["DN_SE_IN_DW"] = flag
+        os.environ[knob] = flag
         try:
             m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
             first = [t.clone() for t in m.forward_heads(imgs)]
@@ -423,7 +425,7 @@ def test_se_tail_in_depthwise_launch_matches_se_kernel(n):
             assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
             res[flag] = first
         finally:
-            del os.environ["DN_SE_IN_DW"]
+            del os.environ[knob]
     d = (res["0"][0] - res["1"][0]).abs()
     print(f"n={n}: SE tail vs SE kernel logits max|d| {d.max().item():.4g} mean {d.mean().item():.3g}")
     assert d.max().item() < 6e-2 and d.mean().item() < 5e-3
