@@ -116,6 +116,7 @@ struct dn_plan {
     // early heads: the head launches of the first `head_early` pyramid levels leave the chain as soon as their feature map exists
     // and run on a side stream of the chain (a parallel branch of the graph) while the backbone goes on; joined before the post-process
     int head_early = 0;
+    int head_inline = 0;                    // DN_HEAD_STAGGER: the early levels' head launches stay ON the chain's stream, right after their feature map (1: odd chains only, 2: all)
     int head_fork_op = -1;                  // op whose output is the last early level's feature map
     hipStream_t head_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_head_fork[4] = {}, ev_head_join[4] = {};
@@ -617,7 +618,11 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         // instead of extending it. MEASURED and left off: a fork inside a chain's graph costs far more than the ~80 us of head
         // launches it hides -- batch 64: 1.13 -> 1.44 ms (level 0), 1.33 ms (levels 0-1); batch 32: 0.78 -> 1.13 ms. (A fork inside
         // a forked branch of one graph also crashes hipStreamEndCapture on ROCm 7.2, hence per-chain graphs in this mode.)
-        const int want = dn_knob("DN_HEAD_EARLY", 0);
+        // DN_HEAD_STAGGER (default 0): the same early launches but ON the chain's own stream (no fork), for odd chains only (1) or all (2),
+        // so that the two chains do not run their head GEMMs at the same moment. MEASURED and left off: batch 64 1.060 -> 1.065 (1) /
+        // 1.078 ms (2), batch 32 0.739 -> 0.747 / 0.762 ms -- the early-born head buffers cost more workspace reuse than the staggering gains.
+        p->head_inline = dn_knob("DN_HEAD_STAGGER", 0);
+        const int want = dn_knob("DN_HEAD_EARLY", p->head_inline > 0 ? 1 : 0);
         p->head_early = 0;
         p->head_fork_op = -1;
         if (want > 0 && want < desc->n_levels && p->head_first >= 0 && !p->multi_stream) {
@@ -858,7 +863,8 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     };
     int ev = ev0;
     hipStream_t const main_stream = s;
-    const bool branch = !record && p->head_early > 0 && p->head_fork_op >= 0 && chain >= 0 && chain < 4;
+    const bool inl = p->head_inline == 2 || (p->head_inline == 1 && (chain & 1));
+    const bool branch = !record && p->head_early > 0 && p->head_fork_op >= 0 && chain >= 0 && chain < 4 && (p->head_inline == 0 || inl);
     bool forked = false;
     // head launches of the pyramid levels [lv0, lv1): the depthwise group, then the 1x1 / dense group(s), on stream hs
     auto launch_heads = [&](int lv0, int lv1, hipStream_t hs, bool rec, size_t& seg) -> int {
@@ -982,10 +988,12 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         };
         if (branch && !forked && (int)i > p->head_fork_op && (int)i < p->head_first) {
             // the early levels' feature maps exist: their head launches leave the chain here
-            DN_HIP_CHECK(hipEventRecord(p->ev_head_fork[chain], main_stream));
-            DN_HIP_CHECK(hipStreamWaitEvent(p->head_stream[chain], p->ev_head_fork[chain], 0));
+            if (!inl) {
+                DN_HIP_CHECK(hipEventRecord(p->ev_head_fork[chain], main_stream));
+                DN_HIP_CHECK(hipStreamWaitEvent(p->head_stream[chain], p->ev_head_fork[chain], 0));
+            }
             size_t seg_side = 0;
-            int hrc = launch_heads(0, p->head_early, p->head_stream[chain], false, seg_side);
+            int hrc = launch_heads(0, p->head_early, inl ? main_stream : p->head_stream[chain], false, seg_side);
             if (hrc != DN_OK) return hrc;
             forked = true;
         }
@@ -995,7 +1003,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             size_t seg = i;
             rc = launch_heads(forked ? p->head_early : 0, 1 << 20, s, record, seg);
             if (rc != DN_OK) return rc;
-            if (forked) {
+            if (forked && !inl) {
                 DN_HIP_CHECK(hipEventRecord(p->ev_head_join[chain], p->head_stream[chain]));
                 DN_HIP_CHECK(hipStreamWaitEvent(main_stream, p->ev_head_join[chain], 0));
             }
@@ -1294,7 +1302,7 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     // two runs of three and 0.82 - 0.85 ms in the third (the placement of the branches differs from process to process); at batch
     // 64 one graph is 0.7 % faster (1.127 vs 1.135 ms). Default: per-chain graphs below 64 images.
     const bool want_chains = p->chain_graphs < 0 ? n < 64 : p->chain_graphs != 0;
-    const bool per_chain = S > 1 && (want_chains || (p->head_early > 0 && p->head_fork_op >= 0));
+    const bool per_chain = S > 1 && (want_chains || (p->head_early > 0 && p->head_fork_op >= 0 && p->head_inline == 0));
     const int flags = (heads_only ? 1 : 0) | (p->input_u8 ? 2 : 0);
     auto capture = [&](const GraphKey& key, hipGraphExec_t* out) -> int {
         hipGraph_t g = nullptr;
