@@ -6,7 +6,10 @@
 A step = one pass of the whole hot path (stem .. heads .. softmax/decode/top-k/NMS/merge) over one device-resident
 batch of synthetic 320x320 images (BASELINE.json configs[1]: ssdlite320_mobilenet_v3_large fp16, batch 64 per GPU).
 Timing window = engine.evaluate's (engine.py:86-94): inputs already on the device, synchronize, forward incl.
-post-process, outputs complete on the stream. N > 1: BASELINE configs[3] -- the global batch 256 is image-sharded, 256 / N per
+post-process, outputs complete on the stream. The K timed steps go through demonet_amd.pipeline.ForwardPipeline: `--inflight`
+(default 3) forwards are kept in flight, each a complete single-chain forward of its own batch on its own stream with its own
+workspace and outputs -- the serving form of the path; `one_at_a_time` in the JSON line repeats the K steps with one forward in
+flight (SSD.forward_batch) and `latency` is the per-forward distribution of that mode. N > 1: BASELINE configs[3] -- the global batch 256 is image-sharded, 256 / N per
 rank (--batch overrides the per-GPU size: weak scaling); the fixed-shape
 detections of every step are staged on the device and all-gathered over RCCL one window (16 steps) at a time, the last window
 flushed inside the timed region (the reference gathers once, after the loop: engine.py:105).
@@ -162,6 +165,9 @@ def main():
                     help="f32: NCHW float images in [0,1] (the headline window, engine.py:86); u8: the decoder's [N,H,W,3] uint8 output")
     ap.add_argument("--weights", choices=["calibrated", "worstcase"], default="calibrated",
                     help="worstcase: class-head weights shrunk so every score passes score_thresh (all K-1 x topk candidates reach NMS; SURVEY 8d)")
+    ap.add_argument("--inflight", type=int, default=-1, help="forwards kept in flight (demonet_amd.pipeline.ForwardPipeline: one stream, workspace and "
+                    "output set per forward, each a single whole-batch chain). -1 = 3 (measured best of 2..12 at batch 32 and 64, tools/pipeline_probe.py), "
+                    "1 = one forward at a time through SSD.forward_batch (two sub-batch chains per forward from 32 images up)")
     ap.add_argument("--no-latency", action="store_true", help="skip the per-step latency percentiles / D2H-inclusive step time (extra passes after the timed region)")
     ap.add_argument("--per-op", default="", help="write a per-op table (time, GB/s, TFLOP/s) to this file")
     args = ap.parse_args()
@@ -208,13 +214,36 @@ def main():
     images = torch.from_numpy(synth.images(1002 + rank, B, H, W)).to(dev)      # device-resident input (engine.py:86)
     if args.eager:
         model.set_graph_mode(False)
-    images_u8 = (images * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous() if args.input == "u8" else None
+    to_u8 = lambda x: (x * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    images_u8 = to_u8(images) if args.input == "u8" else None
 
     gatherer = DetectionGatherer(B, g.post["detections_per_img"], dev) if distributed else None
+    R = args.inflight if args.inflight > 0 else 3
+    if args.eager:
+        R = 1
+    pipe = None
+    if R > 1:
+        # the serving form: R forwards in flight, each a single whole-batch chain (demonet_amd/pipeline.py); one device-resident
+        # synthetic batch per slot (slot 0 holds the batch of the one-at-a-time mode)
+        from demonet_amd.pipeline import ForwardPipeline
+        pipe = ForwardPipeline(model, B, depth=R, chains=1, device=dev, uint8=images_u8 is not None, packed=distributed)
+        batches = [images] + [torch.from_numpy(synth.images(3002 + 16 * rank + j, B, H, W)).to(dev) for j in range(1, R)]
+        if images_u8 is not None:
+            batches = [images_u8] + [to_u8(x) for x in batches[1:]]
+    nstep = [0]
 
     def step():
+        if pipe is not None:
+            k = nstep[0]
+            nstep[0] += 1
+            t = pipe.submit(batches[k % R], persistent_input=True)
+            if distributed:
+                # the merge kernel writes the gather payload itself; it is staged per step (on the forward's own stream) and
+                # all-gathered per window of steps
+                with torch.cuda.stream(pipe.stream_of(t)):
+                    gatherer.submit(src=pipe.packed(t), join=pipe.join)
+            return t
         if distributed:
-            # the merge kernel writes the gather payload itself; it is staged per step and all-gathered per window of steps
             boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True, packed=gatherer.next_buffer())
             gatherer.submit()
         elif images_u8 is not None:
@@ -223,7 +252,7 @@ def main():
             boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True)
         return counts
 
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(args.warmup, 2 * R)):
         step()
     torch.cuda.synchronize(dev)
     if distributed:
@@ -233,7 +262,11 @@ def main():
     for _ in range(args.steps):
         counts = step()
     if distributed:
-        gatherer.flush()
+        if pipe is not None:
+            with torch.cuda.stream(pipe.stream_of(counts)):
+                gatherer.flush(join=pipe.join)
+        else:
+            gatherer.flush()
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
@@ -245,6 +278,13 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt          # whole-job aggregate: every rank processed B images per step
+    if pipe is not None:
+        counts = pipe.result(counts)[3]
+        chains_timed = 1
+        pipe.close()                              # back to the automatic split: the sections below run one forward at a time
+        pipe = None
+    else:
+        chains_timed = model.batch_split(B)
 
     result = {
         "metric": "images/sec ssdlite320_mobilenet_v3_large fp16 end-to-end incl. NMS" if args.model.startswith("ssdlite320")
@@ -256,8 +296,10 @@ def main():
         "config": {"workload": (f"{args.model} fp16, global batch {B * world} image-sharded over {world} GPUs ({B} per GPU), " if scaling == "strong"
                                 else f"{args.model} fp16, batch {B} per GPU, ") + f"{H}x{W} synthetic images, K={ncls}, "
                                f"synthetic weights seed 0, post-process incl. per-class top-{g.post['topk_candidates']} + hard NMS",
-                   "global_batch": B * world, "launch": ("eager" if args.eager else "hipGraph replay") + (f", {model.batch_split(B)} sub-batch chains" + (
-                       " as branches of one graph" if B >= 64 or os.environ.get("DN_CHAIN_GRAPHS") == "0" else " as one graph each on its own stream") if model.batch_split(B) > 1 else ", one chain"),
+                   "global_batch": B * world, "forwards_in_flight": R,
+                   "launch": (f"hipGraph replay, {R} forwards in flight (one stream, workspace and output set each; one plan), each forward a single chain of {B} images" if R > 1 else
+                              ("eager" if args.eager else "hipGraph replay") + (f", one forward at a time, {model.batch_split(B)} sub-batch chains" + (
+                                  " as branches of one graph" if B >= 64 or os.environ.get("DN_CHAIN_GRAPHS") == "0" else " as one graph each on its own stream") if model.batch_split(B) > 1 else ", one forward at a time, one chain")),
                    "parallelism": f"image-sharded x{world}, RCCL all_gather of detections (windows of {gatherer.K} steps)" if distributed else "single GPU",
                    "input": "NCHW fp32 in [0,1], device-resident" if args.input == "f32" else "NHWC uint8 (decoder output), device-resident",
                    "mean_detections": float(counts.float().mean().item())},
@@ -286,6 +328,16 @@ def main():
                 out = model.forward_batch(images, persistent_input=True)
             host = [t.cpu() for t in out]
         d2h_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        if R > 1:
+            # the same K steps one forward at a time (SSD.forward_batch, its own in-forward split): what the pipelining buys
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize(dev)
+            dt2 = time.perf_counter() - t2
+            result["one_at_a_time"] = {"value": round(B * args.steps / dt2, 1), "unit": "images/sec", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                                       "sub_batch_chains": model.batch_split(B)}
         result["latency"] = {"p10_ms": pick(0.10), "median_ms": pick(0.50), "p90_ms": pick(0.90), "samples": len(lat),
                              "ms_per_step_with_d2h": round(d2h_ms, 4),
                              "d2h_bytes": int(sum(t.numel() * t.element_size() for t in host))}
@@ -296,6 +348,10 @@ def main():
         L = _lib.lib()
         h = C.c_void_p(model._handle)
         nseg = len(g.nodes) + 3
+        if chains_timed == 1 and _lib.check(L.dn_batch_split(h, B)) != 1:
+            # the timed region ran whole-batch chains: profile the kernels at that size
+            _lib.check(L.dn_set_chains(h, 1))
+            model._bufs = {}
         _lib.check(L.dn_profile_begin(h))
         for _ in range(min(args.steps, 20)):
             model.forward_batch(images, persistent_input=True)

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "dn_profile_begin": (C.c_int, [C.c_void_p]),
     "dn_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "dn_batch_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "dn_set_chains": (C.c_int, [C.c_void_p, C.c_int]),
     "dn_profile_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32)]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -122,6 +122,7 @@ struct dn_plan {
     hipEvent_t ev_head_fork[4] = {}, ev_head_join[4] = {};
     hipEvent_t ev_fork = nullptr, ev_branch[3] = {nullptr, nullptr, nullptr};
     std::map<std::pair<int, int>, Layout> sub_layouts;
+    int chains_override = 0;                // dn_set_chains: > 0 = that many sub-batch chains per forward whatever the batch size
     float* packed_out = nullptr;
     bool input_u8 = false;                  // the current call's images are [n][h][w][3] uint8 (dn_forward_u8)
     // head ops (dw -> 1x1 / dense 3x3 per level, both heads) run as grouped launches once the backbone is done
@@ -155,7 +156,9 @@ struct dn_plan {
 // two branches; more branches lose again, and below 32 images there is nothing to gain). Every workspace tensor is
 // image-major, so a sub-batch simply addresses rows [n0, n0 + ns) of the same layout.
 static int batch_split(const dn_plan* p, int n) {
-    if (p->split <= 1 || n < 32 || p->multi_stream) return 1;
+    if (p->multi_stream) return 1;
+    if (p->chains_override > 0) return std::min(p->chains_override, n);
+    if (p->split <= 1 || n < 32) return 1;
     return p->split;
 }
 static int sub_count(int n, int S, int k) { const int base = n / S, rem = n % S; return base + (k < rem ? 1 : 0); }
@@ -480,9 +483,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         int users = 0;
         for (int q = 0; q < desc->n_ops; ++q) users += p->ops[q].se == so.out;
         if (users == 1 && pw_se_fold_supported(pj.cin, pj.cout, so.squeeze, ti.h * ti.w)) {
-            // DN_SE_SMALL=1 (see below): these small FCs go to the tail of the pooling depthwise launch instead and the projection runs
+            // DN_SE_SMALL (default 1, see below): these small FCs go to the tail of the pooling depthwise launch instead and the projection runs
             // on the register-direct kernel with the scale applied to its x fragments
-            if (dn_knob("DN_SE_SMALL", 0) && (ti.h * ti.w) % 32 == 0 && pj.cin <= 128 && depthwise_se_tail_supported(so.cin, so.squeeze)) continue;
+            if (dn_knob("DN_SE_SMALL", 1) && (ti.h * ti.w) % 32 == 0 && pj.cin <= 128 && depthwise_se_tail_supported(so.cin, so.squeeze)) continue;
             p->se_fold[i] = -2;
             p->se_fold[i + 1] = i;
         }
@@ -496,11 +499,12 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     //      large blocks stream 230 - 450 KB of weights into ONE compute unit per image on 256 threads: batch 64 1.063 -> 1.068 ms.
     //      DN_SE_SMALL=1 does the same for the small squeeze-excitations only (instead of folding them into the projection's
     //      prologue), the projection then runs on the register-direct kernel with the scale applied to its x fragments:
-    //      1.063 -> 1.054 ms at batch 64, no change at 32 / 16 -- inside the noise of the gain it would have to justify.
+    //      1.063 -> 1.054 ms at batch 64, no change at 32 / 16 one forward at a time; with three forwards in flight (pipeline.py)
+    //      0.840 -> 0.825 ms at batch 64 and 0.463 -> 0.458 ms at 32: on by default.
     p->se_in_dw.assign(desc->n_ops, -1);
     p->se_slot.assign(desc->n_ops, -1);
     p->n_se_in_dw = 0;
-    if ((dn_knob("DN_SE_IN_DW", 0) != 0 || dn_knob("DN_SE_SMALL", 0) != 0) && p->ops[0].type == DN_OP_STEM) {
+    if ((dn_knob("DN_SE_IN_DW", 0) != 0 || dn_knob("DN_SE_SMALL", 1) != 0) && p->ops[0].type == DN_OP_STEM) {
         for (int i = 1; i < desc->n_ops; ++i) {
             const dn_op_desc& so = p->ops[i];
             if (so.type != DN_OP_SE || p->se_fold[i] == -2) continue;
@@ -706,6 +710,23 @@ extern "C" void dn_destroy(dn_plan* p) {
 extern "C" size_t dn_workspace_bytes(const dn_plan* p, int n) {
     if (!p || n <= 0) return 0;
     return get_layout(const_cast<dn_plan*>(p), n).total;
+}
+
+// The in-forward split trades launch-bound kernels for two half-size chains that run in lockstep. A caller that keeps several
+// FORWARDS in flight (one stream, workspace and output set each; demonet_amd/pipeline.py) overlaps chains that sit in different
+// phases instead, and is better served by one whole-batch chain per forward: batch 64, three in flight: 0.84 ms per forward
+// against 1.06 ms for one forward at a time as two chains (tools/pipeline_probe.py).
+extern "C" int dn_set_chains(dn_plan* p, int chains) {
+    DN_REQUIRE(p, "null plan");
+    DN_REQUIRE(chains >= 0 && chains <= 4, "dn_set_chains: %d outside [0, 4] (0 = automatic)", chains);
+    if (chains == p->chains_override) return DN_OK;
+    p->chains_override = chains;
+    // layouts, workspace sizes and captured graphs all depend on the split
+    for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
+    p->graphs.clear();
+    p->layouts.clear();
+    p->sub_layouts.clear();
+    return DN_OK;
 }
 
 extern "C" int dn_set_graph_mode(dn_plan* p, int enabled) {
@@ -1326,7 +1347,7 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
         // first call with this signature: run once eagerly (sets function attributes, validates), then capture
         int rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, false);
         if (rc) return rc;
-        if (p->graphs.size() + (per_chain ? S : 1) > 16) {       // bound the cache
+        if (p->graphs.size() + (per_chain ? S : 1) > 64) {       // bound the cache (a pipeline of forwards holds one entry per slot and output set)
             for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
             p->graphs.clear();
         }

@@ -61,13 +61,16 @@ class DetectionGatherer:
         self.n = 0                  # next ticket (steps submitted, plus the slots a flush() of a partial window skipped)
         self.gathered = 0           # tickets covered by completed collectives (always a multiple of the window after a gather)
         self.filled = [0, 0]        # per gathered window (two deep): how many of its slots hold a submitted step
+        self._ring_free = None      # event: the last collective has read the ring (submits from OTHER streams wait for it)
 
     def next_buffer(self):
         """The packed buffer the forward should write into (SSD.forward_batch(packed=...): the merge kernel fills it, no
         torch-side packing -- a strided torch copy of the boxes alone costs more than the whole forward)."""
         return self.packed
 
-    def _gather_window(self):
+    def _gather_window(self, join=None):
+        if join is not None:
+            join()                  # forwards on several streams (pipeline.ForwardPipeline): this stream waits for all their copies
         w = (self.gathered // self.K) & 1
         self.filled[w] = self.n - self.gathered
         if self.world == 1 and not dist.is_initialized():
@@ -75,30 +78,38 @@ class DetectionGatherer:
         else:
             dist.all_gather_into_tensor(self.out[w].view(self.world, -1), self.acc.view(1, -1), group=self.group)
         self.gathered = (self.gathered // self.K + 1) * self.K
+        if self.acc.is_cuda:
+            self._ring_free = torch.cuda.Event()
+            self._ring_free.record(torch.cuda.current_stream(self.acc.device))
 
-    def submit(self, boxes=None, scores=None, labels=None, counts=None):
+    def submit(self, boxes=None, scores=None, labels=None, counts=None, src=None, join=None):
         """Call on the compute stream right after the forward; returns the step's ticket. With arguments the payload is
-        packed here (CPU tests / callers without the packed output); without, `packed` was filled by the forward."""
+        packed here (CPU tests / callers without the packed output); without, `packed` was filled by the forward.
+        Forwards on several streams (pipeline.ForwardPipeline): call it with the forward's stream current, src = that forward's
+        packed buffer and join = pipeline.join -- the copy into the ring runs on that stream, and the collective that closes a
+        window first waits for the other streams."""
         slot = self.n % self.K
         p = self.acc[slot]
         D = self.D
+        if self._ring_free is not None:
+            torch.cuda.current_stream(self.acc.device).wait_event(self._ring_free)
         if boxes is not None:
             p[:, :D, :4].copy_(boxes)
             p[:, :D, 4].copy_(scores)
             p[:, :D, 5].copy_(labels)
             p[:, D, 0].copy_(counts)
         else:
-            p.copy_(self.packed)            # 0.5 MB device copy on the compute stream; frees `packed` for the next forward
+            p.copy_(self.packed if src is None else src)    # 0.5 MB device copy on the compute stream; frees the buffer for the next forward
         ticket = self.n
         self.n += 1
         if slot == self.K - 1:
-            self._gather_window()
+            self._gather_window(join)
         return ticket
 
-    def flush(self):
+    def flush(self, join=None):
         """Gather the last, partial window (collective: every rank calls it after the same number of steps)."""
         if self.gathered < self.n:
-            self._gather_window()
+            self._gather_window(join)
             # the rest of that window was never submitted: the next submit() starts a fresh window (otherwise its ticket would
             # already count as gathered and result() would hand out the stale rows of the flushed window)
             self.n = self.gathered

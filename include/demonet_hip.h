@@ -174,6 +174,11 @@ DN_API int dn_set_packed_output(dn_plan* plan, float* packed_dev);
 /* Number of independent sub-batch launch chains a forward of n images is issued as (parallel hipGraph branches; 1 = a single
  * chain). Every kernel then runs once per sub-batch on ~n/split images; results are identical to the unsplit forward. */
 DN_API int dn_batch_split(const dn_plan* plan, int n);
+/* Overrides that choice: chains > 0 = every forward is issued as min(chains, n) sub-batch chains, 0 = back to the automatic
+ * choice. For callers that keep several forwards in flight on streams of their own (one workspace and output set per forward):
+ * whole-batch chains of different forwards overlap better than the half-size chains of one. Changes dn_workspace_bytes and drops
+ * the cached graphs: call it before sizing workspaces, with no forward of this plan in flight. */
+DN_API int dn_set_chains(dn_plan* plan, int chains);
 
 /* SSD training loss, forward value only (no gradients). Replaces, per batch: the matching of
  * generalized_ssd.py:316-330 (torchvision box_iou -> SSDMatcher, _utils.py:264-294,348-362) and SSD.compute_loss

@@ -55,6 +55,23 @@ def _worker(rank, world, port, ret):
     for step, t in enumerate(idx2):
         pk, cn = G.result(t)
         assert torch.equal(pk[rank * B:(rank + 1) * B, :, :4], boxes + 10 + step) and cn.tolist() == [D, 2, 0, 1, D, 3]
+    # the pipelined form (ForwardPipeline: every forward has a payload buffer of its own, the window-closing collective first joins
+    # the forwards' streams): src = that buffer, join called once per collective -- per window and per flush
+    G2 = DetectionGatherer(B, D, "cpu", every=2)
+    joins = []
+    bufs = [torch.zeros(B, D + 1, 6) for _ in range(3)]
+    tick = []
+    for step in range(5):
+        b = bufs[step % 3]
+        b[:, :D] = pack_detections(boxes + 20 + step, scores, labels)
+        b[:, D, 0] = counts.float()
+        tick.append(G2.submit(src=b, join=lambda: joins.append(G2.n)))
+    assert joins == [2, 4]                    # after the 2nd and 4th submit
+    G2.flush(join=lambda: joins.append(-1))
+    assert joins == [2, 4, -1]
+    for step in (2, 3, 4):
+        pk, cn = G2.result(tick[step])
+        assert torch.equal(pk[rank * B:(rank + 1) * B, :, :4], boxes + 20 + step) and cn.tolist() == [D, 2, 0, 1, D, 3]
     # bench.py's C4 sharding arithmetic: global batch 256 over 8 ranks -> 32 contiguous images each, every image exactly once
     world8 = [shard_range(256, r, 8) for r in range(8)]
     assert all(hi - lo == 32 for lo, hi in world8) and [lo for lo, _ in world8] == list(range(0, 256, 32))

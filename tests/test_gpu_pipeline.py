@@ -1,0 +1,145 @@
+"""GPU tests (-m gpu) of demonet_amd.pipeline.ForwardPipeline: several forwards of one plan in flight must return, per batch,
+exactly what one forward at a time returns (the oracle parity of that single forward is test_gpu_model.py's subject)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from demonet_amd import _lib, models, synth
+from demonet_amd.dist import pack_detections
+from demonet_amd.pipeline import ForwardPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name="ssdlite320_mobilenet_v3_large", ncls=91):
+    m = getattr(models, name)(num_classes=ncls)
+    models.load_synthetic(m, 0)
+    return m.cuda()
+
+
+def _batches(g, count, n, seed=40):
+    W, H = g.size
+    return [torch.from_numpy(synth.images(seed + i, n, H, W)).cuda() for i in range(count)]
+
+
+@pytest.mark.parametrize("n,depth", [(8, 3), (32, 2), (5, 4)])
+def test_pipeline_equals_one_forward_at_a_time(n, depth):
+    """Seven different batches through a pipeline `depth` deep, results read as late as the contract allows (just before their
+    slot is reused): bit-identical to forward_batch on the same images as single-chain forwards. Runs twice over the same slots,
+    so both the first (eager + capture) and the replayed launches of every slot are covered."""
+    m = _model()
+    batches = _batches(m.graph, 7, n)
+    with ForwardPipeline(m, n, depth=depth, packed=True) as pipe:
+        assert m.batch_split(n) == 1                      # whole-batch chains while the pipeline is open
+        ref = [[t.clone() for t in m.forward_batch(b)] for b in batches]
+        torch.cuda.synchronize()
+        for _ in range(2):
+            got = {}
+            base = pipe.n
+            grab = lambda j: ([x.clone() for x in pipe.result(base + j)], pipe.packed(base + j).clone())
+            for k, b in enumerate(batches):
+                assert pipe.submit(b) == base + k
+                if k - (depth - 1) >= 0:                   # the oldest forward still alive: the next submit overwrites it
+                    got[k - (depth - 1)] = grab(k - (depth - 1))
+            for j in range(max(0, len(batches) - depth + 1), len(batches)):
+                got[j] = grab(j)
+            assert sorted(got) == list(range(len(batches)))
+            for k in range(len(batches)):
+                out, packed = got[k]
+                for a, b in zip(ref[k], out):
+                    assert torch.equal(a, b), "batch %d" % k
+                D = ref[k][1].shape[1]
+                assert torch.equal(packed[:, :D], pack_detections(ref[k][0], ref[k][1], ref[k][2]))
+                assert torch.equal(packed[:, D, 0].to(torch.int32), ref[k][3])
+            assert int(sum(int(r[3].sum()) for r in ref)) > 0
+    # closed: the automatic split is back and the model's own forward still works
+    assert m.batch_split(64) == 2
+    again = m.forward_batch(batches[0])
+    torch.cuda.synchronize()
+    if n < 32:
+        for a, b in zip(ref[0], again):
+            assert torch.equal(a, b)
+
+
+def test_pipeline_persistent_inputs_and_detections_form():
+    m = _model()
+    n, depth = 4, 2
+    batches = _batches(m.graph, depth, n, seed=70)
+    ref = [[t.clone() for t in m.forward_batch(b)] for b in batches]
+    with ForwardPipeline(m, n, depth=depth) as pipe:
+        for rnd in range(3):                              # the same tensor lands on the same slot every time: direct replay
+            ts = [pipe.submit(b, persistent_input=True) for b in batches]
+            for k, t in enumerate(ts):
+                for a, b in zip(ref[k], pipe.result(t)):
+                    assert torch.equal(a, b)
+        dets = pipe.detections(ts[1])
+        assert len(dets) == n and list(dets[0]) == ["boxes", "scores", "labels"]
+        for i, d in enumerate(dets):
+            c = int(ref[1][3][i])
+            assert d["boxes"].shape == (c, 4) and d["labels"].dtype == torch.int64
+            assert torch.equal(d["scores"], ref[1][1][i, :c])
+        # stream-ordered hand-over without a host wait
+        t = pipe.submit(batches[0], persistent_input=True)
+        pipe.wait(t)
+        s = pipe.slots[t % depth].scores.clone()
+        torch.cuda.synchronize()
+        assert torch.equal(s, ref[0][1])
+
+
+def test_pipeline_uint8_input():
+    m = _model()
+    n = 3
+    W, H = m.graph.size
+    u8 = [(torch.from_numpy(synth.images(90 + i, n, H, W)).cuda() * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+          for i in range(3)]
+    ref = [[t.clone() for t in m.forward_uint8(x)] for x in u8]
+    with ForwardPipeline(m, n, depth=2, uint8=True) as pipe:
+        for k, x in enumerate(u8):
+            t = pipe.submit(x)
+            for a, b in zip(ref[k], pipe.result(t)):
+                assert torch.equal(a, b)
+        with pytest.raises(ValueError):
+            pipe.submit(u8[0].float())
+
+
+def test_pipeline_errors():
+    m = _model()
+    n = 2
+    b = _batches(m.graph, 1, n)[0]
+    with pytest.raises(ValueError):
+        ForwardPipeline(m, n, depth=0)
+    pipe = ForwardPipeline(m, n, depth=2)
+    with pytest.raises(RuntimeError, match="never submitted"):
+        pipe.result(0)
+    ts = [pipe.submit(b) for _ in range(3)]
+    with pytest.raises(RuntimeError, match="overwritten"):
+        pipe.result(ts[0])
+    pipe.result(ts[1]); pipe.result(ts[2])
+    with pytest.raises(ValueError):
+        pipe.submit(b[:1])
+    with pytest.raises(TypeError):                        # transform.py:130-134
+        pipe.submit((b * 255).to(torch.int32))
+    with pytest.raises(RuntimeError, match="packed=True"):
+        pipe.packed(ts[2])
+    m.invalidate()                                        # the plan the pipeline replays is gone
+    with pytest.raises(RuntimeError, match="rebuilt"):
+        pipe.submit(b)
+    pipe.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        pipe.submit(b)
+
+
+def test_set_chains_abi():
+    m = _model()
+    m.forward_batch(_batches(m.graph, 1, 2)[0])
+    L, h = _lib.lib(), C.c_void_p(m._handle)
+    assert L.dn_batch_split(h, 64) == 2 and L.dn_batch_split(h, 16) == 1
+    ws2 = L.dn_workspace_bytes(h, 64)
+    assert L.dn_set_chains(h, 1) == 0
+    assert L.dn_batch_split(h, 64) == 1
+    assert L.dn_workspace_bytes(h, 64) > ws2 // 2         # sized for the new split (one chain of 64 rows instead of two of 32)
+    assert L.dn_set_chains(h, 3) == 0 and L.dn_batch_split(h, 64) == 3 and L.dn_batch_split(h, 2) == 2
+    assert L.dn_set_chains(h, 5) != 0 and b"dn_set_chains" in L.dn_last_error()
+    assert L.dn_set_chains(h, 0) == 0 and L.dn_batch_split(h, 64) == 2 and L.dn_workspace_bytes(h, 64) == ws2
+    m._bufs = {}

@@ -25,7 +25,7 @@ for r in rows:
     out.write(f"{n[:60]:60s} calls/step {calls/50:5.1f} avg {avg:7.1f} min {float(r['MinNs'])/1e3:6.1f} us  per-step {t/50:7.1f} us\n")
 out.write(f"sum per step {tot:.1f} us\n")
 try:
-    d=json.loads(open('$OUT/log_$NAME.txt').read().strip().splitlines()[-1])
+    d=json.loads([l for l in open('$OUT/log_$NAME.txt').read().splitlines() if l.startswith('{')][-1])
     out.write(f"bench: {d['value']} img/s {d['ms_per_step']} ms/step\n")
 except Exception as e:
     out.write(f"bench line unreadable: {e}\n")
