@@ -271,6 +271,7 @@ struct ExpDwArgs {
     int xw, chunks_per_wg;                         // filled by the launcher
     int xq;                                        // XCD grouping: images per group (0: plain mapping)
     long long* stamps;                             // dev-only
+    int stage_out = 0; FastDiv fd_oc8 = {1, 0};    // filled by the launcher: the projected tile leaves through LDS as row-contiguous 16-byte chunks
 };
 int launch_expdw(const ExpDwArgs& a, hipStream_t s);
 int expdw_tiles_per_image(int Ho, int Wo, int stride);

@@ -60,11 +60,12 @@ __device__ __forceinline__ void act_n(V& v, int act) {
 //     depthwise needs -- without a per-element inside test, bias add or select;
 //   * activations: one uniform switch per accumulator (act_n);
 //   * every global load is unconditional with a clamped address (a predicated load costs a branch and a conservative wait).
-template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8>
+template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
-    constexpr bool WIDE = PROJ && EXP && KSM <= 2;          // may take a last chunk of 72 channels whole
+    constexpr bool WIDE = WD && PROJ && EXP && KSM <= 2;    // may take a last chunk of 72 channels whole (WD: cexp % 64 == 8 -- the extra
+                                                            // fragments cost 32 registers, which a 64-channel block would only spill)
     static_assert(K * K * 9 <= NT, "one 16-byte piece of the chunk's depthwise weights per thread");
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     const int XW = XW8 > 0 ? XW8 * 8 : a.xw;                // halfs per X row: round16(cin) + 8
@@ -340,12 +341,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
         c0 = cnext;
     }
     if constexpr (PROJ) {
-        // lane = output pixel (row tile prt, row r), registers 4g..4g+3 = channels pc*32 + 8g + 4hh .. +3
+        // lane = output pixel (row tile prt, row r), registers 4g..4g+3 = channels pc*32 + 8g + 4hh .. +3.
+        // The tile leaves through LDS (Os, over the dead E / depthwise buffers) as 16-byte chunks that are consecutive along a tile
+        // row: written straight from this layout every store instruction puts 8-byte pieces at the pixel stride (48 B for the
+        // 24-channel maps), the L2 evicts the half-written lines under the input stream and the 80 x 80 outputs cost 4 - 10x their
+        // size in HBM writes (profiles/r02_hbm_traffic.json before this: 97 MB written for a 9.8 MB output).
+        half_t* Os = Es;
+        const bool staged = a.stage_out != 0;                   // uniform: the tile fits the dead buffers (launcher)
         const int opix = prt * 32 + r;
         const int oy = opix / OW, ox = opix - oy * OW;
         const int gy = oy0 + oy, gx = ox0 + ox;
-        if (punit && opix < OH * OW && gy < a.Ho && gx < a.Wo) {
-            half_t* orow = a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * a.cout;
+        if (punit && opix < OH * OW && (staged || (gy < a.Ho && gx < a.Wo))) {
+            half_t* orow = staged ? Os + opix * a.cout : a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * a.cout;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = pc * 32 + 8 * g + 4 * hh;
@@ -364,17 +371,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
                 }
             }
         }
+        if (staged) {
+            __syncthreads();
+            const int oc8 = a.cout >> 3;
+            for (int i = tid; i < OH * OW * oc8; i += NT) {
+                const int px = (int)fd_div((unsigned)i, a.fd_oc8), c8 = i - px * oc8;
+                const int py = px / OW, pxx = px - py * OW;
+                const int y = oy0 + py, x = ox0 + pxx;
+                if (y < a.Ho && x < a.Wo)
+                    *reinterpret_cast<uint4*>(a.out + (((size_t)n * a.Ho + y) * a.Wo + x) * a.cout + c8 * 8) =
+                        *reinterpret_cast<const uint4*>(Os + px * a.cout + c8 * 8);
+            }
+        }
     }
     XD_STAMP(4);
 }
 
+template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD>
+int launch_kw(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
+    const dim3 grid(a.xq > 0 ? 8 * tiles_x : tiles_x, tiles_y * zsplit, a.xq > 0 ? a.xq : a.n);
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>)));
+    dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
+    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
+    return DN_OK;
+}
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8>
 int launch_k(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
-    const dim3 grid(a.xq > 0 ? 8 * tiles_x : tiles_x, tiles_y * zsplit, a.xq > 0 ? a.xq : a.n);
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8>)));
-    dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
-    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
-    return DN_OK;
+    if constexpr (PROJ && EXP && KSM <= 2) {
+        if (a.cexp % 64 == 8 && dn_knob("DN_EXPDW_WIDE", 1)) return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, true>(a, tiles_x, tiles_y, zsplit, lds, s);
+    }
+    return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, false>(a, tiles_x, tiles_y, zsplit, lds, s);
 }
 
 template <int K, int S, int OH, int OW>
@@ -394,6 +420,13 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     while (!proj && cpw > 1 && (long)tiles * a.n * dn_cdiv(chunks, cpw) < want) --cpw;
     a.chunks_per_wg = cpw;
     a.stamps = g_xd_stamps;
+    if (proj) {
+        // the output tile is staged over the E .. depthwise-output buffers (everything between the X rows and the project bias)
+        const size_t avail = ((exp ? (size_t)G::ROWS * EW : 0) + K * K * EW + (size_t)DROWS * EW) * sizeof(half_t) + (EW + NT / 64 * 64) * sizeof(float);
+        a.stage_out = dn_knob("DN_EXPDW_STAGE_OUT", 1) && (size_t)OH * OW * a.cout * sizeof(half_t) <= avail && a.cout % 8 == 0 &&
+                      fd_ok((unsigned long long)OH * OW * (a.cout >> 3), (unsigned)(a.cout >> 3));
+        a.fd_oc8 = fastdiv((unsigned)(a.cout >> 3));
+    }
     const int zsplit = dn_cdiv(chunks, cpw);
     DN_REQUIRE((long)tiles_y * zsplit <= 65535 && a.n <= 65535, "expand+depthwise: grid too large");
     if (proj) DN_REQUIRE((DROWS / 32) * dn_cdiv(a.cout, 32) <= NT / 64, "expand+depthwise+project: %d output units for %d waves", (DROWS / 32) * dn_cdiv(a.cout, 32), NT / 64);
