@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=-1, help="forwards kept in flight (demonet_amd.pipeline.ForwardPipeline: one stream, workspace and "
                     "output set per forward, each a single whole-batch chain). -1 = 3 (measured best of 2..12 at batch 32 and 64, tools/pipeline_probe.py), "
                     "1 = one forward at a time through SSD.forward_batch (two sub-batch chains per forward from 32 images up)")
+    ap.add_argument("--chains", type=int, default=0, help="with --inflight 1 / --eager: sub-batch chains per forward (0 = the library's choice: 2 from 32 "
+                    "images up). The PMC passes of tools/round_profile.sh use --eager --chains 1: the kernels at the launch size of the timed region")
     ap.add_argument("--no-latency", action="store_true", help="skip the per-step latency percentiles / D2H-inclusive step time (extra passes after the timed region)")
     ap.add_argument("--per-op", default="", help="write a per-op table (time, GB/s, TFLOP/s) to this file")
     args = ap.parse_args()
@@ -222,6 +224,9 @@ def main():
     if args.eager:
         R = 1
     pipe = None
+    if R == 1 and args.chains > 0:
+        from demonet_amd import _lib as _l
+        _l.check(_l.lib().dn_set_chains(C.c_void_p(model._plan(dev)), args.chains))
     if R > 1:
         # the serving form: R forwards in flight, each a single whole-batch chain (demonet_amd/pipeline.py); one device-resident
         # synthetic batch per slot (slot 0 holds the batch of the one-at-a-time mode)

@@ -165,6 +165,8 @@ bool conv_patch_pool_ok(int cin, int cout, int h, int w);
 int launch_conv_patch_pool(const PwArgs& a, hipStream_t s);      // a.pool_out set
 bool conv_head_big_supported(const PwArgs& a);
 int launch_conv_head_big(const PwArgs& a, hipStream_t s);
+bool pw_head_big_supported(const PwArgs& a);
+int launch_pw_head_big(const PwArgs& a, hipStream_t s);
 
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;

@@ -137,6 +137,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int GK = 64;                      // K per stage
 constexpr int GSTAGE = (BP + BC) * GK;      // halfs per stage buffer (64 KB)
 
+// HEAD: the 1x1 class head of a large pyramid level with fp32 [anchor][class] output (SSDLite, generalized_ssd.py:60-74): any
+// cin % 8 == 0 (the chunks of the last 64-deep stage beyond cin are fetched from the zero block on both sides), weight rows beyond the
+// last channel repeat the last row and are never stored, a second head on the same input may follow in the channel range (cout_b).
+template <bool HEAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_glds_kernel(PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];
     float* bsh = reinterpret_cast<float*>(lds_raw);
@@ -146,8 +150,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wp = wave >> 1, wc = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * BP, n0 = blockIdx.y * BC;
-    const int M = a.m, K = a.cin, NC = a.cout, CIN = a.cv_cin;
-    const int KT = K / GK;
+    const int M = a.m, K = a.cin, CIN = a.cv_cin;
+    const int NC = HEAD ? a.cout + a.cout_b : a.cout;
+    const int KT = HEAD ? (K + GK - 1) / GK : K / GK;
 
     floatx16 acc[4][4];
 #pragma unroll
@@ -182,18 +187,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         vmask[j] = mk;
     }
     // weights: row (n0 + w*64 + j*8 + lrow), chunk as above: even / odd j differ by chunk ^ 4
-    const char* wbase = reinterpret_cast<const char*>(a.w) + ((size_t)(n0 + wave * 64) * K) * 2;
-    const unsigned woffE = (unsigned)((lrow * K + (lpos ^ ((lrow >> 1) & 3)) * 8) * 2);
-    const unsigned woffO = (unsigned)((lrow * K + (lpos ^ (4 + ((lrow >> 1) & 3))) * 8) * 2);
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (HEAD ? 0 : ((size_t)(n0 + wave * 64) * K) * 2);
+    const int chE = lpos ^ ((lrow >> 1) & 3), chO = lpos ^ (4 + ((lrow >> 1) & 3));       // K chunk of this lane in an even / odd row group
+    const unsigned woffE = (unsigned)((lrow * K + chE * 8) * 2);
+    const unsigned woffO = (unsigned)((lrow * K + chO * 8) * 2);
+    long wro[HEAD ? 8 : 1];                 // HEAD: byte offset of this lane's weight row (clamped to the last channel; second head behind the first)
+    if constexpr (HEAD) {
+        const long wdelta = a.w_b ? reinterpret_cast<const char*>(a.w_b) - reinterpret_cast<const char*>(a.w) : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = min(n0 + wave * 64 + j * 8 + lrow, NC - 1);
+            wro[j] = (row < a.cout ? (long)row * K * 2 : wdelta + (long)(row - a.cout) * K * 2) + ((j & 1) ? chO : chE) * 16;
+        }
+    }
 
     int ld_c0 = 0, ld_tap = 0, ld_ky = 0, ld_kx = 0, ld_k0 = 0;     // loader position, advanced without divisions
     // a stage = 16 LDS-DMA instructions per wave (8 pixel-row groups, 8 weight-row groups), issued in three parts so that they
     // can sit between the MFMAs of three K steps
-    int st_toff = 0, st_tap = 0, st_k0 = 0;
+    int st_toff = 0, st_tap = 0, st_k0 = 0, st_c0 = 0;
     auto stage_begin = [&]() {
         st_toff = (((ld_ky * a.cv_dil) * a.cv_w + ld_kx * a.cv_dil) * CIN + ld_c0) * 2;
         st_tap = ld_tap;
         st_k0 = ld_k0;
+        st_c0 = ld_c0;
         ld_k0 += GK * 2;
         ld_c0 += GK;
         const int wrap = ld_c0 == CIN;
@@ -206,13 +222,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto issue_x = [&](int b, int j) {
         half_t* dst = lds + b * GSTAGE + wave * 64 * GK;             // wave-uniform
-        const bool ok = (vmask[j] >> st_tap) & 1u;
+        bool ok = (vmask[j] >> st_tap) & 1u;
+        if constexpr (HEAD) ok = ok && st_c0 + ((j & 1) ? chO : chE) * 8 < CIN;      // (1x1 only: K == CIN)
         const char* p = ok ? xbase + (long)(xoff[j] + st_toff) : zeros;
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(dst + j * 8 * GK), 16, 0, 0);
     };
     auto issue_w = [&](int b, int j) {
         half_t* dst = lds + b * GSTAGE + wave * 64 * GK;
-        const char* p = wbase + (size_t)(j * 8) * K * 2 + (((j & 1) ? woffO : woffE) + (unsigned)st_k0);
+        const char* p;
+        if constexpr (HEAD) p = st_c0 + ((j & 1) ? chO : chE) * 8 < K ? wbase + (wro[j] + (long)st_k0) : zeros;
+        else p = wbase + (size_t)(j * 8) * K * 2 + (((j & 1) ? woffO : woffE) + (unsigned)st_k0);
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(dst + BP * GK + j * 8 * GK), 16, 0, 0);
     };
     auto issue_part = [&](int b, int part) {        // part 0: x0-5, part 1: x6-7 w0-3, part 2: w4-7 (6 + 6 + 4)
@@ -221,7 +240,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (part == 2) { issue_w(b, 4); issue_w(b, 5); issue_w(b, 6); issue_w(b, 7); }
     };
 
-    bsh[tid] = a.bias[n0 + tid];
+    if constexpr (HEAD) { const int n = n0 + tid; bsh[tid] = n < a.cout ? a.bias[n] : n < NC ? a.bias_b[n - a.cout] : 0.f; }
+    else bsh[tid] = a.bias[n0 + tid];
 
     // fragment addresses: row base + ((2 ks + hh) ^ ((r >> 1) & 7)) * 16 bytes
     const int sw = (r >> 1) & 7;
@@ -301,7 +321,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
 
-    conv_epilogue<4, 4>(acc, a, lds, bsh, m0, n0);
+    if constexpr (HEAD) conv_epilogue_fp32<4, 4>(acc, a, lds, bsh, m0, n0);
+    else conv_epilogue<4, 4>(acc, a, lds, bsh, m0, n0);
 }
 
 
@@ -772,9 +793,33 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.cout % BC == 0, "conv: cout=%d not a multiple of 256 on the 256x256 tile", a.cout);
     const size_t otile = (size_t)BP * OROW, st = (size_t)2 * GSTAGE;
     const size_t lds = (st > otile ? st : otile) * sizeof(half_t) + BC * sizeof(float);
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_glds_kernel)));
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_glds_kernel<false>)));
     dn_note_kernel("conv_glds_kernel");
-    hipLaunchKernelGGL(conv_glds_kernel, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(conv_glds_kernel<false>, dim3(dn_cdiv(a.m, BP), a.cout / BC), dim3(256), lds, s, a);
+    return DN_OK;
+}
+
+// The 1x1 class head of a large pyramid level (SSDLite: 672 -> 546 on the 20 x 20 map is a quarter of the network's MACs) on the
+// 256 x 256 tile with fp32 output. MEASURED and left off (DN_PW_HEAD_BIG=1 opts in): 120 us for the 64-image launch (156 TFLOP/s)
+// against 110 us for ALL head levels in the grouped 128 x 128-tile launch -- batch 64 0.792 -> 0.813 ms. The reduction is only 11
+// stages long, so the 256 KB fp32 epilogue of a workgroup (two passes through LDS, scattered 8-byte stores) weighs as much as its
+// main loop, and with one workgroup per CU nothing runs under it; 546 channels also waste 29 % of three 256-wide tiles.
+bool pw_head_big_supported(const PwArgs& a) {
+    const int on = dn_knob("DN_PW_HEAD_BIG", 0);
+    const int minwg = dn_knob("DN_PW_HEAD_BIG_MIN", 100);
+    if (!on || !a.out_fp32 || a.residual || a.se || !a.zeros || a.cv_k != 1 || a.cv_stride != 1 || a.cv_pad != 0 || a.cv_ho != a.cv_h || a.cv_wo != a.cv_w) return false;
+    if (a.cin % 8 || a.cin < 2 * GK || a.cin != a.cv_cin || (a.cout & 1)) return false;
+    if ((long)a.m * a.cin * 2 >= (1L << 31) || (long)(a.cout + a.cout_b) * a.cin * 2 >= (1L << 31)) return false;
+    const int tiles = dn_cdiv(a.cout + a.cout_b, BC);
+    return (a.cout + a.cout_b) * 10 >= tiles * BC * 6 && (long)dn_cdiv(a.m, BP) * tiles >= minwg;
+}
+
+int launch_pw_head_big(const PwArgs& a, hipStream_t s) {
+    const size_t otile = (size_t)2 * (BP / 2) * (BC + 4), st = (size_t)2 * GSTAGE;       // fp32 epilogue tile (two halves) / stage buffers, in halfs
+    const size_t lds = (st > otile ? st : otile) * sizeof(half_t) + BC * sizeof(float);
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_glds_kernel<true>)));
+    dn_note_kernel("conv_glds_kernel<head>");
+    hipLaunchKernelGGL(conv_glds_kernel<true>, dim3(dn_cdiv(a.m, BP), dn_cdiv(a.cout + a.cout_b, BC)), dim3(256), lds, s, a);
     return DN_OK;
 }
 

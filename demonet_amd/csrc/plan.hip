@@ -958,6 +958,22 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                     if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
                     continue;
                 }
+                if (!conv) {
+                    // the 1x1 class head of a large level (SSDLite level 0: 672 -> 546 on 20 x 20, a quarter of the network's MACs): its own
+                    // launch on the 256 x 256 MFMA tile instead of the 128 x 128 tile of the grouped launch
+                    PwArgs pb = pa;
+                    const dn_tensor_desc& th = p->tensors[p->ops[lst[q]].in];
+                    pb.cv_k = 1; pb.cv_stride = 1; pb.cv_pad = 0; pb.cv_dil = 1; pb.cv_h = pb.cv_ho = th.h; pb.cv_w = pb.cv_wo = th.w; pb.cv_cin = pb.cin;
+                    pb.zeros = reinterpret_cast<const half_t*>(Wb + p->zeros_off);
+                    if (pw_head_big_supported(pb)) {
+                        rc = launch_pw_head_big(pb, hs);
+                        if (rc != DN_OK) return rc;
+                        hnote(lst[q], seg);
+                        ++seg;
+                        if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
+                        continue;
+                    }
+                }
                 arr[cnt++] = pa;
                 grouped.push_back(lst[q]);
             }

@@ -427,13 +427,18 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
         const bool pair_ok = ((NC | (int)(a.out_base & 1) | (int)(a.out_img_stride & 1)) & 1) == 0 &&
                              (reinterpret_cast<size_t>(outp) & 7) == 0;       // every row start 8-byte aligned
         constexpr int PPR = BC / 2;                     // float2 per tile row
+        // image of a row without a division per element: a tile of BP consecutive rows spans at most two images when hw >= BP
+        const int img0 = m0 / a.hw, rem0 = m0 - img0 * a.hw;
+        const bool two = a.hw >= BP;
 #pragma unroll 4
         for (int c = tid; c < BP * PPR; c += 256) {
             const int row = c / PPR, cp = (c - row * PPR) * 2;
             const int m = m0 + row, n = n0 + cp;
             if (m >= M || n >= NC) continue;
-            const int img = m / a.hw;
-            float* o = outp + (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m - img * a.hw) * NC + n;
+            int img, pix;
+            if (two) { const int t = rem0 + row; const bool wrap = t >= a.hw; img = img0 + (wrap ? 1 : 0); pix = wrap ? t - a.hw : t; }
+            else { img = m / a.hw; pix = m - img * a.hw; }
+            float* o = outp + (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)pix * NC + n;
             const float2 v = *reinterpret_cast<const float2*>(&ot[row * FROW + cp]);
             if (pair_ok && n + 1 < NC) {
                 *reinterpret_cast<float2*>(o) = v;

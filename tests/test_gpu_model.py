@@ -432,6 +432,28 @@ def test_se_tail_in_depthwise_launch_matches_se_kernel(n, knob):
     assert (res["0"][1] - res["1"][1]).abs().max().item() < 4e-2
 
 
+def test_class_head_on_the_256_tile_matches_grouped_launch():
+    """DN_PW_HEAD_BIG=1 (opt-in, measured slower -- convbig.hip): the 1x1 class head of level 0 (672 -> 546) leaves the grouped head
+    launch for the 256 x 256 MFMA tile with the fp32 epilogue; its reduction length 672 is not a multiple of the 64-deep stage (the
+    tail chunks come from the zero block). Same products, 64- instead of 32-deep partial sums: logits agree to fp32 rounding. 50
+    images = 20 000 rows of that head: 79 x 3 workgroups, the last pixel tile partial."""
+    imgs = torch.from_numpy(synth.images(77, 50, 320, 320)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["DN_PW_HEAD_BIG"] = flag
+        os.environ["DN_SPLIT"] = "1"
+        try:
+            m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+            res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        finally:
+            del os.environ["DN_PW_HEAD_BIG"]
+            del os.environ["DN_SPLIT"]
+    d = (res["0"][0] - res["1"][0]).abs().max().item()
+    print(f"class head on the 256 tile vs grouped launch: max|d| {d:.3g} (max|logit| {res['0'][0].abs().max().item():.3g})")
+    assert 0 < d < 2e-4 or d == 0
+    assert torch.equal(res["0"][1], res["1"][1])          # the box heads stay in the grouped launch
+
+
 def test_graph_replay_equals_eager():
     m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
     imgs = torch.from_numpy(synth.images(9, 4, 320, 320)).cuda()

@@ -14,5 +14,5 @@ python3 bench.py --model ssd300_vgg16 --batch 64 --steps 20 --warmup 5 > gpurun_
 python3 bench.py --model ssd_lite_mobilenet_v2 --image-size 300 --batch 128 --steps 20 --warmup 5 > gpurun_out/r02b/v2_300_bench.json 2>/dev/null
 python3 bench.py --batch 32 > gpurun_out/r02b/b32_bench.json 2>/dev/null
 rm -f gpurun_out/r02b/batch_sweep.txt
-for bs in 1 8 16 32 64 128 256; do python3 bench.py --no-cpu-baseline --no-roofline --no-latency --steps 60 --warmup 10 --batch $bs 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('batch $bs  %.1f img/s  %.4f ms/step' % (d['value'], d['ms_per_step']))" >> gpurun_out/r02b/batch_sweep.txt; done
+for bs in 1 8 16 32 64 128 256; do for fl in 3 1; do python3 bench.py --no-cpu-baseline --no-roofline --no-latency --steps 200 --warmup 20 --batch $bs --inflight $fl 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('batch $bs  forwards in flight $fl  %.1f img/s  %.4f ms/step' % (d['value'], d['ms_per_step']))" >> gpurun_out/r02b/batch_sweep.txt; done; done
 cat gpurun_out/r02b/batch_sweep.txt

@@ -13,10 +13,10 @@ tail -c 1200 $OUT/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline "$@" > $OUT/stats.log 2>&1
 cp $(find /tmp/rp_$TAG/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$TAG/pmc/$c -o $c -- python3 bench.py --steps 3 --warmup 2 --eager --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$TAG/pmc/$c -o $c -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_$c.log 2>&1
 done
-PMC_CMD="bench.py --steps 3 --warmup 2 --eager $*" python3 tools/pmc_traffic.py /tmp/rp_$TAG/pmc $OUT/hbm_traffic.json
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/rp_$TAG/sq -o sq -- python3 bench.py --steps 3 --warmup 2 --eager --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_sq.log 2>&1
+PMC_CMD="bench.py --steps 3 --warmup 2 --eager --chains 1 $*" python3 tools/pmc_traffic.py /tmp/rp_$TAG/pmc $OUT/hbm_traffic.json
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/rp_$TAG/sq -o sq -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_sq.log 2>&1
 python3 tools/pmc_mfma.py /tmp/rp_$TAG/sq $OUT/mfma_util.json $OUT/kernel_stats.csv
 rm -rf /tmp/rp_$TAG
 ls $OUT
