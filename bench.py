@@ -441,13 +441,15 @@ def main():
                     e = fam[_norm_kernel(dom)]
                     traffic, traffic_src = round(e[0] / max(e[1], 1)), os.path.relpath(path, ROOT)
                     break
-        rocprof_avg = None
-        if prof_tag is not None:
-            # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
-            # (graph replay, both sub-batch branches in flight); the live figure below is HIP events around each launch in
-            # an eager pass, which adds the ~3 us dispatch gap to every launch
+        def rocprof_avg_of(suffix):
+            # the same kernel's average duration in a committed rocprofv3 --kernel-trace --stats summary (tools/round_profile.sh):
+            # "kernel_stats" = this command (graph replay with the forwards in flight: a launch shares the chip with the other forwards'
+            # kernels), "kernel_stats_one_forward" = --inflight 1 --chains 1 (one single-chain forward at a time: the condition of the
+            # live figure, which is HIP events around each launch in an eager pass and adds the ~3 us dispatch gap)
             import csv, glob, re
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_kernel_stats.csv")), reverse=True):
+            if prof_tag is None:
+                return None
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_{suffix}.csv")), reverse=True):
                 tot_ns, calls = 0.0, 0
                 with open(path) as f:
                     for r in csv.DictReader(f):
@@ -457,12 +459,14 @@ def main():
                             tot_ns += float(r["TotalDurationNs"])
                             calls += int(r["Calls"])
                 if calls:
-                    rocprof_avg = round(tot_ns / calls / 1e3, 2)
-                    break
+                    return round(tot_ns / calls / 1e3, 2)
+            return None
+        rocprof_avg = rocprof_avg_of("kernel_stats")
+        rocprof_avg1 = rocprof_avg_of("kernel_stats_one_forward")
         result["roofline"] = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                               "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
-                              "rocprof_avg_launch_us": rocprof_avg,
+                              "rocprof_avg_launch_us": rocprof_avg, "rocprof_avg_launch_us_one_forward": rocprof_avg1,
                               "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                               "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
                               "share_of_step": round(d["ms"] / total_ms, 3), "profiled_runs": runs,

@@ -12,6 +12,10 @@ python3 bench.py --per-op $OUT/per_op.txt "$@" > $OUT/bench.json 2> $OUT/bench.e
 tail -c 1200 $OUT/bench.json; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline "$@" > $OUT/stats.log 2>&1
 cp $(find /tmp/rp_$TAG/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+# the same kernels with ONE forward in flight (single chain): what bench.py's event pass measures; with three forwards in flight a launch
+# shares the chip and its duration in the summary above stretches (3x for the MFMA-bound VGG convs)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats1 -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline --inflight 1 --chains 1 "$@" > $OUT/stats1.log 2>&1
+cp $(find /tmp/rp_$TAG/stats1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_one_forward.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$TAG/pmc/$c -o $c -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_$c.log 2>&1
 done
