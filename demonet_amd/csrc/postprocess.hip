@@ -812,6 +812,11 @@ int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes,
                    float* keptScore, int* keptAnchor, int* keptCount, hipStream_t s) {
     // 512 threads: the column scan is one batch of loads for A <= 4096, and a heavy class (up to topk candidates) spreads its
     // IoU-mask rows over 8 waves instead of 4 -- the kernel's duration is the lifetime of its heaviest workgroups
+    if (dn_knob("DN_PP_FAST_THREADS", 512) == 256) {
+        hipLaunchKernelGGL((select_nms_fast_kernel<NW, 256>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), 0, s, scoresT, boxes, a.A, a.K - 1,
+                           a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq);
+        return DN_OK;
+    }
     hipLaunchKernelGGL((select_nms_fast_kernel<NW, 512>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(512), 0, s, scoresT, boxes, a.A, a.K - 1,
                        a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq);
     return DN_OK;
