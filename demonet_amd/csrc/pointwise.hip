@@ -884,6 +884,8 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     if (!conv && maxc > 64 && gt == 7) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
     if (!conv && maxc > 64 && gt == 8) return launch_group_cfg<64, 128, 2, 2, false, 64>(arr, count, s);
     if (!conv && maxc > 64 && gt == 9) return launch_group_cfg<128, 128, 2, 2, false, 64>(arr, count, s);
+    if (!conv && maxc > 64 && gt == 10) return launch_group_cfg<128, 192, 2, 2, false>(arr, count, s);
+    if (!conv && maxc > 64 && gt == 11) return launch_group_cfg<64, 192, 2, 2, false>(arr, count, s);
     if (maxc <= 32 && conv && wg128 < 256 && dn_knob("DN_CONV_SMALL_PF", 1)) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
@@ -893,6 +895,17 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         bool all64 = bk64 != 0;
         for (int i = 0; i < count; ++i) all64 &= arr[i].cv_cin % 64 == 0;
         if (all64) return launch_group_cfg<128, 128, 2, 2, true, 64>(arr, count, s);
+    }
+    if (wg128 >= 1500 && !conv && dn_knob("DN_PW_GROUP_96", 1)) {
+        // 96-wide channel tiles (a wave = 32 pixels x 96 channels) where they pad less: the 546 class channels of the SSDLite heads are
+        // 6 x 96 = 576 columns instead of 5 x 128 = 640 -- the head launch is the longest full-chip launch of a forward (batch 64, three
+        // forwards in flight: 0.789 -> 0.775 ms; 128 x 192 tiles 0.808, 64 x 192 level)
+        double c96 = 0, c128 = 0;
+        for (int i = 0; i < count; ++i) {
+            c96 += (double)arr[i].m * dn_cdiv(arr[i].cout, 96) * 96;
+            c128 += (double)arr[i].m * dn_cdiv(arr[i].cout, 128) * 128;
+        }
+        if (c96 <= 0.95 * c128) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
     }
     if (wg128 >= 1500) return conv ? launch_group_cfg<128, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
     // the dense heads of the small levels (a few dozen workgroups, 72 - 144 K stages): latency-bound, stages requested 3 ahead
