@@ -765,6 +765,9 @@ int launch_halo(const PwArgs& a, hipStream_t s, const char* name) {
 int halo_variant(const PwArgs& a) {
     if (a.out_fp32 || a.residual || a.se || !halo_shape(a)) return 0;
     const int hr = halo_rows(a);
+    const int force = dn_knob("DN_CONV_HALO_VARIANT", 0);      // dev knob: prefer the 512 x 128 (2) / 256 x 128 (3) tile where it applies
+    if (force == 2 && a.cout % 128 == 0 && a.cv_cin >= 128 && 512 + hr <= halo_run_rows(8, 2)) return 2;
+    if (force == 3 && a.cout % 128 == 0 && a.cv_cin >= 128 && 256 + hr <= halo_run_rows(4, 2)) return 3;
     if (a.cout % 256 == 0 && 256 + hr <= halo_run_rows(4, 4)) return 1;
     if (a.cout % 128 == 0 && a.cv_cin >= 128 && 512 + hr <= halo_run_rows(8, 2)) return 2;
     if (a.cout % 128 == 0 && a.cv_cin >= 128 && 256 + hr <= halo_run_rows(4, 2)) return 3;      // (one 64-channel iteration: measured level with the 128x128 tile)

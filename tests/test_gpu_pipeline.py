@@ -62,6 +62,25 @@ def test_pipeline_equals_one_forward_at_a_time(n, depth):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name,ncls,n", [("ssd300_vgg16", 91, 2), ("ssd_lite_mobilenet_v2", 21, 33)])
+def test_pipeline_other_model_families(name, ncls, n):
+    """The dense-conv model (256 x 256-tile kernels with 130+ KB of LDS per workgroup, dense 3x3 heads) and the V2 model at a batch
+    that the in-forward split would halve: three forwards in flight equal the single-chain forward of each batch."""
+    m = _model(name, ncls)
+    batches = _batches(m.graph, 4, n, seed=55)
+    with ForwardPipeline(m, n, depth=3) as pipe:
+        ref = [[t.clone() for t in m.forward_batch(b)] for b in batches]
+        for rnd in range(2):
+            ts = [pipe.submit(b) for b in batches[:3]]
+            for k, t in enumerate(ts):
+                for a, b in zip(ref[k], pipe.result(t)):
+                    assert torch.equal(a, b), "%s batch %d" % (name, k)
+        t = pipe.submit(batches[3])
+        for a, b in zip(ref[3], pipe.result(t)):
+            assert torch.equal(a, b)
+    assert int(sum(int(r[3].sum()) for r in ref)) > 0
+
+
 def test_pipeline_persistent_inputs_and_detections_form():
     m = _model()
     n, depth = 4, 2
