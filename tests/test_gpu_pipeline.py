@@ -122,6 +122,50 @@ def test_pipeline_uint8_input():
             pipe.submit(u8[0].float())
 
 
+def test_evaluate_loop_matches_one_call_per_batch():
+    """demonet_amd.engine.evaluate (the reference's engine.evaluate loop, engine.py:84-100, over the pipeline): same-size batches,
+    a change of image size (device resize + boxes mapped back), a mixed-size batch (runs through model(images) after a drain) --
+    every record equals what model(images) returns for that batch, in the loader's order; the COCO records follow coco_eval.py:76-98."""
+    from demonet_amd import engine, evalrec
+    m = _model()
+    g = torch.Generator().manual_seed(5)
+    def imgs(n, h, w, seed):
+        return [torch.from_numpy(synth.images(seed + i, 1, h, w)[0]) for i in range(n)]
+    loader, next_id = [], [100]
+    def add(images):
+        t = [{"image_id": torch.tensor(next_id[0] + i)} for i in range(len(images))]
+        next_id[0] += len(images)
+        loader.append((images, t))
+    for b in range(5):
+        add(imgs(3, 320, 320, 200 + 10 * b))
+    add(imgs(3, 300, 400, 300))
+    add(imgs(1, 320, 320, 400) + imgs(1, 500, 400, 401))        # mixed sizes
+    add(imgs(3, 320, 320, 500))
+    results, stats = engine.evaluate(m, loader, "cuda:0", depth=3)
+    assert stats["images"] == 23 and list(results) == list(range(100, 123))
+    for images, targets in loader:
+        want = m([im.cuda() for im in images])
+        for t, w in zip(targets, want):
+            got = results[int(t["image_id"])]
+            for k in ("boxes", "scores", "labels"):
+                assert torch.equal(got[k], w[k].cpu()), (int(t["image_id"]), k)
+            assert got["labels"].dtype == torch.int64
+    recs = engine.coco_records(results)
+    assert len(recs) == sum(len(r["scores"]) for r in results.values()) > 0
+    r0 = results[100]
+    assert recs[0]["image_id"] == 100 and recs[0]["category_id"] == int(r0["labels"][0]) and recs[0]["score"] == float(r0["scores"][0])
+    x1, y1, x2, y2 = r0["boxes"][0].tolist()
+    assert recs[0]["bbox"] == [x1, y1, (r0["boxes"][0, 2] - r0["boxes"][0, 0]).item(), (r0["boxes"][0, 3] - r0["boxes"][0, 1]).item()]
+    # the padded-array form of evalrec builds the same list
+    ids = list(results)[:3]
+    D = m.detections_per_img
+    boxes = torch.zeros(3, D, 4); scores = torch.zeros(3, D); labels = torch.zeros(3, D, dtype=torch.int64); counts = torch.zeros(3, dtype=torch.int32)
+    for i, k in enumerate(ids):
+        c = len(results[k]["scores"]); counts[i] = c
+        boxes[i, :c], scores[i, :c], labels[i, :c] = results[k]["boxes"], results[k]["scores"], results[k]["labels"]
+    assert evalrec.coco_detection_records(boxes, scores, labels, counts, ids) == [r for r in recs if r["image_id"] in ids]
+
+
 def test_pipeline_errors():
     m = _model()
     n = 2
