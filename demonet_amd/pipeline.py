@@ -5,8 +5,9 @@ then a post-process of one workgroup per image), and nothing of the NEXT batch c
 finished. `SSD.forward_batch` fights that inside one forward (two half-size sub-batch chains, plan.hip `batch_split`); a caller
 with a stream of batches does better by keeping `depth` independent forwards in flight, each a single whole-batch chain on a
 stream of its own with its own workspace and output buffers, all replaying graphs of the SAME plan (one copy of the weights).
-Measured on MI355X, ssdlite320_mobilenet_v3_large (tools/pipeline_probe.py): batch 64 one forward at a time 1.06 ms (60 k img/s),
-three in flight 0.84 ms per forward (76 k img/s); batch 32: 0.74 -> 0.46 ms (43 k -> 70 k img/s) six deep.
+Measured on MI355X, ssdlite320_mobilenet_v3_large (bench.py --inflight R, tools/pipeline_probe.py): batch 64 one forward at a time
+1.04 ms (62 k img/s), three in flight 0.78 ms per forward (82 k img/s); batch 32: 0.74 -> 0.44 ms (43 k -> 73 k img/s). Depths 4 and 5
+are worse than 3 (even depths pair up in lockstep), 6 - 7 level with 3.
 
 The reference has no counterpart (engine.evaluate, engine.py:86-94, runs one synchronous forward per batch); results per batch are
 those of `forward_batch` on the same images, bit for bit (tests/test_gpu_pipeline.py).
@@ -49,10 +50,16 @@ class ForwardPipeline:
         self.model, self.device, self.depth, self.batch, self.uint8 = model, device, int(depth), int(batch), bool(uint8)
         self.h, self.w = int(height or H), int(width or W)
         self._handle = model._plan(device)          # raises without a GPU / the HIP library: there is no fallback path
+        self._gen = model._plan_gen
         L = _lib.lib()
         self._L = L
-        _lib.check(L.dn_set_chains(C.c_void_p(self._handle), int(chains)))
-        model._bufs = {}                            # workspaces sized for the previous split are stale
+        if getattr(model, "_pipe_refs", 0) > 0 and getattr(model, "_pipe_chains", chains) != chains:
+            raise ValueError("another open pipeline of this model uses chains={}".format(model._pipe_chains))
+        if getattr(model, "_pipe_refs", 0) == 0:    # (dn_set_chains drops the plan's graphs: only with no other pipeline replaying them)
+            _lib.check(L.dn_set_chains(C.c_void_p(self._handle), int(chains)))
+            model._bufs = {}                        # workspaces sized for the previous split are stale
+        model._pipe_refs = getattr(model, "_pipe_refs", 0) + 1
+        model._pipe_chains = chains
         D = model.detections_per_img
         self._fwd = L.dn_forward_u8 if uint8 else L.dn_forward
         self._name = "dn_forward_u8" if uint8 else "dn_forward"
@@ -92,7 +99,7 @@ class ForwardPipeline:
         batch is first copied into the slot's own input buffer (a device copy on the slot's stream)."""
         if self._closed:
             raise RuntimeError("the pipeline is closed")
-        if self.model._handle != self._handle:
+        if self.model._handle != self._handle or self.model._plan_gen != self._gen:
             raise RuntimeError("the model's plan was rebuilt (weights changed / invalidate()): build a new ForwardPipeline")
         s = self.slots[self.n % self.depth]
         if tuple(images.shape) != tuple(s.images.shape):
@@ -169,9 +176,11 @@ class ForwardPipeline:
             return
         self.drain()
         self._closed = True
-        if self.model._handle == self._handle:
-            _lib.check(self._L.dn_set_chains(C.c_void_p(self._handle), 0))
-            self.model._bufs = {}
+        if self.model._handle == self._handle and self.model._plan_gen == self._gen:
+            self.model._pipe_refs -= 1
+            if self.model._pipe_refs == 0:          # the last pipeline of the plan: back to the automatic split
+                _lib.check(self._L.dn_set_chains(C.c_void_p(self._handle), 0))
+                self.model._bufs = {}
         self.slots = []
 
     def __enter__(self):

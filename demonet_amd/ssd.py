@@ -119,6 +119,8 @@ class SSD(nn.Module):
             self._handle = self._lowered.create()
         self._sig = sig
         self._bufs = {}
+        self._plan_gen = getattr(self, "_plan_gen", 0) + 1      # (a new plan may reuse the old one's address: pipelines compare this)
+        self._pipe_refs = 0
         return self._handle
 
     def release(self):

@@ -185,6 +185,14 @@ def test_pipeline_errors():
         pipe.submit((b * 255).to(torch.int32))
     with pytest.raises(RuntimeError, match="packed=True"):
         pipe.packed(ts[2])
+    with ForwardPipeline(m, n, depth=2) as second:        # two pipelines of one plan: the split is reset when the LAST one closes
+        t2 = second.submit(b)
+        with pytest.raises(ValueError, match="chains"):
+            ForwardPipeline(m, n, depth=2, chains=2)
+        t1 = pipe.submit(b)
+        assert torch.equal(second.result(t2)[1], pipe.result(t1)[1])
+    assert m.batch_split(64) == 1                         # `pipe` is still open
+    pipe.result(pipe.submit(b))
     m.invalidate()                                        # the plan the pipeline replays is gone
     with pytest.raises(RuntimeError, match="rebuilt"):
         pipe.submit(b)
