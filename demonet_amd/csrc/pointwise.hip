@@ -847,7 +847,7 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
         if (!all_xq) g.a[i].xq = 0;
-        g.a[i].stamps = nullptr;
+        g.a[i].stamps = g_pw_stamps;        // dev hook (null unless tools/probe_head_stamps.py set it)
         g.start[i] = acc;
         g.gx[i] = pw_row_tiles(g.a[i], BP);
         acc += (g.a[i].xq > 0 ? 8 * g.gx[i] : g.gx[i]) * dn_cdiv(arr[i].cout, BC);
