@@ -884,8 +884,6 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     if (!conv && maxc > 64 && gt == 7) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
     if (!conv && maxc > 64 && gt == 8) return launch_group_cfg<64, 128, 2, 2, false, 64>(arr, count, s);
     if (!conv && maxc > 64 && gt == 9) return launch_group_cfg<128, 128, 2, 2, false, 64>(arr, count, s);
-    if (!conv && maxc > 64 && gt == 10) return launch_group_cfg<128, 192, 2, 2, false>(arr, count, s);
-    if (!conv && maxc > 64 && gt == 11) return launch_group_cfg<64, 192, 2, 2, false>(arr, count, s);
     if (maxc <= 32 && conv && wg128 < 256 && dn_knob("DN_CONV_SMALL_PF", 1)) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
