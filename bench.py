@@ -152,8 +152,8 @@ def cpu_baseline(name, graph, seed, budget_s=24.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 64 on one GPU = BASELINE configs[1]; on N > 1 GPUs "
                                                      "the global batch 256 of configs[3] is sharded, 256 / N per GPU)")
     ap.add_argument("--model", default=DEFAULT_MODEL)

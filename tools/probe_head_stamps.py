@@ -30,3 +30,13 @@ print(f"batch {n}: {len(s)} workgroups; prologue {d[:,0].mean():.2f} kloop {d[:,
       f" span {(s[:,3].max()-t0)*0.01:.1f} us; start spread {(s[:,0].max()-t0)*0.01:.1f} us")
 starts = np.sort((s[:, 0] - t0) * 0.01)
 print("start time percentiles (us):", " ".join(f"{np.percentile(starts, q):.1f}" for q in (0, 10, 25, 50, 75, 90, 100)))
+# timeline by workgroup index (blocks of 100): when they start and end relative to the launch
+allw = st.cpu().numpy().reshape(-1, 8)[:, :4].astype(np.float64)
+valid = allw[:, 0] > 0
+idx = np.nonzero(valid & (np.abs(allw[:, 0] - t0) < 1e5))[0]
+for lo in range(0, int(idx.max()) + 1, 100):
+    sel = idx[(idx >= lo) & (idx < lo + 100)]
+    if len(sel) == 0:
+        continue
+    b = allw[sel]
+    print(f"  WGs {lo:5d}..{lo + 99:5d} ({len(sel):3d}): start {(b[:,0].min()-t0)*0.01:6.1f}..{(b[:,0].max()-t0)*0.01:6.1f}  end {(b[:,3].min()-t0)*0.01:6.1f}..{(b[:,3].max()-t0)*0.01:6.1f}  life {((b[:,3]-b[:,0]).mean())*0.01:5.1f} us")
