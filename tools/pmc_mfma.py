@@ -6,7 +6,8 @@ Per kernel and launch (averages over the sampled launches): SQ_INSTS_MFMA (wave-
 (cycles a SIMD's matrix pipe is busy; 32 per v_mfma_f32_32x32x16_f16: MI355X_MICROARCH.md), SQ_BUSY_CYCLES, SQ_WAVE_CYCLES (quad-cycles),
 SQ_WAIT_ANY. Derived:
   mfma_pipe_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * launch duration * 2.4 GHz)   -- share of the chip's matrix-pipe cycles
-                   in use while the kernel runs (duration = rocprofv3 --kernel-trace --stats average of the same bench command;
+                   in use while the kernel runs (duration = rocprofv3 --kernel-trace --stats average of bench.py --inflight 1 --chains 1, i.e. one
+                   single-chain forward at a time like the eager counter pass;
                    2.4 GHz is the maximum clock, so this is a lower bound when the chip clocks down under load);
   mfma_cycles_per_inst = SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA (a consistency check: 32 for 32x32x16 fp16, 64 for 32x32x2 f32).
 """

@@ -21,6 +21,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 PMC_CMD="bench.py --steps 3 --warmup 2 --eager --chains 1 $*" python3 tools/pmc_traffic.py /tmp/rp_$TAG/pmc $OUT/hbm_traffic.json
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/rp_$TAG/sq -o sq -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_sq.log 2>&1
-python3 tools/pmc_mfma.py /tmp/rp_$TAG/sq $OUT/mfma_util.json $OUT/kernel_stats.csv
+python3 tools/pmc_mfma.py /tmp/rp_$TAG/sq $OUT/mfma_util.json $OUT/kernel_stats_one_forward.csv
 rm -rf /tmp/rp_$TAG
 ls $OUT
