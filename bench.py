@@ -378,7 +378,7 @@ def main():
         # fused inverted-residual launches: the intermediate activations never reach HBM -> external bytes only
         fused = {}
         for i, c in enumerate(costs):
-            if c["kernel"].startswith("expdw_kernel"):
+            if c["kernel"].startswith(("expdw_kernel", "pw_dw_direct_kernel")):
                 fused.setdefault(c["owner"], []).append(i)
         for mem in fused.values():
             first, last = costs[mem[0]], costs[mem[-1]]

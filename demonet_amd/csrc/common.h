@@ -166,6 +166,9 @@ int launch_conv_patch_pool(const PwArgs& a, hipStream_t s);      // a.pool_out s
 bool conv_head_big_supported(const PwArgs& a);
 int launch_conv_head_big(const PwArgs& a, hipStream_t s);
 bool pw_head_big_supported(const PwArgs& a);
+struct DwArgs;
+bool pw_dw_direct_supported(const PwArgs& a, const DwArgs& d);      // depthwise 3x3 + the 1x1 behind it in one register-direct launch (pwdirect.hip)
+int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s);
 int launch_pw_head_big(const PwArgs& a, hipStream_t s);
 
 struct DwArgs {

@@ -370,7 +370,17 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
                 }
                 continue;
             }
-            // depthwise -> project without an expand (first block of the MobileNets): correct but measured slower than the two
+            // depthwise 3x3 -> project without an expand (first block of the MobileNets, 16 / 32 channels on the largest map): the
+            // depthwise is computed straight into the projection's B fragments (pwdirect.hip pw_dw_direct_kernel), fused_kind 8
+            // (measured: V3's 16-channel block batch 64 0.782 -> 0.771 ms in flight, 1.035 -> 1.026 one at a time; the 32-channel block of the V2
+            // model at 300 x 300 1.481 -> 1.495 ms -- two K steps of nine taps per lane for a projection that fills half a tile: DN_PW_DW=2 only)
+            if (dn_knob("DN_PW_DW", 1) && dw_ok(a) && a.k == 3 && a.stride == 1 && a.pad == 1 && a.pool < 0 && (a.cin == 16 || (a.cin == 32 && dn_knob("DN_PW_DW", 1) == 2)) &&
+                p->tensors[a.in].kind == DN_T_ACT && plain_pw(d) && d.in == a.out && uses[a.out] == 1 && d.cout <= 32 && d.cout % 8 == 0 &&
+                (d.residual < 0 || (d.residual == a.in && d.cout == a.cin)) && p->tensors[a.in].h * p->tensors[a.in].w >= 32) {
+                p->fused_len[i] = 2; p->fused_kind[i] = 8; i += 1;
+                continue;
+            }
+            // the same pair through the LDS-tiled block kernel: correct but measured slower than the two
             // launches (16 channels leave half of the workgroup idle in the depthwise stage) -- opt-in
             const bool noexp = dn_knob("DN_EXPDW_NOEXP", 0) != 0;
             if (noexp && dw_ok(a) && p->tensors[a.in].kind == DN_T_ACT && expdw_supported(a.cin, a.cin, a.k, a.stride) && a.cin <= 32 &&
@@ -1121,6 +1131,18 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             for (int q = 1; q < ta.count; ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             i += ta.count - 1;
+            continue;
+        }
+        if (p->fused_len[i] > 0 && p->fused_kind[i] == 8) {
+            PwArgs pa = make_pw(p->ops[i + 1]);
+            const DwArgs da = make_dw(o);
+            pa.x = da.x;                                    // (the depthwise output is not materialised)
+            if (pa.residual) pa.residual = da.x;
+            rc = launch_pw_dw_direct(pa, da, s);
+            if (rc != DN_OK) return rc;
+            note(i, i); note(i + 1, i);
+            if (record) (void)hipEventRecord(p->events[ev++], s);
+            i += 1;
             continue;
         }
         if (p->fused_len[i] > 0 && p->fused_kind[i] == 4) {

@@ -20,6 +20,8 @@
 // (mobilenetv3.py:97-99 computes act(conv + bias) + x).
 #include "common.h"
 
+__device__ const uint4 g_pwdw_zero16 = {0u, 0u, 0u, 0u};      // what a tap outside the image reads
+
 namespace {
 
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
@@ -207,6 +209,148 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
     }
 }
 
+// Depthwise 3x3 (stride 1, pad 1) + the 1x1 projection behind it in ONE launch, register-direct: the first block of the MobileNets
+// (mobilenetv3.py:61-99 with expanded == input channels: depthwise -> project (+ residual); mobilenetv2.py:57-84 with expand_ratio 1).
+// Lane (r, hh) of the projection's B fragment holds 8 channels of ONE pixel -- exactly what a depthwise thread produces -- so the
+// depthwise is computed straight into the fragment: nine 16-byte taps per lane and K step (neighbouring pixels, same channels; the
+// wave covers 32 consecutive pixels of a row, the taps overlap in L1), bias first, taps in (ky, kx) order through v_fma_mix_f32,
+// activation, ONE rounding to fp16 -- the arithmetic of dw_kernel, bit for bit -- and the value never exists in HBM: on the 160 x 160
+// map that is 52 MB written and 52 MB read back per 64 images, and the residual (the block's input) is the centre tap's line.
+// The projection (bias in the reduction, permlane epilogue) is pw_direct_kernel<KSF, 1>'s.
+struct PwDwArgs {
+    PwArgs pw;                       // x = the depthwise INPUT [n][h][w][cin]; cin == depthwise channels; residual: null or == x
+    const half_t* wd; const float* bd;      // depthwise weights [9][cin] fp16, bias [cin] fp32
+    int h, w, act_dw;
+    float inv_hw;                    // 1 / (h w): image of a row by a corrected float quotient (rows < 2^24)
+    FastDiv fd_w;
+};
+
+template <int KSF>
+__global__ __launch_bounds__(256) void pw_dw_direct_kernel(PwDwArgs q, int tiles) {
+    const PwArgs& a = q.pw;
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = a.cin, NC = a.cout;
+    int m0, mend;
+    {
+        const int flat = blockIdx.x;
+        if (a.xq > 0) {
+            const int g = flat & 7, t = flat >> 3;
+            const int r0 = g * a.xq * a.hw;
+            mend = min(a.m, r0 + a.xq * a.hw);
+            m0 = r0 + t * 128;
+        } else {
+            m0 = flat * 128;
+            mend = a.m;
+        }
+    }
+    const int mrow0 = m0 + wave * 32;
+    if (mrow0 >= mend) return;                             // wave-uniform
+    const int row = mrow0 + r;
+    const int rowc = min(row, mend - 1);
+    // position of this lane's pixel inside its image: the wave's first row by a corrected float quotient (wave-uniform), then at most
+    // one wrap for the lane (hw >= 32)
+    int rem;
+    {
+        int q0 = (int)((float)mrow0 * q.inv_hw);
+        int r0 = mrow0 - q0 * a.hw;
+        if (r0 < 0) r0 += a.hw;
+        if (r0 >= a.hw) r0 -= a.hw;
+        rem = r0 + (rowc - mrow0);
+        if (rem >= a.hw) rem -= a.hw;
+    }
+    const int py = (int)fd_div((unsigned)rem, q.fd_w), px = rem - py * q.w;
+    // the projection's operands that do not depend on the depthwise: requested first
+    const int nrow = min(r, NC - 1);
+    const half_t* wpt = a.w + (size_t)nrow * K + hh * 8;
+    half8 wf[KSF];
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) wf[ks] = *reinterpret_cast<const half8*>(wpt + ks * 16);
+    const int kb = KSF * 16 + hh * 8;                      // == K + 8 hh: hh = 0 carries the bias columns, hh = 1 zeros
+    const float bl = a.bias[nrow];
+    uint2 rres[4];
+    const bool has_res = a.residual != nullptr;
+    if (has_res) {
+        const half_t* rp = a.residual + (size_t)rowc * NC;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rres[g] = *reinterpret_cast<const uint2*>(rp + min(8 * g + 4 * hh, NC - 4));
+    }
+    // ---- depthwise into the B fragments
+    typedef const __attribute__((address_space(1))) half8* gp8;
+    const gp8 zero = (gp8)(&g_pwdw_zero16);
+    const half_t* xpix = a.x + (size_t)rowc * K + hh * 8;           // this lane's channels of its own pixel
+    half8 xf[KSF];
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) {
+        const int cb = ks * 16 + hh * 8;
+        half8 xin[9], wv[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = py + ky - 1, ix = px + kx - 1;
+                const bool ok = iy >= 0 && iy < q.h && ix >= 0 && ix < q.w;
+                wv[ky * 3 + kx] = *reinterpret_cast<const half8*>(q.wd + (ky * 3 + kx) * K + cb);
+                xin[ky * 3 + kx] = *(ok ? (gp8)(xpix + ks * 16 + ((ky - 1) * q.w + (kx - 1)) * K) : zero);
+            }
+        float acc[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4*>(q.bd + cb);
+            const float4 b1 = *reinterpret_cast<const float4*>(q.bd + cb + 4);
+            acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) fma_mix_h8(acc, *reinterpret_cast<const uint4*>(&xin[t]), *reinterpret_cast<const uint4*>(&wv[t]));
+        dn_act_n<float[8], 8>(acc, q.act_dw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[ks][e] = (half_t)acc[e];
+    }
+    // ---- the projection: KSF full steps, then the bias step (pw_direct_kernel's last step with kb >= K)
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const half8 ones = {(half_t)1.f, (half_t)1.f, 0, 0, 0, 0, 0, 0};
+    const half_t bhi = (half_t)bl;
+    const half8 bw = {bhi, (half_t)(bl - (float)bhi), 0, 0, 0, 0, 0, 0};
+    const bool bcol = kb == K;
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf[ks], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bcol ? bw : zero8, bcol ? ones : zero8, acc, 0, 0, 0);
+    act16(acc, a.act);
+    if (has_res) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const half4 rr = __builtin_bit_cast(half4, rres[g]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g + e] += (float)rr[e];
+        }
+    }
+    uint2v p[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[4 * g + e];
+        p[g] = __builtin_bit_cast(uint2v, hv);
+    }
+    uint4 lo4, hi4;
+    {
+        const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[2][0], false, false);
+        const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[2][1], false, false);
+        const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[1][0], p[3][0], false, false);
+        const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[1][1], p[3][1], false, false);
+        lo4 = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        hi4 = make_uint4(s2[0], s3[0], s2[1], s3[1]);
+    }
+    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 16;
+    const int c0 = hh * 16;
+    if (row < mend) {
+        if (c0 < NC) *reinterpret_cast<uint4*>(orow) = lo4;
+        if (c0 + 8 < NC) *reinterpret_cast<uint4*>(orow + 8) = hi4;
+    }
+}
+
 template <int KSF, int TC>
 int launch_t(const PwArgs& a, int wc_log, hipStream_t s) {
     const int BP = 32 * (4 >> wc_log), BC = (32 * TC) << wc_log;
@@ -218,6 +362,27 @@ int launch_t(const PwArgs& a, int wc_log, hipStream_t s) {
 }
 
 }  // namespace
+
+bool pw_dw_direct_supported(const PwArgs& a, const DwArgs& d) {
+    return dn_knob("DN_PW_DW", 1) != 0 && pw_direct_supported(a) && !a.se && (a.cin == 16 || a.cin == 32) && a.cout <= 32 && d.c == a.cin && d.k == 3 &&
+           d.stride == 1 && d.pad == 1 && !d.pool && d.ho == d.h && d.wo == d.w_ && a.hw == d.h * d.w_ && (!a.residual || (a.residual == d.x && a.cout == a.cin)) &&
+           a.hw >= 32 && a.m < (1 << 24) && fd_ok((unsigned long long)a.hw, (unsigned)d.w_);
+}
+
+int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s) {
+    DN_REQUIRE(pw_dw_direct_supported(a, d), "depthwise + pointwise (direct): unsupported cin=%d cout=%d", a.cin, a.cout);
+    PwDwArgs q{};
+    q.pw = a;
+    q.pw.x = d.x;
+    q.wd = d.w; q.bd = d.bias; q.h = d.h; q.w = d.w_; q.act_dw = d.act;
+    q.inv_hw = 1.0f / (float)a.hw; q.fd_w = fastdiv((unsigned)d.w_);
+    const int tiles = a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, 128) : dn_cdiv(a.m, 128);
+    const dim3 grid((unsigned)(a.xq > 0 ? 8 * tiles : tiles));
+    dn_note_kernel("pw_dw_direct_kernel<%d>", a.cin / 16);
+    if (a.cin == 16) hipLaunchKernelGGL((pw_dw_direct_kernel<1>), grid, dim3(256), 0, s, q, tiles);
+    else hipLaunchKernelGGL((pw_dw_direct_kernel<2>), grid, dim3(256), 0, s, q, tiles);
+    return DN_OK;
+}
 
 bool pw_direct_supported(const PwArgs& a) {
     // squeeze-excitation scaled inputs: only where a 32-row tile lies inside one image (the 40 x 40 maps) and the reduction is short

@@ -454,6 +454,28 @@ def test_class_head_on_the_256_tile_matches_grouped_launch():
     assert torch.equal(res["0"][1], res["1"][1])          # the box heads stay in the grouped launch
 
 
+@pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
+                                           ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 3), ("ssd_lite_mobilenet_v2", 21, {}, 9)])
+def test_first_block_depthwise_in_the_projection_is_bit_identical(name, ncls, kw, n):
+    """DN_PW_DW (default 1 = 16-channel blocks, 2 = 32-channel ones too): the depthwise 3x3 of the first inverted-residual block (16 / 32 channels on the 160 x 160 / 150 x 150 map;
+    mobilenetv3.py:61-99, mobilenetv2.py:57-84 with expand_ratio 1) is computed straight into the B fragments of the projection behind it
+    (pwdirect.hip pw_dw_direct_kernel) with the arithmetic of the stand-alone kernels: head outputs must be bit-identical to the two
+    launches. 150 x 150 = 22 500 pixels per image is not a multiple of the 32-row wave tile (tiles straddle images); 37 images also run
+    as two sub-batch chains with the XCD grouping."""
+    size = kw.get("image_size", 320)
+    imgs = torch.from_numpy(synth.images(83, n, size, size)).cuda()
+    res = {}
+    for flag in ("0", "2"):                 # 2: also the 32-channel block of the V2 model (1, the default: 16 channels only)
+        os.environ["DN_PW_DW"] = flag
+        try:
+            m = _model(name, num_classes=ncls, **kw)
+            res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        finally:
+            del os.environ["DN_PW_DW"]
+    assert torch.equal(res["0"][0], res["2"][0]) and torch.equal(res["0"][1], res["2"][1])
+    assert float(res["2"][0].abs().max()) > 1.0
+
+
 def test_graph_replay_equals_eager():
     m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
     imgs = torch.from_numpy(synth.images(9, 4, 320, 320)).cuda()
