@@ -376,7 +376,8 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             // model at 300 x 300 1.481 -> 1.495 ms -- two K steps of nine taps per lane for a projection that fills half a tile: DN_PW_DW=2 only)
             if (dn_knob("DN_PW_DW", 1) && dw_ok(a) && a.k == 3 && a.stride == 1 && a.pad == 1 && a.pool < 0 && (a.cin == 16 || (a.cin == 32 && dn_knob("DN_PW_DW", 1) == 2)) &&
                 p->tensors[a.in].kind == DN_T_ACT && plain_pw(d) && d.in == a.out && uses[a.out] == 1 && d.cout <= 32 && d.cout % 8 == 0 &&
-                (d.residual < 0 || (d.residual == a.in && d.cout == a.cin)) && p->tensors[a.in].h * p->tensors[a.in].w >= 32) {
+                (d.residual < 0 || (d.residual == a.in && d.cout == a.cin)) && p->tensors[a.in].h * p->tensors[a.in].w >= 32 &&
+                fd_ok((unsigned long long)p->tensors[a.in].h * p->tensors[a.in].w, (unsigned)p->tensors[a.in].w)) {      // (the kernel's x = pixel % w)
                 p->fused_len[i] = 2; p->fused_kind[i] = 8; i += 1;
                 continue;
             }

@@ -221,7 +221,7 @@ struct PwDwArgs {
     PwArgs pw;                       // x = the depthwise INPUT [n][h][w][cin]; cin == depthwise channels; residual: null or == x
     const half_t* wd; const float* bd;      // depthwise weights [9][cin] fp16, bias [cin] fp32
     int h, w, act_dw;
-    float inv_hw;                    // 1 / (h w): image of a row by a corrected float quotient (rows < 2^24)
+    float inv_hw;                    // 1 / (h w): image of a row by a corrected float quotient
     FastDiv fd_w;
 };
 
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void pw_dw_direct_kernel(PwDwArgs q, int tiles
     {
         int q0 = (int)((float)mrow0 * q.inv_hw);
         int r0 = mrow0 - q0 * a.hw;
-        if (r0 < 0) r0 += a.hw;
-        if (r0 >= a.hw) r0 -= a.hw;
+        while (r0 < 0) r0 += a.hw;                            // (the float quotient is off by at most a few units even for 2^31 rows)
+        while (r0 >= a.hw) r0 -= a.hw;
         rem = r0 + (rowc - mrow0);
         if (rem >= a.hw) rem -= a.hw;
     }
@@ -366,7 +366,7 @@ int launch_t(const PwArgs& a, int wc_log, hipStream_t s) {
 bool pw_dw_direct_supported(const PwArgs& a, const DwArgs& d) {
     return dn_knob("DN_PW_DW", 1) != 0 && pw_direct_supported(a) && !a.se && (a.cin == 16 || a.cin == 32) && a.cout <= 32 && d.c == a.cin && d.k == 3 &&
            d.stride == 1 && d.pad == 1 && !d.pool && d.ho == d.h && d.wo == d.w_ && a.hw == d.h * d.w_ && (!a.residual || (a.residual == d.x && a.cout == a.cin)) &&
-           a.hw >= 32 && a.m < (1 << 24) && fd_ok((unsigned long long)a.hw, (unsigned)d.w_);
+           a.hw >= 32 && fd_ok((unsigned long long)a.hw, (unsigned)d.w_);
 }
 
 int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s) {
