@@ -23,7 +23,7 @@ def _batches(g, count, n, seed=40):
     return [torch.from_numpy(synth.images(seed + i, n, H, W)).cuda() for i in range(count)]
 
 
-@pytest.mark.parametrize("n,depth", [(8, 3), (32, 2), (5, 4)])
+@pytest.mark.parametrize("n,depth", [(8, 3), (32, 2), (5, 4), (64, 3)])          # (64, 3): BASELINE config C2 as bench.py runs it
 def test_pipeline_equals_one_forward_at_a_time(n, depth):
     """Seven different batches through a pipeline `depth` deep, results read as late as the contract allows (just before their
     slot is reused): bit-identical to forward_batch on the same images as single-chain forwards. Runs twice over the same slots,
