@@ -372,8 +372,8 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             }
             // depthwise 3x3 -> project without an expand (first block of the MobileNets, 16 / 32 channels on the largest map): the
             // depthwise is computed straight into the projection's B fragments (pwdirect.hip pw_dw_direct_kernel), fused_kind 8
-            // (measured: V3's 16-channel block batch 64 0.782 -> 0.771 ms in flight, 1.035 -> 1.026 one at a time; the 32-channel block of the V2
-            // model at 300 x 300 1.481 -> 1.495 ms -- two K steps of nine taps per lane for a projection that fills half a tile: DN_PW_DW=2 only)
+            // (measured: V3's 16-channel block batch 64 0.782 -> 0.765 ms in flight, 1.035 -> 1.02 one at a time; the 32-channel block of the V2
+            // model at 300 x 300 level with the two launches -- two K steps of nine taps per lane for a projection that fills half a tile: DN_PW_DW=2 only)
             if (dn_knob("DN_PW_DW", 1) && dw_ok(a) && a.k == 3 && a.stride == 1 && a.pad == 1 && a.pool < 0 && (a.cin == 16 || (a.cin == 32 && dn_knob("DN_PW_DW", 1) == 2)) &&
                 p->tensors[a.in].kind == DN_T_ACT && plain_pw(d) && d.in == a.out && uses[a.out] == 1 && d.cout <= 32 && d.cout % 8 == 0 &&
                 (d.residual < 0 || (d.residual == a.in && d.cout == a.cin)) && p->tensors[a.in].h * p->tensors[a.in].w >= 32 &&

@@ -283,24 +283,38 @@ __global__ __launch_bounds__(256) void pw_dw_direct_kernel(PwDwArgs q, int tiles
 #pragma unroll
     for (int ks = 0; ks < KSF; ++ks) {
         const int cb = ks * 16 + hh * 8;
-        half8 xin[9], wv[9];
+        // The launch is bound by the vector-memory pipe (22 wave-wide loads per wave for two MFMAs), and the depthwise weights / bias are the
+        // same for every pixel: both 8-channel halves of a tap come through the scalar cache (uniform address, constant address space) and
+        // the lane picks its half with selects -- nine vector loads less per lane.
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(4))) u4v* cp4;
+        typedef const __attribute__((address_space(4))) f4v* cpf4;
+        half8 xin[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int iy = py + ky - 1, ix = px + kx - 1;
                 const bool ok = iy >= 0 && iy < q.h && ix >= 0 && ix < q.w;
-                wv[ky * 3 + kx] = *reinterpret_cast<const half8*>(q.wd + (ky * 3 + kx) * K + cb);
                 xin[ky * 3 + kx] = *(ok ? (gp8)(xpix + ks * 16 + ((ky - 1) * q.w + (kx - 1)) * K) : zero);
             }
         float acc[8];
         {
-            const float4 b0 = *reinterpret_cast<const float4*>(q.bd + cb);
-            const float4 b1 = *reinterpret_cast<const float4*>(q.bd + cb + 4);
-            acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+            const cpf4 bp = (cpf4)(q.bd + ks * 16);
+            const f4v c0 = bp[0], c1 = bp[1], c2 = bp[2], c3 = bp[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] = hh ? c2[e] : c0[e]; acc[4 + e] = hh ? c3[e] : c1[e]; }
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) fma_mix_h8(acc, *reinterpret_cast<const uint4*>(&xin[t]), *reinterpret_cast<const uint4*>(&wv[t]));
+        for (int t = 0; t < 9; ++t) {
+            // this tap's weights: both halves sit in scalar registers, the lane's half is selected right before its use (nine selected
+            // fragments held at once cost 32 registers and three waves of occupancy)
+            const cp4 wp = (cp4)(q.wd + t * K + ks * 16);
+            const u4v w0 = wp[0], w1 = wp[1];
+            const uint4 wsel = make_uint4(hh ? w1[0] : w0[0], hh ? w1[1] : w0[1], hh ? w1[2] : w0[2], hh ? w1[3] : w0[3]);
+            fma_mix_h8(acc, *reinterpret_cast<const uint4*>(&xin[t]), wsel);
+        }
         dn_act_n<float[8], 8>(acc, q.act_dw);
 #pragma unroll
         for (int e = 0; e < 8; ++e) xf[ks][e] = (half_t)acc[e];
