@@ -81,9 +81,7 @@ __device__ __forceinline__ void dw_se_tail(const DwArgs& a, const int n, const i
     fc(a.se_w2t, a.se_b2, z, sq, c, a.se_scale + (size_t)n * c, true);
 }
 
-// POOL: 0 = none, 1 = per-workgroup channel sums for the squeeze-excitation, 2 = sums + the FCs in the image's last workgroup (dw_se_tail: its
-// 16-row load batches need 114 registers, which would cap every pooling launch at 4 waves per SIMD if the code were compiled into all of them)
-template <int K, int S, int TW, int POOL>
+template <int K, int S, int TW, bool POOL>
 __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int nblocks, const int n) {
     constexpr int NIN = (TW - 1) * S + K;
     extern __shared__ float red[];            // [256][8], only when pooling
@@ -113,14 +111,10 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     const int ix0 = ox0 * S - a.pad;
     typedef const __attribute__((address_space(1))) half8* gp8;     // explicit global pointers: the selected pointer must not degrade to a flat load
     const gp8 zero = (gp8)(&g_dw_zero16);
-    // RP kernel rows are requested together before their first use. Round 1 batched them (3 rows for 3x3, 2 for 5x5: fewer dependent
-    // memory round trips per thread) at 140 - 172 registers, i.e. 2 - 3 waves per SIMD. Re-measured with whole-batch launches and several
-    // forwards in flight: one row at a time (about 100 registers less, 2 - 3x the resident waves) is faster everywhere -- batch 64 0.766 ->
-    // 0.751 ms in flight, 1.019 -> 1.015 ms one forward at a time, batch 32 0.428 -> 0.424 ms (3x3 alone: 0.762 / 1.016; 5x5 alone: 0.756 / 1.033).
-    // The launches that carry a squeeze-excitation tail (POOL == 2) keep the round-1 batching: with one row at a time their cross-workgroup
-    // hand-over showed run-to-run differences (tests/test_gpu_model.py::test_se_tail..., 2 of 10 runs) that the batched form never has --
-    // not understood yet, so the timing that has been exercised all round stays.
-    constexpr int RP = POOL == 2 ? ((K == 3) ? 3 : 2) : 1;
+    // RP kernel rows are requested together before their first use: hipcc otherwise waits for each row's loads before
+    // issuing the next row's (vmcnt(0) per row), i.e. K dependent memory round trips per thread. 3x3 takes all rows at once;
+    // 5x5 two at a time (all five would need 260 VGPRs of staging).
+    constexpr int RP = (K == 3) ? 3 : 2;
     const half_t* const wbase = a.w + c0;
     const half_t* const xbase = a.x + (size_t)n * a.h * a.w_ * a.c + c0;
 #pragma unroll
@@ -181,21 +175,17 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t8[e] += red[u * 8 + e];
             float* dst = a.pool + ((size_t)n * nblocks + bx) * a.c + cgp * 8;
-            if constexpr (POOL == 2) {
+            if (a.se_scale) {
                 // published for the last workgroup of the image (below): device-scope atomic stores go to the coherence point
                 // themselves, so no cache-flushing fence is needed to make them visible
 #pragma unroll
                 for (int e = 0; e < 8; ++e) __hip_atomic_store(&dst[e], t8[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // ... and THIS thread waits until they are acknowledged there, before the barrier that precedes the ticket: a workgroup-scope
-                // fence alone compiles to no wait in non-tgsplit mode (the waves of a workgroup share an L1), and the ticket of thread 0
-                // -- another wave -- could overtake stores still in flight (seen as run-to-run differences once the launch got faster)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dst[e] = t8[e];
             }
         }
-        if constexpr (POOL == 2) {
+        if (a.se_scale) {
             // last workgroup of the image (threadfence + counter, the classic "last block" reduction): its partial sums and
             // everybody else's are visible after the fences; the counter goes back to zero for the next launch
             // Last workgroup of the image: ticket by a relaxed device-scope atomic. NO device-scope fence: on gfx950 a release at agent
@@ -217,7 +207,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     }
 }
 
-template <int K, int S, int TW, int POOL>
+template <int K, int S, int TW, bool POOL>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, int nblocks) {
     int img, bx;
     if (!xcd_image_of2(a.xq, a.n, img, bx)) return;
@@ -246,7 +236,7 @@ __global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
     if (a.xq > 0) { img = (rel & 7) * a.xq + blockIdx.y; bx = rel >> 3; }
     else { img = blockIdx.y; bx = rel; }
     if (img >= a.n) return;
-    dw_body<K, S, TW, 0>(a, bx, g.nblocks[p], img);
+    dw_body<K, S, TW, false>(a, bx, g.nblocks[p], img);
 }
 
 template <int K, int S, int TW>
@@ -286,9 +276,8 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
     const int nblocks = dn_cdiv(threads, 256);
     if (a.se_scale) DN_REQUIRE(a.pool && a.se_counter && depthwise_se_tail_supported(a.c, a.se_sq), "depthwise: squeeze-excitation tail needs the pooled output and c <= 1024, squeeze <= 256, both multiples of 8");
     const size_t pool_lds = a.se_scale ? (size_t)(a.c + a.se_sq + 2048) * 4 : (size_t)256 * 8 * 4;
-    if (a.pool && a.se_scale) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), pool_lds, s, a, nblocks);
-    else if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), pool_lds, s, a, nblocks);
-    else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), 0, s, a, nblocks);
+    if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, true>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), pool_lds, s, a, nblocks);
+    else hipLaunchKernelGGL((dw_kernel<K, S, TW, false>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), 0, s, a, nblocks);
     return DN_OK;
 }
 

