@@ -126,6 +126,14 @@ def test_factory_api_mirrors_reference():
     m.eval()
     with pytest.raises(RuntimeError):
         m([torch.zeros(3, 320, 320)])          # CPU input: the product path has no fallback
+    from demonet_amd.pipeline import ForwardPipeline
+    from demonet_amd import engine
+    with pytest.raises(RuntimeError):
+        ForwardPipeline(m, 4, device="cpu")    # ... nor does the pipeline of forwards in flight
+    with pytest.raises(ValueError):
+        ForwardPipeline(m, 4, depth=0)
+    with pytest.raises(RuntimeError):
+        engine.evaluate(m, [([torch.zeros(3, 320, 320)], [{"image_id": 1}])], device="cpu")
 
 
 def test_graph_geometry_matches_survey():
