@@ -34,16 +34,16 @@ DEFAULT_MODEL, DEFAULT_BATCH = "ssdlite320_mobilenet_v3_large", 64   # BASELINE.
 C4_GLOBAL_BATCH = 256                                                  # BASELINE.json configs[3]: batch 256 over the GPUs of one node
 
 
-def _norm_kernel(name):
-    """rocprofv3 spells defaulted template arguments out (conv_halo_kernel<3,4,4,false>), the library's labels do not. The
-    register-direct 1x1 kernel (pwdirect.hip) is ONE kernel instantiated per reduction length (pw_direct_kernel<cin / 16, 1>): its
-    instantiations are accounted as one family, launch-weighted."""
+def _family(name):
+    """Kernel FAMILY = the template's name without its arguments: every template is grouped the same way (expdw_kernel<3,2,8,8,2,..> and
+    expdw_kernel<3,1,8,16,..> are one family, like the per-reduction-length instantiations of pw_direct_kernel), launch-weighted.
+    The dominant family is the one with the largest share of the step's kernel time."""
     name = name.replace(" ", "")
-    if name.startswith("pw_direct_kernel<"):
-        return "pw_direct_kernel"
-    while name.endswith(",false>"):
-        name = name[:-7] + ">"
-    return name
+    cut = name.find("<")
+    return name if cut < 0 else name[:cut]
+
+
+POINTWISE_FAMILIES = ("pw_direct_kernel", "pw_kernel", "pw_xs_kernel", "pw_group_kernel")     # stand-alone 1x1 launches (north_star's ">= 90 % of roofline" path)
 
 
 def op_costs(graph, n):
@@ -104,24 +104,32 @@ def cpu_baseline(name, graph, seed, budget_s=24.0):
     per-class top-k + NMS: python / numpy loops as in the reference) are timed separately. `value` = the fastest variant."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ssd_oracle as so
+    import fast_post
     from demonet_amd import synth
     cores = os.cpu_count() or 1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     many = min(cores, 16)          # more threads than this only adds oversubscription on these small convs
     o = so.OracleSSD(name, synth.state_dict(graph, 0), graph.num_classes, size=graph.size)
     W, H = graph.size
     hw = (H, W)
     imgs = [torch.from_numpy(synth.images(seed + i, 1, H, W)[0]) for i in range(8)]
 
-    def run(batch, threads, budget):
+    def run(batch, threads, budget, post="python"):
         torch.set_num_threads(threads)
         o(imgs[:1])                                   # warm-up
+        pp = so.postprocess_detections if post == "python" else fast_post.postprocess_detections
         done, t_net, t_post = 0, 0.0, 0.0
         t0 = time.time()
         while True:
             a = time.time()
             r = o.forward_raw(imgs[:batch])
             b = time.time()
-            dets = so.postprocess_detections(r["cls_logits"], r["bbox_regression"], r["anchors"], hw, **o.post)
+            dets = pp(r["cls_logits"], r["bbox_regression"], r["anchors"], hw, **o.post)
             for d, orig in zip(dets, r["orig"]):
                 d["boxes"] = so.resize_boxes(d["boxes"], hw, orig)
             c = time.time()
@@ -131,19 +139,28 @@ def cpu_baseline(name, graph, seed, budget_s=24.0):
             if time.time() - t0 > budget or done >= 64:
                 break
         dt = time.time() - t0
-        return {"batch": batch, "threads": threads, "images": done, "seconds": round(dt, 2), "images_per_sec": round(done / dt, 2),
+        return {"batch": batch, "threads": threads, "postprocess": post, "images": done, "seconds": round(dt, 2), "images_per_sec": round(done / dt, 2),
                 "network_ms_per_img": round(t_net / done * 1e3, 2), "postprocess_ms_per_img": round(t_post / done * 1e3, 2)}
 
-    share = budget_s / 4.0
-    variants = [run(8, many, share), run(1, many, share), run(1, 1, share), run(8, 1, share)]
+    # two post-process implementations of the SAME function: "python" = the checker's numpy / Python loops (the port of the reference's
+    # 90-iteration loop with a Python NMS: what this repo's oracle runs), "vectorised" = torch.topk per class + a compiled greedy NMS
+    # (oracle/fast_post.py + nms_c.c: what the reference's loop costs on a box with torchvision's C++ nms). Six bounded variants.
+    share = budget_s / 6.0
+    variants = [run(8, many, share, "vectorised"), run(1, many, share, "vectorised"), run(1, 1, share, "vectorised"), run(8, 1, share, "vectorised"),
+                run(8, many, share, "python"), run(1, 1, share, "python")]
     torch.set_num_threads(many)
     best = max(variants, key=lambda v: v["images_per_sec"])
+    best_py = max((v for v in variants if v["postprocess"] == "python"), key=lambda v: v["images_per_sec"])
     net = min(variants, key=lambda v: v["network_ms_per_img"])
     return {"value": best["images_per_sec"], "unit": "images/sec", "cores": cores, "threads": best["threads"], "kind": "port",
-            # the post-process of the port (and of the reference: 90 python iterations per image) dominates the CPU path; the network
-            # alone (transform + backbone + heads), fastest variant, for orientation:
+            "cpu_model": cpu_model,
+            "postprocess": best["postprocess"],
+            # the checker's own post-process (Python / numpy loops), for comparison with earlier rounds' lines:
+            "port_python_postprocess_images_per_sec": best_py["images_per_sec"],
+            # the network alone (transform + backbone + heads), fastest variant, for orientation:
             "network_only_images_per_sec": round(1e3 / net["network_ms_per_img"], 1),
-            "sample": f"synthetic {H}x{W} images, full path incl. NMS, fp32 torch CPU eager; os.cpu_count() = {cores}; fastest of "
+            "sample": f"synthetic {H}x{W} images, full path incl. NMS, fp32 torch CPU eager, post-process = {best['postprocess']} "
+                      f"(vectorised: torch.topk per class + compiled greedy NMS; python: the checker's loops); {cpu_model}, os.cpu_count() = {cores}; fastest of "
                       f"{len(variants)} bounded variants (batch {best['batch']}, {best['threads']} threads: {best['images']} images in "
                       f"{best['seconds']} s); per-variant split of network vs post-process time in `variants`",
             "variants": variants}
@@ -387,9 +404,12 @@ def main():
                 costs[i]["bytes"] = ext / len(mem)
         owners = {}
         for i, c in enumerate(costs):
-            a = agg.setdefault(_norm_kernel(c["kernel"]) if c["kernel"].startswith("pw_direct_kernel<") else c["kernel"], dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+            if c["kernel"].startswith("("):
+                continue                            # no launch of its own (a squeeze-excitation computed inside another launch): its event segment is empty
+            a = agg.setdefault(_family(c["kernel"]), dict(ms=0.0, bytes=0.0, flops=0.0, launches=0, members=set()))
             a["bytes"] += c["bytes"]
             a["flops"] += c["flops"]
+            a["members"].add(c["kernel"])
             if c["owner"] not in owners:
                 owners[c["owner"]] = c["kernel"]
                 a["ms"] += buf[c["owner"]]          # summed over the sub-batch launches of one forward
@@ -418,61 +438,111 @@ def main():
         total_ms = sum(a["ms"] for a in agg.values())
         dom = max(agg, key=lambda k: agg[k]["ms"])
         d = agg[dom]
-        # which roof bounds the dominant kernel: arithmetic intensity against the machine balance (2500 TF/s / 8 TB/s = 312 flop/B)
-        mfma_bound = d["flops"] / max(d["bytes"], 1.0) > MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
-        if mfma_bound:
-            ach, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
-        else:
-            ach, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-        traffic, traffic_src = None, None
-        prof_tag = {("ssdlite320_mobilenet_v3_large", 64): "", ("ssd512_vgg16", 32): "_vgg512", ("ssd300_vgg16", 64): "_vgg300"}.get((args.model, B))
-        if prof_tag is not None:
-            # HBM bytes per launch from the PMC passes committed under profiles/ (tools/round_profile.sh + tools/pmc_traffic.py)
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_hbm_traffic.json")), reverse=True):
-                with open(path) as f:
-                    tk = json.load(f)["kernels"]
-                fam = {}
-                for k, v in tk.items():         # launch-weighted over the instantiations of a family
-                    e = fam.setdefault(_norm_kernel(k), [0.0, 0])
-                    e[0] += v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1)
-                    e[1] += v.get("launches_sampled", 1)
-                if _norm_kernel(dom) in fam:
-                    e = fam[_norm_kernel(dom)]
-                    traffic, traffic_src = round(e[0] / max(e[1], 1)), os.path.relpath(path, ROOT)
-                    break
-        def rocprof_avg_of(suffix):
-            # the same kernel's average duration in a committed rocprofv3 --kernel-trace --stats summary (tools/round_profile.sh):
-            # "kernel_stats" = this command (graph replay with the forwards in flight: a launch shares the chip with the other forwards'
-            # kernels), "kernel_stats_one_forward" = --inflight 1 --chains 1 (one single-chain forward at a time: the condition of the
-            # live figure, which is HIP events around each launch in an eager pass and adds the ~3 us dispatch gap)
-            import csv, glob, re
+
+        def roof(x, ms):
+            # which roof bounds it: arithmetic intensity against the machine balance (2500 TF/s / 8 TB/s = 312 flop/B)
+            mfma = x["flops"] / max(x["bytes"], 1.0) > MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+            if mfma:
+                return "mfma", x["flops"] / (ms * 1e-3) / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+            return "hbm", x["bytes"] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+
+        bound, ach, peak, unit = roof(d, d["ms"])
+        import csv, glob, re
+        prof_tag = {("ssdlite320_mobilenet_v3_large", 64): "", ("ssdlite320_mobilenet_v3_large", 32): "_batch32", ("ssd512_vgg16", 32): "_vgg512",
+                    ("ssd300_vgg16", 64): "_vgg300", ("ssd_lite_mobilenet_v2", 128): "_v2_300" if H == 300 else None}.get((args.model, B))
+
+        def latest(suffix):
             if prof_tag is None:
                 return None
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_{suffix}.csv")), reverse=True):
-                tot_ns, calls = 0.0, 0
-                with open(path) as f:
-                    for r in csv.DictReader(f):
-                        nm = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
-                        nm = re.sub(r"\(.*$", "", nm).replace("void ", "").replace(", ", ",").strip()
-                        if _norm_kernel(nm) == _norm_kernel(dom):
-                            tot_ns += float(r["TotalDurationNs"])
-                            calls += int(r["Calls"])
-                if calls:
-                    return round(tot_ns / calls / 1e3, 2)
-            return None
-        rocprof_avg = rocprof_avg_of("kernel_stats")
-        rocprof_avg1 = rocprof_avg_of("kernel_stats_one_forward")
-        result["roofline"] = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
+            paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{prof_tag}_{suffix}")), reverse=True)
+            return paths[0] if paths else None
+
+        def traffic_of(fam_name):
+            # HBM bytes per launch from the PMC passes committed under profiles/ (tools/round_profile.sh + tools/pmc_traffic.py), launch-weighted
+            path = latest("hbm_traffic.json")
+            if not path:
+                return None, None
+            with open(path) as f:
+                tk = json.load(f)["kernels"]
+            tot, cnt = 0.0, 0
+            for k, v in tk.items():
+                if _family(k) == fam_name:
+                    tot += v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1)
+                    cnt += v.get("launches_sampled", 1)
+            return (round(tot / cnt), os.path.relpath(path, ROOT)) if cnt else (None, None)
+
+        def rocprof_families(suffix):
+            # per-family totals of a committed rocprofv3 --kernel-trace --stats summary (tools/round_profile.sh): "kernel_stats.csv" = this
+            # command (graph replay, forwards in flight: a launch shares the chip), "kernel_stats_one_forward.csv" = --inflight 1 --chains 1
+            # (one single-chain forward at a time: the condition of the live event pass, without its ~3-5 us eager dispatch gap per launch)
+            path = latest(suffix)
+            if not path:
+                return None, None
+            fam = {}
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    nm = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
+                    nm = re.sub(r"\(.*$", "", nm).replace("void ", "").strip()
+                    if nm.startswith("__amd") or "at::" in nm:
+                        continue
+                    e = fam.setdefault(_family(nm), [0.0, 0])
+                    e[0] += float(r["TotalDurationNs"])
+                    e[1] += int(r["Calls"])
+            return fam, os.path.relpath(path, ROOT)
+
+        traffic, traffic_src = traffic_of(dom)
+        fam_t, src_t = rocprof_families("kernel_stats.csv")
+        fam_1, src_1 = rocprof_families("kernel_stats_one_forward.csv")
+        rp = {}
+        if fam_1 and dom in fam_1:
+            avg_us = fam_1[dom][0] / fam_1[dom][1] / 1e3
+            _, ach1, _, _ = roof(d, avg_us * 1e-3 * d["launches"])
+            rp = {"source": src_1, "avg_launch_us": round(avg_us, 2), "achieved": round(ach1, 1), "frac": round(ach1 / peak, 4),
+                  "share_of_kernel_time": round(fam_1[dom][0] / sum(v[0] for v in fam_1.values()), 3)}
+        if fam_t:
+            tot_t = sum(v[0] for v in fam_t.values())
+            dom_t = max(fam_t, key=lambda k: fam_t[k][0])
+            rp.update({"timed_command_source": src_t, "timed_command_dominant": dom_t, "timed_command_dominant_share": round(fam_t[dom_t][0] / tot_t, 3)})
+            if dom in fam_t:
+                rp.update({"timed_command_avg_launch_us": round(fam_t[dom][0] / fam_t[dom][1] / 1e3, 2), "timed_command_share": round(fam_t[dom][0] / tot_t, 3)})
+        # the whole step against the HBM roof: external algorithmic bytes of every launch / the TIMED step
+        step_bytes = sum(a["bytes"] for a in agg.values())
+        step_flops = sum(a["flops"] for a in agg.values())
+        # the stand-alone 1x1 launches together (north_star: ">= 90 % of fp16 roofline on the pointwise-conv hot path"); the 1x1 convs inside
+        # the fused block kernels (expdw_kernel, pw_dw_direct_kernel) are accounted with those families
+        pw = dict(ms=sum(agg[k]["ms"] for k in agg if k in POINTWISE_FAMILIES), bytes=sum(agg[k]["bytes"] for k in agg if k in POINTWISE_FAMILIES),
+                  flops=sum(agg[k]["flops"] for k in agg if k in POINTWISE_FAMILIES), launches=sum(agg[k]["launches"] for k in agg if k in POINTWISE_FAMILIES))
+        pw_obj = None
+        if pw["ms"] > 0:
+            # per-launch roofline time max(bytes / 8 TB/s, flops / 2.5 PF/s) summed over the launches, against the measured time
+            t_roof_ms = 0.0
+            seen = set()
+            for i, c in enumerate(costs):
+                if not c["kernel"].startswith("(") and _family(c["kernel"]) in POINTWISE_FAMILIES:
+                    t_roof_ms += max(c["bytes"] / (HBM_PEAK_GBS * 1e9), c["flops"] / (MFMA_PEAK_TFLOPS * 1e12)) * 1e3
+            pw_obj = {"families": [k for k in agg if k in POINTWISE_FAMILIES], "launches_per_step": pw["launches"], "ms": round(pw["ms"], 4),
+                      "GB/s": round(pw["bytes"] / pw["ms"] / 1e6, 1), "TFLOP/s": round(pw["flops"] / pw["ms"] / 1e9, 1),
+                      "roofline_ms": round(t_roof_ms, 4), "frac": round(t_roof_ms / pw["ms"], 4)}
+            if fam_1:
+                ns = sum(fam_1[k][0] / max(fam_1[k][1], 1) * agg[k]["launches"] for k in agg if k in POINTWISE_FAMILIES and k in fam_1)
+                if ns > 0:
+                    pw_obj["rocprof_ms"] = round(ns / 1e6, 4)
+                    pw_obj["rocprof_frac"] = round(t_roof_ms / (ns / 1e6), 4)
+        result["roofline"] = {"kernel": dom, "members": sorted(d["members"]), "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                              "timing": "HIP events around every launch of one eager single-chain forward on the launch stream (includes the eager dispatch gap); `rocprof` = the same family in the committed rocprofv3 summaries",
                               "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
-                              "rocprof_avg_launch_us": rocprof_avg, "rocprof_avg_launch_us_one_forward": rocprof_avg1,
                               "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                               "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
                               "share_of_step": round(d["ms"] / total_ms, 3), "profiled_runs": runs,
-                              "eager_sum_ms": round(total_ms, 4)}
+                              "eager_sum_ms": round(total_ms, 4), "rocprof": rp or None,
+                              "step": {"algorithmic_bytes": round(step_bytes), "algorithmic_flops": round(step_flops), "ms_per_step": round(ms_per_step, 4),
+                                       "GB/s": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "TFLOP/s": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1)},
+                              "pointwise": pw_obj}
         result["kernels"] = {k: {"ms": round(v["ms"], 4), "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
-                                 "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "launches": v["launches"]}
+                                 "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "launches": v["launches"],
+                                 "share": round(v["ms"] / total_ms, 3)}
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, g, 1002)

@@ -43,7 +43,8 @@ __device__ __forceinline__ float dn_act(float v, int act) {
     const float hi = (act == DN_ACT_RELU6) ? 6.f : INFINITY;
     const float clamped = fminf(fmaxf(v, lo), hi);
     const float hs = v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
-    return act == DN_ACT_HSWISH ? hs : clamped;
+    // (identity returns v itself: fmaxf / fminf would turn a NaN into -inf and hide a numerical failure from the NaN checks)
+    return act == DN_ACT_HSWISH ? hs : (act == DN_ACT_NONE ? v : clamped);
 }
 
 // acc[0..7] += e[0..7] * w[0..7] with fp16 operands and fp32 accumulation in ONE instruction per element (v_fma_mix_f32).
@@ -183,6 +184,7 @@ struct DwArgs {
     const half_t* se_w2t = nullptr; const float* se_b2 = nullptr;      // fc2 transposed [sq][c] fp16, bias [c]
     float* se_scale = nullptr; unsigned* se_counter = nullptr;
     int se_sq = 0; float se_inv = 0.f;                                 // squeeze width, 1 / pooled pixels
+    float* dbg = nullptr;                                              // dev-only (dn_debug_dw_table)
 };
 bool depthwise_se_tail_supported(int c, int squeeze);
 int launch_depthwise(const DwArgs& a, hipStream_t s);

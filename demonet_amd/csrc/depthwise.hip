@@ -9,6 +9,18 @@
 
 static long long* g_se_stamps = nullptr;     // dev hook (tools/probe_se.py)
 extern "C" __attribute__((visibility("default"))) void dn_debug_se_stamps(void* dev_ptr) { g_se_stamps = (long long*)dev_ptr; }
+// dev hook (tools/hunt_dw_rows.py): pooling launches whose partial-sum buffer is in the table also dump every thread's fp32 outputs and
+// pooled sums ([workgroup][256][TW * 8 + 8] floats) to buf + index * stride_bytes
+static const void* g_dw_dbg_pool[64];
+static int g_dw_dbg_count = 0;
+static unsigned char* g_dw_dbg_buf = nullptr;
+static size_t g_dw_dbg_stride = 0;
+extern "C" __attribute__((visibility("default"))) void dn_debug_dw_table(const void* const* pool_ptrs, int count, void* buf, size_t stride_bytes) {
+    g_dw_dbg_count = count < 64 ? (count > 0 ? count : 0) : 64;
+    for (int i = 0; i < g_dw_dbg_count; ++i) g_dw_dbg_pool[i] = pool_ptrs[i];
+    g_dw_dbg_buf = (unsigned char*)buf;
+    g_dw_dbg_stride = stride_bytes;
+}
 
 namespace {
 
@@ -81,7 +93,10 @@ __device__ __forceinline__ void dw_se_tail(const DwArgs& a, const int n, const i
     fc(a.se_w2t, a.se_b2, z, sq, c, a.se_scale + (size_t)n * c, true);
 }
 
-template <int K, int S, int TW, bool POOL>
+// POOL: 0 = none, 1 = per-workgroup channel sums for the squeeze-excitation, 2 = sums + the FCs in the image's last workgroup
+//   (dw_se_tail: its 16-row load batches need 114 registers, which capped EVERY pooling launch while the code was compiled into all of them).
+// MODE bit 0: one kernel row of loads at a time instead of the batched rows (DN_DW_ROWS=1; see RP below); bit 1: debug dump (dn_debug_dw_table).
+template <int K, int S, int TW, int POOL, int MODE>
 __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int nblocks, const int n) {
     constexpr int NIN = (TW - 1) * S + K;
     extern __shared__ float red[];            // [256][8], only when pooling
@@ -92,7 +107,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     const unsigned oy = fd_div(q1, a.fd_xs);
     const unsigned xs = q1 - oy * a.fd_xs.d;
     const bool valid = (int)oy < a.ho;
-    if (!valid && !POOL) return;
+    if (!valid && POOL == 0) return;
     const int ox0 = xs * TW;
     const unsigned c0 = cg * 8;
     float psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -114,7 +129,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     // RP kernel rows are requested together before their first use: hipcc otherwise waits for each row's loads before
     // issuing the next row's (vmcnt(0) per row), i.e. K dependent memory round trips per thread. 3x3 takes all rows at once;
     // 5x5 two at a time (all five would need 260 VGPRs of staging).
-    constexpr int RP = (K == 3) ? 3 : 2;
+    constexpr int RP = (MODE & 1) ? 1 : ((K == 3) ? 3 : 2);
     const half_t* const wbase = a.w + c0;
     const half_t* const xbase = a.x + (size_t)n * a.h * a.w_ * a.c + c0;
 #pragma unroll
@@ -155,13 +170,27 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if constexpr (POOL) psum[e] += acc[t][e];
+            if constexpr (POOL != 0) psum[e] += acc[t][e];
             o[e] = (half_t)acc[t][e];
         }
         *reinterpret_cast<half8*>(orow + (unsigned)((ox0 + t) * a.c)) = o;
+        if constexpr ((MODE & 2) != 0) {
+            if (a.dbg) {
+                float* dp = a.dbg + ((size_t)(n * nblocks + bx) * 256 + threadIdx.x) * (TW * 8 + 8) + t * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dp[e] = acc[t][e];
+            }
+        }
     }
     }   // valid
-    if constexpr (POOL) {
+    if constexpr ((MODE & 2) != 0) {
+        if (a.dbg) {
+            float* dp = a.dbg + ((size_t)(n * nblocks + bx) * 256 + threadIdx.x) * (TW * 8 + 8) + TW * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dp[e] = psum[e];
+        }
+    }
+    if constexpr (POOL != 0) {
         // SE squeeze (mobilenetv3.py:32 adaptive_avg_pool2d) fused as deterministic per-workgroup partial sums:
         // threads with equal channel group sit C8 apart; thread t < C8 adds them in a fixed order.
 #pragma unroll
@@ -175,26 +204,29 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t8[e] += red[u * 8 + e];
             float* dst = a.pool + ((size_t)n * nblocks + bx) * a.c + cgp * 8;
-            if (a.se_scale) {
-                // published for the last workgroup of the image (below): device-scope atomic stores go to the coherence point
-                // themselves, so no cache-flushing fence is needed to make them visible
+            if constexpr (POOL == 2) {
+                // published for the last workgroup of the image (below): device-scope atomic stores (sc1) write through to the
+                // coherence point themselves, so no cache-flushing fence is needed to make them visible ...
 #pragma unroll
                 for (int e = 0; e < 8; ++e) __hip_atomic_store(&dst[e], t8[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // ... but THIS thread must see them acknowledged before the barrier that precedes the ticket. A workgroup-scope fence
+                // compiles to NO wait here (non-tgsplit mode: the waves of a workgroup share an L1; ISA before this line was
+                // `global_store_dword ... sc1` x 8 -> s_barrier -> global_atomic_add), so the ticket of thread 0 -- another wave, another
+                // L2 channel -- could become visible before these stores and the last workgroup would read stale rows.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dst[e] = t8[e];
             }
         }
-        if (a.se_scale) {
-            // last workgroup of the image (threadfence + counter, the classic "last block" reduction): its partial sums and
-            // everybody else's are visible after the fences; the counter goes back to zero for the next launch
+        if constexpr (POOL == 2) {
             // Last workgroup of the image: ticket by a relaxed device-scope atomic. NO device-scope fence: on gfx950 a release at agent
-            // scope writes back the XCD's whole L2 (measured: +20 - 100 us per launch, once per workgroup). The partial sums were
-            // stored with device-scope atomics; a workgroup-scope fence (s_waitcnt: the stores are acknowledged by the coherence point)
-            // + barrier orders them before the ticket of thread 0, and the last workgroup reads them back with device-scope atomic
-            // loads. (Hardware reasoning, not the formal model: the formal release would be the flushing fence.)
+            // scope writes back the XCD's whole L2 (measured: +20 - 100 us per launch, once per workgroup). Instead: the partial sums
+            // were stored with device-scope (write-through) atomics and every storing thread has waited for their acknowledgement
+            // (s_waitcnt vmcnt(0) above); the barrier orders those waits before the ticket of thread 0; the last workgroup reads the
+            // rows back with device-scope atomic loads issued after its ticket has returned (the barrier below). This is the
+            // hardware's ordering, spelled out -- the formal-model release would be the flushing fence.
             __shared__ int s_last;
-            __threadfence_block();
             __syncthreads();
             if (threadIdx.x == 0)
                 s_last = __hip_atomic_fetch_add(&a.se_counter[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1);
@@ -207,11 +239,11 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     }
 }
 
-template <int K, int S, int TW, bool POOL>
+template <int K, int S, int TW, int POOL, int MODE>
 __global__ __launch_bounds__(256) void dw_kernel(DwArgs a, int nblocks) {
     int img, bx;
     if (!xcd_image_of2(a.xq, a.n, img, bx)) return;
-    dw_body<K, S, TW, POOL>(a, bx, nblocks, img);
+    dw_body<K, S, TW, POOL, MODE>(a, bx, nblocks, img);
 }
 
 // Grouped launch: up to 12 independent depthwise problems of the same (k, stride) and batch in ONE launch (the head
@@ -236,7 +268,7 @@ __global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
     if (a.xq > 0) { img = (rel & 7) * a.xq + blockIdx.y; bx = rel >> 3; }
     else { img = blockIdx.y; bx = rel; }
     if (img >= a.n) return;
-    dw_body<K, S, TW, false>(a, bx, g.nblocks[p], img);
+    dw_body<K, S, TW, 0, 0>(a, bx, g.nblocks[p], img);
 }
 
 template <int K, int S, int TW>
@@ -276,8 +308,30 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
     const int nblocks = dn_cdiv(threads, 256);
     if (a.se_scale) DN_REQUIRE(a.pool && a.se_counter && depthwise_se_tail_supported(a.c, a.se_sq), "depthwise: squeeze-excitation tail needs the pooled output and c <= 1024, squeeze <= 256, both multiples of 8");
     const size_t pool_lds = a.se_scale ? (size_t)(a.c + a.se_sq + 2048) * 4 : (size_t)256 * 8 * 4;
-    if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, true>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), pool_lds, s, a, nblocks);
-    else hipLaunchKernelGGL((dw_kernel<K, S, TW, false>), xcd_grid2(nblocks, a.xq, a.n), dim3(256), 0, s, a, nblocks);
+    const dim3 grid = xcd_grid2(nblocks, a.xq, a.n);
+    const int rows1 = dn_knob("DN_DW_ROWS", 0) == 1 ? 1 : 0;
+    if (a.pool && g_dw_dbg_count > 0) {
+        for (int i = 0; i < g_dw_dbg_count; ++i)
+            if (g_dw_dbg_pool[i] == (const void*)a.pool) a.dbg = reinterpret_cast<float*>(g_dw_dbg_buf + (size_t)i * g_dw_dbg_stride);
+        if (a.se_scale) {
+            if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 3>), grid, dim3(256), pool_lds, s, a, nblocks);
+            else hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 2>), grid, dim3(256), pool_lds, s, a, nblocks);
+        } else {
+            if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 3>), grid, dim3(256), pool_lds, s, a, nblocks);
+            else hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 2>), grid, dim3(256), pool_lds, s, a, nblocks);
+        }
+        return DN_OK;
+    }
+    if (a.pool && a.se_scale) {
+        if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 1>), grid, dim3(256), pool_lds, s, a, nblocks);
+        else hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 0>), grid, dim3(256), pool_lds, s, a, nblocks);
+    } else if (a.pool) {
+        if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 1>), grid, dim3(256), pool_lds, s, a, nblocks);
+        else hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 0>), grid, dim3(256), pool_lds, s, a, nblocks);
+    } else {
+        if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 1>), grid, dim3(256), 0, s, a, nblocks);
+        else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 0>), grid, dim3(256), 0, s, a, nblocks);
+    }
     return DN_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <set>
@@ -149,7 +150,19 @@ struct dn_plan {
     std::vector<std::string> prof_kernel;   // label of the launch each op took part in
     std::vector<int> prof_owner;            // op index whose event segment holds that launch's time
     int prof_runs = 0;
+    // packed_out / input_u8 / the graph cache are per-plan mutable state set around a call: a plan serves ONE host thread at a time
+    // (several forwards in flight are several STREAMS fed by one thread, pipeline.py). A second thread entering gets DN_E_INVALID.
+    std::atomic<int> in_call{0};
 };
+
+// Graph executables may still be replaying on other streams (the slots of a ForwardPipeline) when the cache is cleared: drain the
+// device first. Clearing is rare (cache bound reached, dn_set_chains, dn_destroy), so the host wait does not matter.
+static void drop_graphs(dn_plan* p) {
+    if (p->graphs.empty()) return;
+    (void)hipDeviceSynchronize();
+    for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
+    p->graphs.clear();
+}
 
 // The launch chain is latency-bound (~70 dependent launches, most of them far from filling 256 CUs), so a forward of n images
 // is issued as `split` independent sub-batch chains that the hipGraph runs as parallel branches (measured +6 % at n = 64 with
@@ -701,7 +714,8 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
 
 extern "C" void dn_destroy(dn_plan* p) {
     if (!p) return;
-    for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
+    (void)hipDeviceSynchronize();       // forwards of this plan may still be in flight on the caller's streams: the weights go away below
+    drop_graphs(p);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
     for (int i = 0; i < 2; ++i) if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
     for (int i = 0; i < 8; ++i) if (p->ev_feat[i]) (void)hipEventDestroy(p->ev_feat[i]);
@@ -733,10 +747,16 @@ extern "C" int dn_set_chains(dn_plan* p, int chains) {
     if (chains == p->chains_override) return DN_OK;
     p->chains_override = chains;
     // layouts, workspace sizes and captured graphs all depend on the split
-    for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
-    p->graphs.clear();
+    drop_graphs(p);
     p->layouts.clear();
     p->sub_layouts.clear();
+    return DN_OK;
+}
+
+// dev hook: forget the captured graphs (tools that install debug hooks after the first forward)
+extern "C" __attribute__((visibility("default"))) int dn_debug_clear_graphs(dn_plan* p) {
+    DN_REQUIRE(p, "null plan");
+    drop_graphs(p);
     return DN_OK;
 }
 
@@ -1315,6 +1335,12 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
                         int32_t* counts, void* workspace, size_t ws_bytes, void* stream, bool heads_only) {
     DN_REQUIRE(p && images && workspace, "dn_forward: null argument");
     DN_REQUIRE(n > 0 && h > 0 && w > 0, "dn_forward: bad shape n=%d h=%d w=%d", n, h, w);
+    struct Busy {
+        std::atomic<int>& f; bool ok;
+        explicit Busy(std::atomic<int>& x) : f(x), ok(x.exchange(1) == 0) {}
+        ~Busy() { if (ok) f.store(0); }
+    } busy(p->in_call);
+    DN_REQUIRE(busy.ok, "dn_forward: the plan is in use by another host thread (one plan serves one thread at a time; use one plan per thread)");
     DN_REQUIRE(heads_only || (boxes && scores && labels && counts), "dn_forward: null output buffer");
     const Layout& L = get_layout(p, n);
     if (ws_bytes < L.total) {
@@ -1386,10 +1412,8 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
         // first call with this signature: run once eagerly (sets function attributes, validates), then capture
         int rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, false);
         if (rc) return rc;
-        if (p->graphs.size() + (per_chain ? S : 1) > 64) {       // bound the cache (a pipeline of forwards holds one entry per slot and output set)
-            for (auto& kv : p->graphs) (void)hipGraphExecDestroy(kv.second);
-            p->graphs.clear();
-        }
+        if (p->graphs.size() + (per_chain ? S : 1) > 64)         // bound the cache (a pipeline of forwards holds one entry per slot and output set)
+            drop_graphs(p);                                      // (drains the device first: other slots may be replaying these executables)
         for (int k = 0; k < (per_chain ? S : 1); ++k) {
             GraphKey kk = key;
             kk.chain = per_chain ? k : -1;

@@ -6,7 +6,10 @@
 
 `head_outputs` = {'cls_logits': [N, A, K], 'bbox_regression': [N, A, 4]} fp32 CUDA tensors (e.g. `SSD.forward_heads`), `anchors`
 = [A, 4] (or the reference's list of N identical [A, 4] tensors), `targets` = list of {'boxes': [G, 4], 'labels': [G] int64}.
-Same error behaviour as the reference where it has one: degenerate boxes raise ValueError (generalized_ssd.py:300-308)."""
+Same error behaviour as the reference where it has one: degenerate boxes raise ValueError (generalized_ssd.py:300-308).
+Tie order: the reference ranks the negatives with two (unstable) sorts; only the SUM of the selected losses enters the result, which
+does not depend on the order of equal values -- except in the corner where more negatives are wanted than exist (the -inf entries of
+the foreground anchors enter the ranking): there csrc/loss.hip follows the stable-sort order, as torch's CPU sort happens to."""
 import ctypes as C
 from typing import Dict, List, Tuple
 
@@ -24,8 +27,15 @@ def ssd_loss(head_outputs: Dict[str, Tensor], anchors, targets: List[Dict[str, T
     if isinstance(anchors, (list, tuple)):
         anchors = anchors[0]
     n, A, K = logits.shape
+    if n == 0:
+        raise ValueError("ssd_loss: empty batch")
     if reg.shape != (n, A, 4) or anchors.shape != (A, 4) or len(targets) != n:
         raise ValueError("ssd_loss: inconsistent shapes")
+    GMAX = 256                                  # csrc/loss.hip: ground-truth boxes per image the matcher keeps in LDS
+    for ti, t in enumerate(targets):
+        if int(t["boxes"].shape[0]) > GMAX:
+            raise ValueError("ssd_loss: {} ground-truth boxes for target at index {}; the matcher kernel holds at most {} per image".format(
+                int(t["boxes"].shape[0]), ti, GMAX))
     for ti, t in enumerate(targets):
         b = t["boxes"]
         if b.numel():

@@ -101,6 +101,10 @@ class ForwardPipeline:
             raise RuntimeError("the pipeline is closed")
         if self.model._handle != self._handle or self.model._plan_gen != self._gen:
             raise RuntimeError("the model's plan was rebuilt (weights changed / invalidate()): build a new ForwardPipeline")
+        if self.n % 64 == 0 and (self.model._weights_signature(), str(self.device)) != self.model._sig:
+            # in-place weight updates do not rebuild the plan by themselves (only the model's own forward re-checks the signature):
+            # looked at every 64th submit (~0.1 ms), so a pipeline never replays stale folded weights for long
+            raise RuntimeError("the model's weights changed since the plan was lowered: close this pipeline and build a new one")
         s = self.slots[self.n % self.depth]
         if tuple(images.shape) != tuple(s.images.shape):
             raise ValueError("expected a batch of shape {}, got {}".format(tuple(s.images.shape), tuple(images.shape)))

@@ -284,7 +284,12 @@ class SSD(nn.Module):
 
     def loss(self, images: Tensor, targets: List[Dict[str, Tensor]]) -> Dict[str, Tensor]:
         """Backbone + heads (forward_heads) -> compute_loss: the loss values a reference model in train mode would return for this
-        batch with the same (eval-mode, BN folded) weights. images: [N,3,H,W] at the network size."""
+        batch with the same (eval-mode, BN folded) weights. images: [N,3,H,W] AT THE NETWORK SIZE: the reference's transform also resizes
+        the target boxes with the images (transform.py:93-108), which this entry point does not do -- other sizes raise."""
+        W, H = self.graph.size
+        if tuple(images.shape[-2:]) != (H, W):
+            raise ValueError("SSD.loss: images of {}x{} but the network size is {}x{}; resize the images AND the target boxes first "
+                             "(the reference's transform does both, transform.py:93-108)".format(images.shape[-2], images.shape[-1], H, W))
         logits, reg = self.forward_heads(images)
         return self.compute_loss(targets, {"cls_logits": logits, "bbox_regression": reg})
 

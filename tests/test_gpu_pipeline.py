@@ -214,3 +214,41 @@ def test_set_chains_abi():
     assert L.dn_set_chains(h, 5) != 0 and b"dn_set_chains" in L.dn_last_error()
     assert L.dn_set_chains(h, 0) == 0 and L.dn_batch_split(h, 64) == 2 and L.dn_workspace_bytes(h, 64) == ws2
     m._bufs = {}
+
+
+@pytest.mark.parametrize("se_small", ["1", "0"])
+def test_stress_forwards_in_flight_are_bit_identical_to_serial(se_small, monkeypatch):
+    """>= 500 forwards at depths 2 - 4, batch 32 and 64, every result compared bit for bit with the serial forward
+    of the same batch. The comparisons are enqueued on the device (no host wait between submits), so the chip stays shared by `depth`
+    forwards the whole time -- the regime in which a cross-workgroup hand-over (the squeeze-excitation FCs in the last workgroup of the
+    pooling depthwise launch, DN_SE_SMALL=1: depthwise.hip dw_se_tail) or any timing-dependent kernel would show. DN_SE_SMALL=0 runs the
+    same load with the FCs folded into the projection (no hand-over) as the control."""
+    monkeypatch.setenv("DN_SE_SMALL", se_small)
+    m = _model()
+    total = 0
+    for n, depth, count in [(32, 2, 90), (32, 3, 90), (32, 4, 90), (64, 2, 90), (64, 3, 100), (64, 4, 90)] if se_small == "1" else [(32, 3, 60), (64, 3, 60)]:
+        batches = _batches(m.graph, 6, n, seed=90)
+        with ForwardPipeline(m, n, depth=depth) as pipe:
+            ref = [[t.clone() for t in m.forward_batch(b)] for b in batches]
+            torch.cuda.synchronize()
+            flags = torch.zeros(count, dtype=torch.int32, device="cuda")
+            base = pipe.n
+
+            def check(j):
+                pipe.wait(base + j)                           # stream-ordered, no host wait
+                s = pipe.slots[(base + j) % depth]
+                r = ref[j % len(batches)]
+                ne = (s.boxes != r[0]).any() | (s.scores != r[1]).any() | (s.labels != r[2]).any() | (s.counts != r[3]).any()
+                flags[j] = ne.to(torch.int32)
+
+            for k in range(count):
+                pipe.submit(batches[k % len(batches)])
+                if k - (depth - 1) >= 0:
+                    check(k - (depth - 1))                    # as late as the contract allows: the next submit overwrites that slot
+            for j in range(max(0, count - depth + 1), count):
+                check(j)
+            torch.cuda.synchronize()
+            bad = torch.nonzero(flags).flatten().tolist()
+            assert not bad, f"batch {n}, {depth} in flight, DN_SE_SMALL={se_small}: forwards {bad[:10]} of {count} differ from their serial forward"
+            total += count
+    assert total >= (500 if se_small == "1" else 100)
