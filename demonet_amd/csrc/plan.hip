@@ -635,6 +635,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             }
         }
     }
+    p->graph_mode = dn_knob("DN_GRAPH", 1) != 0;      // DN_GRAPH=0: plain launches (diagnostics)
     p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
     p->xcd = getenv("DN_XCD") ? atoi(getenv("DN_XCD")) != 0 : true;
     p->chain_graphs = dn_knob("DN_CHAIN_GRAPHS", -1);      // -1: auto (forward_impl)

@@ -68,6 +68,14 @@ with ForwardPipeline(m, n, depth=depth) as pipe:
                             print("      sum of rows serial   ", [round(float(B[ii, :, c].sum()), 3) for c in ch[:8]])
                             print("      sum of dw output     ", [round(float(outp[ii, c]), 3) for c in ch[:8]])
                             print("      row value pipelined / serial", [(round(float(A[ii, rr, c]), 3), round(float(B[ii, rr, c]), 3)) for c in ch[:8]])
+                            print("      differing channels:", len(ch), "of", t.c, " components (c % 8):", sorted(set(c % 8 for c in ch)), " max |d|", float((A[ii, rr] - B[ii, rr]).abs().max()))
+                            # is the pipelined row STALE, i.e. equal to what another batch leaves at this position (the slot's previous forward)?
+                            for jb in range(len(ref)):
+                                if jb != j and tid in ref[jb][1]:
+                                    O = ref[jb][1][tid].view(a16.dtype).view(n, rows, t.c)
+                                    same = int((A[ii, rr] == O[ii, rr]).sum())
+                                    samech = int((A[ii, rr][ch] == O[ii, rr][ch]).sum())
+                                    print(f"         vs serial batch {jb}: {same} of {t.c} channels equal, {samech} of the {len(ch)} differing ones")
                     for (ii, rr) in nz.tolist()[:0]:
                         print("      pipelined", A[ii, rr, :6].tolist(), "\n      serial   ", B[ii, rr, :6].tolist(), " channels differing", int((A[ii, rr] != B[ii, rr]).sum()))
             found = True
