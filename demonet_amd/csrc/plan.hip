@@ -264,6 +264,8 @@ static const Layout& get_layout(dn_plan* p, int n) {
                 if (lv >= 0 && lv < p->head_early && born[o.out] >= 0) born[o.out] = std::min(born[o.out], when[p->head_fork_op]);
             }
         const int t_end = NO + 2;
+        if (const int slack = dn_knob("DN_WS_SLACK", 0))        // diagnostics: every block stays reserved `slack` launches beyond its last reader
+            for (size_t t = 0; t < T; ++t) if (dies[t] >= 0) dies[t] += slack;
         for (int l = 0; l < p->d.n_levels; ++l) dies[p->d.level_tensor[l]] = t_end;      // read back by tests / callers after the forward
         struct Blk { size_t off, bytes; int born, dies; };
         std::vector<Blk> placed;
