@@ -185,6 +185,7 @@ struct DwArgs {
     float* se_scale = nullptr; unsigned* se_counter = nullptr;
     int se_sq = 0; float se_inv = 0.f;                                 // squeeze width, 1 / pooled pixels
     float* dbg = nullptr;                                              // dev-only (dn_debug_dw_table)
+    int pool_rows = 0;                                                 // rows per image the plan sized `pool` for (0: the launcher's own choice)
 };
 bool depthwise_se_tail_supported(int c, int squeeze);
 int launch_depthwise(const DwArgs& a, hipStream_t s);

@@ -561,6 +561,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             const dn_tensor_desc& to = p->tensors[o.out];
             DwArgs a{};
             a.n = 1; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.ho = to.h; a.wo = to.w;
+            a.pool = reinterpret_cast<float*>(1);      // (geometry only: a pooling launch)
             p->pool_blocks[o.pool] = depthwise_pool_blocks(a);
         }
     }
@@ -880,6 +881,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.n = n; a.h = ti.h; a.w_ = ti.w; a.c = o.cin; a.k = o.k; a.stride = o.stride; a.pad = o.pad; a.act = o.act;
         a.ho = to.h; a.wo = to.w;
         a.pool = o.pool >= 0 ? reinterpret_cast<float*>(tptr(o.pool)) : nullptr;
+        a.pool_rows = o.pool >= 0 ? p->pool_blocks[o.pool] : 0;
         a.xq = xq;
         const int oi = (int)(&o - p->ops.data());
         if (oi >= 0 && oi < (int)p->ops.size() && p->se_in_dw[oi] >= 0) {
