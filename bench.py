@@ -166,8 +166,63 @@ def cpu_baseline(name, graph, seed, budget_s=24.0):
             "variants": variants}
 
 
-def main():
+class _StubGraph:
+    """--stub-cpu: the shapes bench.py needs from a model graph"""
+    size = (320, 320)
+    post = {"detections_per_img": 300, "topk_candidates": 300}
+    nodes = ()
+
+
+class _StubPipe:
+    """--stub-cpu: stands in for demonet_amd.pipeline.ForwardPipeline on a box without a GPU (tests/test_dist_cpu.py runs main() with it at
+    world size 2 over gloo, so the C4 path -- sharding, forwards in flight feeding the windowed gather, flush, barriers, MAX over ranks --
+    is EXECUTED on CPU, not only its arithmetic). A 'forward' writes a payload that depends on the rank, the step and the shard."""
+
+    def __init__(self, batch, dets, depth, rank, lo):
+        self.B, self.D, self.depth, self.rank, self.lo, self.n = batch, dets, depth, rank, lo, 0
+        self.bufs = [torch.zeros(batch, dets + 1, 6) for _ in range(depth)]
+        self.joins = 0
+
+    @staticmethod
+    def payload(batch, dets, lo, step):
+        p = torch.zeros(batch, dets + 1, 6)
+        img = torch.arange(lo, lo + batch, dtype=torch.float32)
+        p[:, :dets, 4] = (img[:, None] + 1) / 1024.0 + step              # scores encode (global image index, step)
+        p[:, :dets, 5] = 1.0
+        p[:, dets, 0] = (img % 7) + 1                                    # counts
+        return p
+
+    def submit(self, images, persistent_input=False):
+        t = self.n
+        self.bufs[t % self.depth].copy_(self.payload(self.B, self.D, self.lo, t))
+        self.n += 1
+        return t
+
+    def packed(self, t):
+        return self.bufs[t % self.depth]
+
+    def stream_of(self, t):
+        return None
+
+    def join(self):
+        self.joins += 1
+
+    def result(self, t):
+        p = self.bufs[t % self.depth]
+        return p[:, :self.D, :4], p[:, :self.D, 4], p[:, :self.D, 5].long(), p[:, self.D, 0].int()
+
+    def close(self):
+        pass
+
+
+def _on(stream):
+    import contextlib
+    return contextlib.nullcontext() if stream is None else torch.cuda.stream(stream)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # CPU / gloo run of the multi-rank control path with a stub forward (tests)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -189,27 +244,36 @@ def main():
                     "images up). The PMC passes of tools/round_profile.sh use --eager --chains 1: the kernels at the launch size of the timed region")
     ap.add_argument("--no-latency", action="store_true", help="skip the per-step latency percentiles / D2H-inclusive step time (extra passes after the timed region)")
     ap.add_argument("--per-op", default="", help="write a per-op table (time, GB/s, TFLOP/s) to this file")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    stub = args.stub_cpu
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
     distributed = world > 1 or os.environ.get("DN_BENCH_FORCE_DIST") == "1"     # (the latter: 1-GPU smoke test of the RCCL path)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = lambda: torch.cuda.synchronize(dev)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")       # (only matters for the 1-GPU DN_BENCH_FORCE_DIST run; torchrun sets all of these)
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if stub:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from demonet_amd import models, synth
     from demonet_amd.dist import DetectionGatherer
     ncls = 21 if args.model == "ssd_lite_mobilenet_v2" else 91
     fkw = {"image_size": args.image_size} if (args.image_size and args.model == "ssd_lite_mobilenet_v2") else {}
-    model = models.load_synthetic(getattr(models, args.model)(num_classes=ncls, **fkw), 0)
+    model = None if stub else models.load_synthetic(getattr(models, args.model)(num_classes=ncls, **fkw), 0)
     if args.weights == "worstcase":
         sd = {k: torch.from_numpy(v.copy()) for k, v in synth.state_dict(model.graph, 0).items()}
         for k in sd:
@@ -217,21 +281,26 @@ def main():
             if "classification_head" in k and last:
                 sd[k] = sd[k] * 0.01          # near-uniform softmax: 1/K > score_thresh for every (anchor, class)
         model.load_state_dict(sd, strict=True)
-    model = model.to(dev)
-    g = model.graph
+    if not stub:
+        model = model.to(dev)
+    g = _StubGraph() if stub else model.graph
     W, H = g.size
+    lo = 0
     if args.batch > 0:
         B, scaling = args.batch, "weak"
     elif world > 1:
         # BASELINE configs[3] (C4): global batch 256 image-sharded over the node, 256 / N contiguous images per rank
         # (dist.shard_range; the reference launches one process per GPU the same way: util/misc.py:302-324)
         from demonet_amd.dist import shard_range
+        shard_lo = [shard_range(C4_GLOBAL_BATCH - C4_GLOBAL_BATCH % world, r, world)[0] for r in range(world)]
         lo, hi = shard_range(C4_GLOBAL_BATCH - C4_GLOBAL_BATCH % world, rank, world)      # equal shards (the gather is fixed-shape)
         B, scaling = hi - lo, "strong"
     else:
         B, scaling = DEFAULT_BATCH, "weak"
-    images = torch.from_numpy(synth.images(1002 + rank, B, H, W)).to(dev)      # device-resident input (engine.py:86)
-    if args.eager:
+    if scaling == "weak":
+        lo = rank * B
+    images = torch.zeros(1) if stub else torch.from_numpy(synth.images(1002 + rank, B, H, W)).to(dev)      # device-resident input (engine.py:86)
+    if args.eager and not stub:
         model.set_graph_mode(False)
     to_u8 = lambda x: (x * 255).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
     images_u8 = to_u8(images) if args.input == "u8" else None
@@ -244,7 +313,10 @@ def main():
     if R == 1 and args.chains > 0:
         from demonet_amd import _lib as _l
         _l.check(_l.lib().dn_set_chains(C.c_void_p(model._plan(dev)), args.chains))
-    if R > 1:
+    if stub:
+        pipe = _StubPipe(B, g.post["detections_per_img"], R, rank, lo)
+        batches = [images] * R
+    elif R > 1:
         # the serving form: R forwards in flight, each a single whole-batch chain (demonet_amd/pipeline.py); one device-resident
         # synthetic batch per slot (slot 0 holds the batch of the one-at-a-time mode)
         from demonet_amd.pipeline import ForwardPipeline
@@ -253,6 +325,7 @@ def main():
         if images_u8 is not None:
             batches = [images_u8] + [to_u8(x) for x in batches[1:]]
     nstep = [0]
+    last_ticket = [-1]
 
     def step():
         if pipe is not None:
@@ -262,8 +335,8 @@ def main():
             if distributed:
                 # the merge kernel writes the gather payload itself; it is staged per step (on the forward's own stream) and
                 # all-gathered per window of steps
-                with torch.cuda.stream(pipe.stream_of(t)):
-                    gatherer.submit(src=pipe.packed(t), join=pipe.join)
+                with _on(pipe.stream_of(t)):
+                    last_ticket[0] = gatherer.submit(src=pipe.packed(t), join=pipe.join)
             return t
         if distributed:
             boxes, scores, labels, counts = model.forward_batch(images, persistent_input=True, packed=gatherer.next_buffer())
@@ -276,23 +349,23 @@ def main():
 
     for _ in range(max(args.warmup, 2 * R)):
         step()
-    torch.cuda.synchronize(dev)
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         counts = step()
     if distributed:
         if pipe is not None:
-            with torch.cuda.stream(pipe.stream_of(counts)):
+            with _on(pipe.stream_of(counts)):
                 gatherer.flush(join=pipe.join)
         else:
             gatherer.flush()
-    torch.cuda.synchronize(dev)
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     dt = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -300,6 +373,23 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt          # whole-job aggregate: every rank processed B images per step
+    if stub:
+        # what the last step's gather holds on every rank: the global batch in image order, every rank's shard where shard_range put it
+        total_steps = max(args.warmup, 2 * R) + args.steps
+        pk, cn = gatherer.result(last_ticket[0])
+        D = g.post["detections_per_img"]
+        per = pk.shape[0] // world
+        ok = pk.shape[0] == world * B
+        for r in range(world):
+            want = _StubPipe.payload(B, D, r * B if scaling == "weak" else shard_lo[r], total_steps - 1)
+            ok = ok and torch.equal(pk[r * per:(r + 1) * per], want[:, :D]) and torch.equal(cn[r * per:(r + 1) * per], want[:, D, 0].int())
+        result = {"metric": "stub", "value": round(value, 1), "n_gpus": world, "steps": args.steps, "ms_per_step": round(ms_per_step, 4), "scaling": scaling,
+                  "global_batch": B * world, "per_rank_batch": B, "shard": [lo, lo + B], "gather_windows": gatherer.gathered // gatherer.K,
+                  "joins": pipe.joins, "stub_check": bool(ok)}
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        return result
     if pipe is not None:
         counts = pipe.result(counts)[3]
         chains_timed = 1
@@ -553,6 +643,7 @@ def main():
         C.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+    return result
 
 
 if __name__ == "__main__":

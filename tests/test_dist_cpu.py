@@ -97,3 +97,35 @@ def test_gather_detections_gloo_world2():
 def test_shard_range():
     assert [shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]       # 32 images per GPU
     assert shard_range(10, 3, 4) == (9, 10) and shard_range(2, 3, 4) == (2, 2)     # ragged / empty shards
+
+
+def _bench_worker(rank, world, port, ret, extra):
+    import importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ret[rank] = bench.main(["--gpus", str(world), "--steps", "37", "--warmup", "5", "--stub-cpu"] + extra)
+
+
+def test_bench_main_c4_path_runs_at_world2_on_cpu():
+    """bench.py's OWN main() at world size 2 over gloo with a stub forward (--stub-cpu): the code the driver launches for the scaling
+    curve -- C4 sharding of the global batch 256 (128 per rank here), forwards in flight feeding the windowed gather from their own
+    payload buffers, the flush of the last partial window inside the timed region, barriers, MAX over ranks, one JSON line from rank 0
+    -- is executed, and what the last step's gather holds on every rank is the global batch in image order (util/misc.py:75-115 and
+    engine.py:105 are the reference's counterparts). Also with --batch (weak scaling: the per-rank size fixed)."""
+    for extra, per, scaling in (([], 128, "strong"), (["--batch", "8"], 8, "weak")):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ret = mp.Manager().dict()
+        mp.spawn(_bench_worker, args=(2, port, ret, extra), nprocs=2, join=True)
+        assert len(ret) == 2
+        for r in (0, 1):
+            d = ret[r]
+            assert d["stub_check"] and d["n_gpus"] == 2 and d["per_rank_batch"] == per and d["scaling"] == scaling
+            assert d["shard"] == [r * per, (r + 1) * per] and d["global_batch"] == 2 * per
+            assert d["gather_windows"] == 3 and d["joins"] == 3          # 6 warm-up + 37 timed steps = two full windows of 16 + the flushed one
+        assert ret[0]["ms_per_step"] == ret[1]["ms_per_step"]            # MAX over ranks
