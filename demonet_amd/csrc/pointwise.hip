@@ -427,8 +427,38 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
         const bool pair_ok = ((NC | (int)(a.out_base & 1) | (int)(a.out_img_stride & 1)) & 1) == 0 &&
                              (reinterpret_cast<size_t>(outp) & 7) == 0;       // every row start 8-byte aligned
         constexpr int PPR = BC / 2;                     // float2 per tile row
-        // image of a row without a division per element: a tile of BP consecutive rows spans at most two images when hw >= BP
         const int img0 = m0 / a.hw, rem0 = m0 - img0 * a.hw;
+        constexpr int RG = 256 / PPR;                   // row groups: thread (rg, j) owns column pair j of rows rg, rg + RG, ...
+        if (a.hw >= RG && RG >= 1) {
+            // Round 3 instruction diet: the element loop used to pay a division, the image wrap and a 64-bit address per float2 (~25 vector
+            // instructions each, ~600 per thread and tile); with a fixed column pair per thread the row walks by increments.
+            const int rg = tid / PPR, j = tid - rg * PPR;
+            const int n = n0 + 2 * j;
+            if (rg < RG && n < NC) {
+                int row = rg;
+                int pix = rem0 + rg, img = img0;
+                while (pix >= a.hw) { pix -= a.hw; ++img; }
+                float* o = outp + (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)pix * NC + n;
+                const long wrap = a.out_img_stride - (long)a.hw * NC;
+                const bool two_ok = pair_ok && n + 1 < NC;
+                const float* src = &ot[row * FROW + 2 * j];
+                for (; row < BP && m0 + row < M; row += RG) {
+                    const float2 v = *reinterpret_cast<const float2*>(src);
+                    if (two_ok) {
+                        *reinterpret_cast<float2*>(o) = v;
+                    } else {
+                        o[0] = v.x;
+                        if (n + 1 < NC) o[1] = v.y;
+                    }
+                    src += RG * FROW;
+                    o += (size_t)RG * NC;
+                    pix += RG;
+                    if (pix >= a.hw) { pix -= a.hw; o += wrap; }      // (hw >= RG: at most one image boundary per step)
+                }
+            }
+            PW_STAMP(3);
+            return;
+        }
         const bool two = a.hw >= BP;
 #pragma unroll 4
         for (int c = tid; c < BP * PPR; c += 256) {
