@@ -178,6 +178,7 @@ struct DwArgs {
     float* pool = nullptr;      // optional: [n][blocks][c] fp32 per-workgroup sums of the outputs (SE squeeze)
     int xq = 0;                 // XCD grouping: images per group (0: plain mapping)
     FastDiv fd_c8{1, 0}, fd_xs{1, 0};      // filled by the launcher: divisions by c / 8 and by the x strips per row
+    int rb_log2 = 0; FastDiv fd_rbxs{1, 0};   // row blocks (depthwise.hip dw_body): log2 of the rows per block, division by strips * rows per block
     // squeeze-excitation FCs in the tail of the pooling launch (depthwise.hip, dw_se_tail): the workgroup of an image that finishes
     // last turns the partial sums into scale[n][c]. se_counter: one zero-initialised unsigned per image, left at zero again.
     const half_t* se_w1t = nullptr; const float* se_b1 = nullptr;      // fc1 transposed [c][sq] fp16, bias [sq]

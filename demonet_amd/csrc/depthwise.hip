@@ -95,6 +95,71 @@ __device__ __forceinline__ void dw_se_tail(const DwArgs& a, const int n, const i
     fc(a.se_w2t, a.se_b2, z, sq, c, a.se_scale + (size_t)n * c, true);
 }
 
+// The same for the SMALL squeeze-excitations (c <= 128, squeeze <= 32, <= 32 partial rows: the 40 x 40 blocks) with every global load of
+// the tail -- the partial rows, both FC weight slices of this thread, the biases -- requested TOGETHER right after the ticket: the tail
+// is the exposed end of its launch (it starts when the image's other workgroups are done), and the phase-by-phase form above made
+// four dependent memory round trips of it (~10 us per launch, three launches per chain). Same sums in the same order: bit-identical.
+__device__ __forceinline__ void dw_se_tail_small(const DwArgs& a, const int n, const int nblk, float* sh) {
+    const int c = a.c, sq = a.se_sq, tid = threadIdx.x;
+    float* mean = sh;               // [c]
+    float* z = sh + c;              // [sq]
+    float* part = z + sq;           // [256][8]
+    // thread = (8-output group og, K slice ks) of each FC, as in dw_se_tail::fc; at these sizes a slice is at most two rows
+    const int OG1 = (sq + 7) >> 3, OG2 = (c + 7) >> 3;
+    int ogp1 = 1, ogp2 = 1;
+    while (ogp1 < OG1) ogp1 <<= 1;
+    while (ogp2 < OG2) ogp2 <<= 1;
+    const int KS1 = 256 / ogp1, KS2 = 256 / ogp2;
+    const int og1 = tid & (ogp1 - 1), ks1 = tid / ogp1, per1 = (c + KS1 - 1) / KS1, i0 = ks1 * per1, i1 = min(c, i0 + per1);
+    const int og2 = tid & (ogp2 - 1), ks2 = tid / ogp2, per2 = (sq + KS2 - 1) / KS2, j0 = ks2 * per2, j1 = min(sq, j0 + per2);
+    const bool act1 = og1 < OG1 && i0 < i1, act2 = og2 < OG2 && j0 < j1;
+    float pv[32];
+    {
+        const float* p0 = a.pool + (size_t)n * nblk * c + min(tid, c - 1);
+#pragma unroll
+        for (int b = 0; b < 32; ++b) pv[b] = __hip_atomic_load(&p0[(size_t)min(b, nblk - 1) * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint4 w1[2], w2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        w1[u] = *reinterpret_cast<const uint4*>(a.se_w1t + (size_t)min(i0 + u, c - 1) * sq + min(og1, OG1 - 1) * 8);
+        w2[u] = *reinterpret_cast<const uint4*>(a.se_w2t + (size_t)min(j0 + u, sq - 1) * c + min(og2, OG2 - 1) * 8);
+    }
+    const float b1v = a.se_b1[min(tid, sq - 1)], b2v = a.se_b2[min(tid, c - 1)];
+    if (tid < c) {
+        float t = 0.f;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) t += (b < nblk) ? pv[b] : 0.f;
+        mean[tid] = t * a.se_inv;
+    }
+    __syncthreads();
+    auto fc = [&](const uint4 (&w)[2], bool act, int r0, int r1, const float* in, int ogp, int KS, int nout, float bias, float* out, bool hsig) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float m = (r0 + u < r1) ? in[r0 + u] : 0.f;
+                const half8 h = *reinterpret_cast<const half8*>(&w[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] * m;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[tid * 8 + e] = acc[e];
+        __syncthreads();
+        if (tid < nout) {
+            float t = bias;
+            const int g = tid >> 3, e = tid & 7;
+            for (int q = 0; q < KS; ++q) t += part[(q * ogp + g) * 8 + e];
+            out[tid] = hsig ? fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f) : fmaxf(t, 0.f);
+        }
+        __syncthreads();
+    };
+    fc(w1, act1, i0, i1, mean, ogp1, KS1, sq, b1v, z, false);
+    fc(w2, act2, j0, j1, z, ogp2, KS2, c, b2v, a.se_scale + (size_t)n * c, true);
+}
+__device__ __forceinline__ bool dw_se_tail_is_small(int c, int sq, int nblk) { return c <= 128 && sq <= 32 && nblk <= 32; }
+
 // POOL: 0 = none, 1 = per-workgroup channel sums for the squeeze-excitation, 2 = sums + the FCs in the image's last workgroup
 //   (dw_se_tail: its 16-row load batches need 114 registers, which capped EVERY pooling launch while the code was compiled into all of them).
 // MODE bit 0: one kernel row of loads at a time instead of the batched rows (DN_DW_ROWS; see RP below); bit 1: debug dump (dn_debug_dw_table).
@@ -106,8 +171,18 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     const unsigned idx0 = bx * 256 + threadIdx.x;
     const unsigned q1 = fd_div(idx0, a.fd_c8);
     const unsigned cg = idx0 - q1 * C8;
-    const unsigned oy = fd_div(q1, a.fd_xs);
-    const unsigned xs = q1 - oy * a.fd_xs.d;
+    // strip position q1 -> (output row, strip). Plain: row-major. Row blocks (rb_log2 > 0, DN_DW_RB): q1 walks down RB rows before it moves
+    // to the next strip, so the ~256 / C8 strip positions of a workgroup form a RB-row block whose input rows overlap -- the K-fold
+    // vertical re-read of every input row is then served by the CU's own L1 instead of L2.
+    unsigned oy, xs;
+    if (a.rb_log2 == 0) {
+        oy = fd_div(q1, a.fd_xs);
+        xs = q1 - oy * a.fd_xs.d;
+    } else {
+        const unsigned blk = fd_div(q1, a.fd_rbxs), within = q1 - blk * a.fd_rbxs.d;
+        xs = within >> a.rb_log2;
+        oy = (blk << a.rb_log2) + (within & ((1u << a.rb_log2) - 1u));
+    }
     const bool valid = (int)oy < a.ho;
     if (!valid && POOL == 0) return;
     const int ox0 = xs * TW;
@@ -134,6 +209,35 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     constexpr int RP = (MODE & 1) ? 1 : ((K == 3) ? 3 : 2);
     const half_t* const wbase = a.w + c0;
     const half_t* const xbase = a.x + (size_t)n * a.h * a.w_ * a.c + c0;
+    if constexpr ((MODE & 4) != 0) {
+        // Software-pipelined rows (MODE bit 2, DN_DW_PIPE): two register sets; row ky + 1 is requested BEFORE the multiply-adds of row ky
+        // are issued, so only the first row's round trip is exposed (the batched form exposes ceil(K / RP) of them: three for 5x5).
+        half8 wv[2][K];
+        half8 xin[2][NIN];
+        auto load_row = [&](const int ky, const int buf) {
+            const int iy = (int)oy * S - a.pad + ky;
+            const bool yok = iy >= 0 && iy < a.h;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) wv[buf][kx] = *reinterpret_cast<const half8*>(wbase + (unsigned)((ky * K + kx) * a.c));
+            const half_t* rowp = xbase + (unsigned)((yok ? iy : 0) * a.w_ * a.c);
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const int ix = ix0 + i;
+                const bool ok = yok && ix >= 0 && ix < a.w_;
+                xin[buf][i] = *(ok ? (gp8)(rowp + (unsigned)(ix * a.c)) : zero);
+            }
+        };
+        load_row(0, 0);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            if (ky + 1 < K) load_row(ky + 1, (ky + 1) & 1);
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+                    fma_mix_h8(acc[t], *reinterpret_cast<const uint4*>(&xin[ky & 1][t * S + kx]), *reinterpret_cast<const uint4*>(&wv[ky & 1][kx]));
+        }
+    } else {
 #pragma unroll
     for (int ky0 = 0; ky0 < K; ky0 += RP) {
         half8 wv[RP][K];
@@ -163,6 +267,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
                 for (int kx = 0; kx < K; ++kx)
                     fma_mix_h8(acc[t], *reinterpret_cast<const uint4*>(&xin[rr][t * S + kx]), *reinterpret_cast<const uint4*>(&wv[rr][kx]));
         }
+    }
     }
     half_t* orow = a.out + ((size_t)(n * a.ho + oy) * a.wo) * a.c + c0;
 #pragma unroll
@@ -234,7 +339,8 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
                 s_last = __hip_atomic_fetch_add(&a.se_counter[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1);
             __syncthreads();
             if (s_last) {
-                dw_se_tail(a, n, nblocks, red);
+                if (dw_se_tail_is_small(a.c, a.se_sq, nblocks)) dw_se_tail_small(a, n, nblocks, red);
+                else dw_se_tail(a, n, nblocks, red);
                 if (threadIdx.x == 0) a.se_counter[n] = 0u;
             }
         }
@@ -242,7 +348,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
 }
 
 template <int K, int S, int TW, int POOL, int MODE>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs a, int nblocks) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 4) ? 3 : 1))) void dw_kernel(DwArgs a, int nblocks) {
     int img, bx;
     if (!xcd_image_of2(a.xq, a.n, img, bx)) return;
     dw_body<K, S, TW, POOL, MODE>(a, bx, nblocks, img);
@@ -401,7 +507,8 @@ __global__ __launch_bounds__(256) void dwl_kernel(DwArgs a, int tiles_x, int til
                 s_last = __hip_atomic_fetch_add(&a.se_counter[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(tiles * chunks - 1);
             __syncthreads();
             if (s_last) {
-                dw_se_tail(a, n, tiles, reinterpret_cast<float*>(dwl_lds));
+                if (dw_se_tail_is_small(a.c, a.se_sq, tiles)) dw_se_tail_small(a, n, tiles, reinterpret_cast<float*>(dwl_lds));
+                else dw_se_tail(a, n, tiles, reinterpret_cast<float*>(dwl_lds));
                 if (tid == 0) a.se_counter[n] = 0u;
             }
         }
@@ -483,8 +590,14 @@ bool dw_fill(DwArgs& a) {
     const unsigned c8 = a.c / 8, xs = (a.wo + TW - 1) / TW;
     a.fd_c8 = fastdiv(c8);
     a.fd_xs = fastdiv(xs);
+    // row blocks: the largest power of two <= DN_DW_RB that divides the output height (the thread count, and with it the number of
+    // pooled partial rows the plan sized, stays what it is)
+    int rb = 0;
+    for (int want = dn_knob("DN_DW_RB", 1); (2 << rb) <= want && a.ho % (2 << rb) == 0; ) ++rb;
+    a.rb_log2 = rb;
+    a.fd_rbxs = fastdiv(xs << rb);
     const unsigned long long threads = (unsigned long long)a.ho * xs * c8 + 256;
-    return fd_ok(threads, c8) && fd_ok(threads / c8 + 1, xs) && (unsigned long long)a.h * a.w_ * a.c < 0x80000000ull;
+    return fd_ok(threads, c8) && fd_ok(threads / c8 + 1, xs << rb) && (unsigned long long)a.h * a.w_ * a.c < 0x80000000ull;
 }
 
 template <int K, int S, int TW>
@@ -524,6 +637,7 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
     const int cls = a.pool ? (a.se_scale ? 4 : 2) : 1;
     const int kf = dn_knob("DN_DW_K", 0);
     const bool rows1 = (dn_knob("DN_DW_ROWS", 0) & cls) != 0 && (kf == 0 || kf == K);
+    const bool pipe = !rows1 && K == 5 && (dn_knob("DN_DW_PIPE", 7) & cls) != 0;      // software-pipelined rows (5x5 only: 3x3 already takes its three rows in one round trip); default on (round 3: 29 -> 25.7 us per 40 x 40 launch, stress-tested)
     const size_t lds = a.pool ? pool_lds : 0;
     if (a.pool && g_dw_dbg_count > 0) {
         for (int i = 0; i < g_dw_dbg_count; ++i)
@@ -536,6 +650,14 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
             else hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 2>), grid, dim3(256), lds, s, a, nblocks);
         }
         return DN_OK;
+    }
+    if constexpr (K == 5) {
+        if (pipe) {
+            if (a.pool && a.se_scale) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 4>), grid, dim3(256), lds, s, a, nblocks);
+            else if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 4>), grid, dim3(256), lds, s, a, nblocks);
+            else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 4>), grid, dim3(256), lds, s, a, nblocks);
+            return DN_OK;
+        }
     }
     if (a.pool && a.se_scale) {
         if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 1>), grid, dim3(256), lds, s, a, nblocks);
