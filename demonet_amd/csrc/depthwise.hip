@@ -698,13 +698,15 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ p
     const int tid = threadIdx.x;
     SE_STAMP(0);
     const int sq2 = sq >> 1, c2 = c >> 1;
-    const int JP = (sq2 + 63) & ~63;                  // fc1: output pair j, slice r1 of the c inputs
+    // (round 3: exact, not wave-rounded, pair counts -- 84 pairs give 12 K slices of 56 rows where 128 gave 8 of 84: the 672-channel
+    // blocks walk their slices in two batches of loads per FC instead of three)
+    const int JP = sq2;                               // fc1: output pair j, slice r1 of the c inputs
     const int KS1 = 1024 / JP;
     const int j = tid % JP, r1 = tid / JP;
     const int per1 = (c + KS1 - 1) / KS1;
     const int i0 = r1 * per1, i1 = min(c, i0 + per1);
     const bool act1 = j < sq2 && r1 < KS1;
-    const int CP = (c2 + 63) & ~63;                   // fc2: output pair i, slice r2 of the sq inputs
+    const int CP = c2;                                // fc2: output pair i, slice r2 of the sq inputs
     const int KS2 = max(1, 1024 / CP);
     const int i = tid % CP, r2 = tid / CP;
     const int per2 = (sq + KS2 - 1) / KS2;
