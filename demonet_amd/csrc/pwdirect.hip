@@ -14,10 +14,12 @@
 //   * the bias rides in the reduction: two extra K columns hold (1, 1) on the pixel side and (hi, lo) = the fp32 bias split into
 //     two fp16 values on the weight side (|b - hi - lo| <= 2^-22 |b|), so the accumulator starts life as conv + bias;
 //   * the activation is ONE uniform switch per 16-value accumulator, not a select per element;
-//   * v_permlane32_swap turns the accumulator layout (4 channels per lane and register group) into 16 contiguous channels per
-//     lane: the tile leaves as two 16-byte stores per lane, 64 contiguous bytes per pixel, without an LDS transpose.
+//   * v_permlane32_swap turns the accumulator layout (4 channels per lane and register group) into 8-channel runs: the tile leaves as
+//     two 16-byte stores per lane, each instruction writing 32 contiguous bytes per pixel, without an LDS transpose.
 // The residual (fp16, NHWC) is requested up front in the accumulator layout and added in fp32 before the single rounding
 // (mobilenetv3.py:97-99 computes act(conv + bias) + x).
+#include <algorithm>
+
 #include "common.h"
 
 __device__ const uint4 g_pwdw_zero16 = {0u, 0u, 0u, 0u};      // what a tap outside the image reads
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
     for (int i = 0; i < TC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xl, acc[i], 0, 0, 0);
 
     // ---- epilogue: lane = pixel r; registers 4g .. 4g+3 of tile i = channels n_base + 32 i + 8g + 4hh .. +3
-    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 16;
+    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 8;
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int nt = n_base + i * 32;
@@ -194,19 +196,142 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
         // 0..15 and lane r + 32 with channels 16..31 of the tile (v_permlane32_swap: upper half of the first operand <-> lower half of the second)
         uint4 lo4, hi4;
         {
-            const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[2][0], false, false);
-            const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[2][1], false, false);
-            const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[1][0], p[3][0], false, false);
-            const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[1][1], p[3][1], false, false);
+            // (round 3: groups (0, 1) and (2, 3) are paired, so that lane r ends up with channels 0..7 / 16..23 and lane r + 32 with 8..15 /
+            // 24..31: each store instruction then writes 32 CONTIGUOUS bytes per pixel -- whole sectors -- instead of two 16-byte pieces
+            // 32 bytes apart)
+            const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[1][0], false, false);
+            const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[1][1], false, false);
+            const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[2][0], p[3][0], false, false);
+            const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[2][1], p[3][1], false, false);
             lo4 = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             hi4 = make_uint4(s2[0], s3[0], s2[1], s3[1]);
         }
-        const int c0 = nt + hh * 16;
+        const int c0 = nt + hh * 8;
         if (row < mend) {
             if (c0 < NC) *reinterpret_cast<uint4*>(orow + nt) = lo4;
-            if (c0 + 8 < NC) *reinterpret_cast<uint4*>(orow + nt + 8) = hi4;
+            if (c0 + 16 < NC) *reinterpret_cast<uint4*>(orow + nt + 16) = hi4;
         }
     }
+}
+
+// Streaming variant for the WIDE expansions (round 3): 112 -> 672 and 80 -> 480 on the 20 x 20 maps. pw_direct_kernel<7, 2> needs 186
+// registers for "every operand of the wave up front" (2 waves per SIMD) and puts 8 800 waves through the chip in 4.3 rounds (24 us for a
+// 40 MB layer). Here a wave keeps its 32 pixel rows (the B fragments) for a RUN of channel tiles and streams the weight tiles through two
+// register sets: tile t + 1 is requested before the matrix instructions of tile t are issued, so after the first tile no round trip is
+// exposed, and 800 pixel tiles x 3 channel runs = 2 400 waves fit the chip at once (~150 registers, 3 waves per SIMD). The four waves of a
+// workgroup walk the same weight tiles at the same time (three of the four reads hit L1). Per-tile arithmetic, bias-in-the-reduction and
+// the permlane epilogue are pw_direct_kernel's: the outputs are bit-identical to it. No squeeze-excitation scale, no residual (the
+// expansions have neither).
+template <int KSF>
+__global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, int tiles, int tiles_per_run) {
+    constexpr int KSM = KSF > 0 ? KSF : 1;
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = a.cin, NC = a.cout;
+    int m0, mend, by;
+    {
+        const int flat = blockIdx.x;
+        if (a.xq > 0) {
+            const int g = flat & 7, w = flat >> 3;
+            by = w / tiles;
+            const int t = w - by * tiles;
+            const int r0 = g * a.xq * a.hw;
+            mend = min(a.m, r0 + a.xq * a.hw);
+            m0 = r0 + t * 128;
+        } else {
+            by = flat / tiles;
+            m0 = (flat - by * tiles) * 128;
+            mend = a.m;
+        }
+    }
+    const int mrow0 = m0 + wave * 32;
+    const int ctiles = (NC + 31) >> 5;
+    const int ct0 = by * tiles_per_run, ct1 = min(ctiles, ct0 + tiles_per_run);
+    if (mrow0 >= mend || ct0 >= ct1) return;               // wave-uniform
+    const int row = mrow0 + r;
+    const int rowc = min(row, mend - 1);
+    const half_t* xp = a.x + (size_t)rowc * K + hh * 8;
+    const int kb = KSF * 16 + hh * 8;
+    const int kcl = min(kb, K - 8) - hh * 8;
+    const bool data = kb < K, bcol = kb == K;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8 wf[2][KSM], wl[2];
+    float bl[2];
+    auto request = [&](const int ct, const int buf) {
+        const int nrow = min(ct * 32 + r, NC - 1);
+        const half_t* wp = a.w + (size_t)nrow * K + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) wf[buf][ks] = *reinterpret_cast<const half8*>(wp + ks * 16);
+        wl[buf] = *reinterpret_cast<const half8*>(wp + kcl);
+        bl[buf] = a.bias[nrow];
+    };
+    half8 xf[KSM];
+#pragma unroll
+    for (int ks = 0; ks < KSF; ++ks) xf[ks] = *reinterpret_cast<const half8*>(xp + ks * 16);
+    half8 xl = *reinterpret_cast<const half8*>(xp + kcl);
+    request(ct0, 0);
+    {
+        const half8 ones = {(half_t)1.f, (half_t)1.f, 0, 0, 0, 0, 0, 0};
+        xl = data ? xl : (bcol ? ones : zero8);
+    }
+    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 8;
+    auto tile = [&](const int ct, const int buf) {
+        half8 wlast;
+        {
+            const half_t hi = (half_t)bl[buf];
+            const half_t lo = (half_t)(bl[buf] - (float)hi);
+            const half8 bw = {hi, lo, 0, 0, 0, 0, 0, 0};
+            wlast = data ? wl[buf] : (bcol ? bw : zero8);
+        }
+        floatx16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][ks], xf[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast, xl, acc, 0, 0, 0);
+        act16(acc, a.act);
+        uint2v p[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[4 * g + e];
+            p[g] = __builtin_bit_cast(uint2v, hv);
+        }
+        const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[1][0], false, false);
+        const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[1][1], false, false);
+        const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[2][0], p[3][0], false, false);
+        const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[2][1], p[3][1], false, false);
+        const uint4 lo4 = make_uint4(s0[0], s1[0], s0[1], s1[1]), hi4 = make_uint4(s2[0], s3[0], s2[1], s3[1]);
+        const int nt = ct * 32, c0 = nt + hh * 8;
+        if (row < mend) {
+            if (c0 < NC) *reinterpret_cast<uint4*>(orow + nt) = lo4;
+            if (c0 + 16 < NC) *reinterpret_cast<uint4*>(orow + nt + 16) = hi4;
+        }
+    };
+    // (the requests are UNCONDITIONAL, with a clamped tile index: behind a branch the compiler cannot count which loads are outstanding at
+    // the join and waits for all of them -- vmcnt(0) before the first matrix instruction, i.e. no overlap at all; the price is one
+    // redundant tile request at the end of a run)
+    // (and pinned in front of the matrix instructions: left alone the scheduler sinks the next tile's loads below the current tile's MFMAs)
+    for (int ct = ct0; ct < ct1; ct += 2) {
+        request(min(ct + 1, ct1 - 1), 1);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(ct, 0);
+        if (ct + 1 < ct1) {
+            request(min(ct + 2, ct1 - 1), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(ct + 1, 1);
+        }
+    }
+}
+
+template <int KSF>
+int launch_stream_t(const PwArgs& a, int runs, int tiles_per_run, hipStream_t s) {
+    const int tiles = a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, 128) : dn_cdiv(a.m, 128);
+    const dim3 grid((unsigned)(a.xq > 0 ? 8 * tiles : tiles) * runs);
+    dn_note_kernel("pw_stream_kernel<%d>", KSF);
+    hipLaunchKernelGGL((pw_stream_kernel<KSF>), grid, dim3(256), 0, s, a, tiles, tiles_per_run);
+    return DN_OK;
 }
 
 // Depthwise 3x3 (stride 1, pad 1) + the 1x1 projection behind it in ONE launch, register-direct: the first block of the MobileNets
@@ -350,18 +475,18 @@ __global__ __launch_bounds__(256) void pw_dw_direct_kernel(PwDwArgs q, int tiles
     }
     uint4 lo4, hi4;
     {
-        const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[2][0], false, false);
-        const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[2][1], false, false);
-        const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[1][0], p[3][0], false, false);
-        const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[1][1], p[3][1], false, false);
+        const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[1][0], false, false);
+        const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[1][1], false, false);
+        const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[2][0], p[3][0], false, false);
+        const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[2][1], p[3][1], false, false);
         lo4 = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         hi4 = make_uint4(s2[0], s3[0], s2[1], s3[1]);
     }
-    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 16;
-    const int c0 = hh * 16;
+    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 8;
+    const int c0 = hh * 8;
     if (row < mend) {
         if (c0 < NC) *reinterpret_cast<uint4*>(orow) = lo4;
-        if (c0 + 8 < NC) *reinterpret_cast<uint4*>(orow + 8) = hi4;
+        if (c0 + 16 < NC) *reinterpret_cast<uint4*>(orow + 16) = hi4;
     }
 }
 
@@ -413,6 +538,20 @@ int launch_pw_direct(const PwArgs& a, hipStream_t s) {
     // (measured: threshold 400 -> batch 64 1.115 -> 1.107 ms, batch 32 0.79 -> 0.77 ms; 200 and 600 in between).
     const int ctiles = dn_cdiv(a.cout, 32);
     const int ksf = a.cin >> 4;
+    // wide expansions with enough rows: the streaming variant (pw_stream_kernel) -- channel runs sized so that all waves are resident at once
+    if (dn_knob("DN_PW_STREAM", 1) && !a.se && !a.residual && ksf >= 4 && ksf <= 8 && ctiles >= 12 && a.m >= dn_knob("DN_PW_STREAM_MINM", 12800)) {
+        const long ptiles = dn_cdiv(a.m, 32);
+        int runs = (int)std::max(1L, std::min((long)ctiles, (long)dn_knob("DN_PW_STREAM_WAVES", 2800) / ptiles));
+        const int per = dn_cdiv(ctiles, runs);
+        runs = dn_cdiv(ctiles, per);
+        switch (ksf) {
+            case 4: return launch_stream_t<4>(a, runs, per, s);
+            case 5: return launch_stream_t<5>(a, runs, per, s);
+            case 6: return launch_stream_t<6>(a, runs, per, s);
+            case 7: return launch_stream_t<7>(a, runs, per, s);
+            case 8: return launch_stream_t<8>(a, runs, per, s);
+        }
+    }
     if (ksf <= 8 && a.cout >= dn_knob("DN_PW_DIRECT_TC2", 400)) {
         const int wc_log = ctiles <= 2 ? 0 : ctiles <= 4 ? 1 : 2;
         switch (ksf) {

@@ -50,6 +50,8 @@ PW_CASES = [
     (1100, 480, 80, 100, 0, True, True, False),       # strip kernel, 11 images, SE scale + residual
     (17 * 25, 512, 128, 25, 2, False, False, False),  # 17 images of 25 pixels
     (8 * 6400, 24, 72, 6400, 1, False, False, False), # one image per XCD group
+    (13 * 1000, 80, 480, 1000, 3, False, False, False),   # streaming kernel (round 3): 15 channel tiles in runs, ragged rows inside the image groups
+    (12800, 72, 408, 12800, 1, False, False, False),      # ... K tail of 8 columns, a last channel tile of 24, one image (plain mapping)
 ]
 
 
@@ -93,6 +95,28 @@ def test_pointwise_conv(m, cin, cout, hw, act, res, se, fp32):
         torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
     else:
         torch.testing.assert_close(out.cpu().float(), ref.half().float(), rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("m,cin,cout,hw,act", [(25600, 112, 672, 400, 3), (13 * 1000, 80, 480, 1000, 3), (12800, 72, 408, 12800, 1)])
+def test_pointwise_streaming_bit_identical_to_direct(m, cin, cout, hw, act, monkeypatch):
+    """pw_stream_kernel (weight tiles streamed through two register sets past resident pixel rows) runs pw_direct_kernel's per-tile
+    arithmetic: same outputs, bit for bit."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(m + cin)
+    x = torch.randn(m, cin, generator=g).half().cuda()
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).half()
+    b = torch.randn(cout, generator=g).cuda()
+    wfd = torch.from_numpy(fragment_major(w.numpy())).cuda()
+    wd = w.cuda()
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_PW_STREAM", flag)
+        out = torch.zeros(m, cout, dtype=torch.half, device="cuda")
+        L.check(lib.dn_pointwise_conv(_ptr(x), _ptr(wd), _ptr(wfd), _ptr(b), _ptr(None), _ptr(None), _ptr(out), m, cin, cout, hw, act, 0, 0,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dn_pointwise_conv")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().max()) > 0
 
 
 DW_CASES = [
