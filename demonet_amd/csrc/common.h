@@ -288,6 +288,34 @@ bool expdw_supported(int cin, int cexp, int k, int stride);
 bool expdw_project_supported(int cexp, int cout, int Ho, int Wo, int stride);
 
 
+// Pyramid levels of the anchor axis. The class-major score array of the post-process is stored ANCHOR-MAJOR WITHIN A LEVEL:
+//   canonical (the reference's order, generalized_ssd.py:66-74):  a  = off[l] + pixel * aloc[l] + anchor
+//   stored:                                                       a' = off[l] + anchor * hw[l] + pixel
+// so that a head GEMM tile (consecutive pixels of one anchor) writes runs of consecutive floats per class (round 3: softmax in the head
+// launch's epilogue). Every consumer turns a' back into a before an index enters a key, a box lookup or an output.
+struct PostLevels {
+    int n = 1;
+    int off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};     // off[n] = A
+    int hw[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    int aloc[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+};
+__device__ __forceinline__ int post_level_of(const PostLevels& lv, int a) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) l += (i < lv.n && a >= lv.off[i]) ? 1 : 0;
+    return l;
+}
+__device__ __forceinline__ int post_canon(const PostLevels& lv, int ap) {      // stored -> canonical
+    const int l = post_level_of(lv, ap), r = ap - lv.off[l];
+    const int anc = r / lv.hw[l], pix = r - anc * lv.hw[l];
+    return lv.off[l] + pix * lv.aloc[l] + anc;
+}
+__device__ __forceinline__ int post_perm(const PostLevels& lv, int a) {        // canonical -> stored
+    const int l = post_level_of(lv, a), r = a - lv.off[l];
+    const int pix = r / lv.aloc[l], anc = r - pix * lv.aloc[l];
+    return lv.off[l] + anc * lv.hw[l] + pix;
+}
+
 struct PostArgs {
     const float* logits; const float* reg; const float* anchors;
     int n, A, K;
@@ -297,6 +325,8 @@ struct PostArgs {
     float* packed = nullptr;    // optional [n][dets+1][6] fp32: rows (x1,y1,x2,y2,score,label), row `dets` = (count,0,..)
     void* ws; size_t ws_bytes;
     int xq = 0;                 // XCD grouping: images per group (0: plain mapping)
+    PostLevels lv;              // default: one level with one anchor per location (stored order == canonical order)
+    int fused = 0;              // 1: the class scores and their histogram were written by the head launch (pointwise.hip, softmax epilogue)
 };
 size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets);
 int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev /* optional [4] phase boundaries */);

@@ -1274,6 +1274,14 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.packed = packed;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         a.xq = xq;
+        a.lv.n = d.n_levels;                     // the class-major scores are stored anchor-major within a level (common.h PostLevels)
+        for (int l = 0; l < d.n_levels; ++l) {
+            const dn_tensor_desc& tl = p->tensors[d.level_tensor[l]];
+            a.lv.off[l] = p->level_off[l];
+            a.lv.hw[l] = tl.h * tl.w;
+            a.lv.aloc[l] = d.anchors_per_loc[l];
+        }
+        a.lv.off[d.n_levels] = d.num_anchors;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
         if (rc) return rc;

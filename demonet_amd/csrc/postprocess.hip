@@ -39,10 +39,11 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
                                                             const float* __restrict__ anchors, float* __restrict__ scoresT,
                                                             float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
                                                             float score_thr, unsigned* __restrict__ phist, int hb0, int nb,
-                                                            long long* __restrict__ stamps, int nimg, int tiles, int xq) {
+                                                            long long* __restrict__ stamps, int nimg, int tiles, int xq, PostLevels lv) {
     extern __shared__ float tile[];            // [64][K] then rowsum[64] then hist[HBINS]
     float* rowsum = tile + 64 * K;
     unsigned* lhist = reinterpret_cast<unsigned*>(rowsum + 64);
+    __shared__ int pidx[64];                   // stored (anchor-major within the level) index of the tile's anchors
     // only bins [hb0, hb0 + nb) can be hit: scores lie in (score_thr, 1] (161 bins for score_thr = 0.001; nb <= HBINS)
     if (threadIdx.x < nb) lhist[threadIdx.x] = 0u;
     const int tid = threadIdx.x;
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     const int a0 = atile * 64;
     PP_STAMP(8);
     const int na = min(64, A - a0);
+    if (tid < 64) pidx[tid] = post_perm(lv, min(a0 + tid, A - 1));      // (visible after the barrier behind the tile load)
     const float* src = logits + ((size_t)n * A + a0) * K;
     const int total = na * K;
     {
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
         const int k = 1 + (idx >> 6), a = idx & 63;
         if (a < na) {
             const float sc = tile[a * K + k] / rowsum[a];
-            scoresT[((size_t)n * Km1 + (k - 1)) * A + a0 + a] = sc;
+            scoresT[((size_t)n * Km1 + (k - 1)) * A + pidx[a]] = sc;
             if (sc > score_thr) atomicAdd(&lhist[min(max((int)(__float_as_uint(sc) >> HSHIFT) - hb0, 0), nb - 1)], 1u);
         }
     }
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
                                                         int A, int Km1, float score_thr, float nms_thr, int topk,
                                                         float* __restrict__ keptScore, int* __restrict__ keptAnchor,
                                                         int* __restrict__ keptCount, const int* __restrict__ needFull,
-                                                        long long* stamps, int nimg, int xq) {
+                                                        long long* stamps, int nimg, int xq, PostLevels lv) {
     int n, cls;                          // flat grid [image slot][class]; cls 0..Km1-1 (label = cls + 1)
     if (!xcd_image_of(blockIdx.x, Km1, xq, nimg, n, cls)) return;
     if (needFull && !needFull[n]) return;      // the fast path already produced this image's result
@@ -407,10 +409,10 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     if (tid < 16) sh[tid] = 0;
     __syncthreads();
     unsigned local = 0;
-    for (int a = tid; a < A; a += 256) {
-        const float s = col[a];
+    for (int ap = tid; ap < A; ap += 256) {
+        const float s = col[ap];
         const unsigned k = (s > score_thr) ? __float_as_uint(s) : 0u;     // strict > (generalized_ssd.py:371)
-        key[a] = k;
+        key[post_canon(lv, ap)] = k;                                       // the column is stored anchor-major within a level: back to the canonical order
         local += (k != 0u);
     }
     {
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
                                                              int A, int Km1, float score_thr, float nms_thr, int topk,
                                                              const unsigned* __restrict__ tauKey, int* __restrict__ needFull,
                                                              float* __restrict__ keptScore, int* __restrict__ keptAnchor,
-                                                             int* __restrict__ keptCount, long long* __restrict__ stamps, int nimg, int xq) {
+                                                             int* __restrict__ keptCount, long long* __restrict__ stamps, int nimg, int xq, PostLevels lv) {
     constexpr int MC = 64 * NW;
     constexpr int CAP = (64 * NW * NW < 2048) ? 64 * NW * NW : 2048;      // candidate list (>= MC); the sort scratch aliases the IoU mask
     static_assert(CAP >= MC && CAP <= MC * NW, "sort scratch must fit the mask array");
@@ -575,9 +577,10 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
         for (int u = 0; u < 8; ++u) {
             const unsigned k = __float_as_uint(v[u]);
             if (v[u] > score_thr && k >= tau) {          // out-of-range lanes are re-checked below (a < A)
-                const int a = a0 + u * FT + tid;
-                if (a < A) {
+                const int ap = a0 + u * FT + tid;
+                if (ap < A) {
                     const unsigned pos = atomicAdd(&cnt_sh, 1u);
+                    const int a = post_canon(lv, ap);       // stored -> canonical anchor index (tie-break, box lookup, output)
                     if (pos < (unsigned)CAP) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
                 }
             }
@@ -803,7 +806,7 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
     }
     DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW>)));
     hipLaunchKernelGGL((select_nms_kernel<NW>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq);
+                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv);
     return DN_OK;
 }
 
@@ -814,11 +817,11 @@ int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes,
     // IoU-mask rows over 8 waves instead of 4 -- the kernel's duration is the lifetime of its heaviest workgroups
     if (dn_knob("DN_PP_FAST_THREADS", 512) == 256) {
         hipLaunchKernelGGL((select_nms_fast_kernel<NW, 256>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), 0, s, scoresT, boxes, a.A, a.K - 1,
-                           a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq);
+                           a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv);
         return DN_OK;
     }
     hipLaunchKernelGGL((select_nms_fast_kernel<NW, 512>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(512), 0, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq);
+                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv);
     return DN_OK;
 }
 
@@ -837,7 +840,8 @@ static int pp_env(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
+int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
+    PostArgs a = a0;
     DN_REQUIRE(a.n > 0 && a.A > 0 && a.K >= 2, "postprocess: bad sizes n=%d A=%d K=%d", a.n, a.A, a.K);
     DN_REQUIRE(a.topk >= 1 && a.topk <= 512, "postprocess: topk_candidates=%d outside [1,512]", a.topk);
     DN_REQUIRE(a.dets >= 1 && a.dets <= 512, "postprocess: detections_per_img=%d outside [1,512]", a.dets);
@@ -846,6 +850,12 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     if (a.ws_bytes < need) {
         dn_set_error("postprocess: workspace %zu B < required %zu B", a.ws_bytes, need);
         return DN_E_WORKSPACE;
+    }
+    if (a.lv.n == 1 && a.lv.off[1] == 0) { a.lv.off[1] = a.A; a.lv.hw[0] = a.A; a.lv.aloc[0] = 1; }      // no level table given: one level, stored == canonical
+    {
+        bool ok = a.lv.n >= 1 && a.lv.n <= 8 && a.lv.off[0] == 0 && a.lv.off[a.lv.n] == a.A;
+        for (int l = 0; ok && l < a.lv.n; ++l) ok = a.lv.hw[l] >= 1 && a.lv.aloc[l] >= 1 && a.lv.off[l + 1] - a.lv.off[l] == a.lv.hw[l] * a.lv.aloc[l];
+        DN_REQUIRE(ok, "postprocess: the level table does not cover the %d anchors", a.A);
     }
     const size_t Km1 = a.K - 1;
     unsigned char* p = reinterpret_cast<unsigned char*>(a.ws);
@@ -889,7 +899,7 @@ int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev) {
     const int slots = xcd_image_slots(a.xq, a.n);
     hipLaunchKernelGGL(softmax_decode_kernel, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
                        scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,
-                       a.n, tiles, a.xq);
+                       a.n, tiles, a.xq, a.lv);
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
     if (fast) {
