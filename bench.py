@@ -91,7 +91,11 @@ def op_costs(graph, n):
         out.append(c)
     A, K = graph.num_anchors(), graph.num_classes
     topk, D = graph.post["topk_candidates"], graph.post["detections_per_img"]
-    out.append(dict(kernel="softmax_decode_kernel", bytes=float(n * A * (4 * K + 16 + 4 * (K - 1) + 16)), flops=float(5 * n * A * K)))
+    if graph.name.startswith(("ssdlite", "ssd_lite")) and os.environ.get("DN_HEAD_SOFTMAX", "0") != "0":
+        # the class heads' epilogue computes the softmax (scores written instead of logits): only the box decode is left of this launch
+        out.append(dict(kernel="decode_boxes_kernel", bytes=float(n * A * 48), flops=float(20 * n * A)))
+    else:
+        out.append(dict(kernel="softmax_decode_kernel", bytes=float(n * A * (4 * K + 16 + 4 * (K - 1) + 16)), flops=float(5 * n * A * K)))
     out.append(dict(kernel="select_nms_kernel", bytes=float(n * (K - 1) * (4 * A + 24 * topk)), flops=float(25 * n * (K - 1) * topk * topk / 2)))
     out.append(dict(kernel="merge_kernel", bytes=float(n * ((K - 1) * topk * 8 + D * 40)), flops=0.0))
     return out
@@ -474,7 +478,7 @@ def main(argv=None):
         # the library reports which kernel each op launched and which op's event segment holds a grouped launch's time
         name = C.create_string_buffer(96)
         owner = C.c_int32()
-        post = ["softmax_decode_kernel", "select_nms_fast_kernel (+tau, fallback select)", "merge_kernel"]
+        post = [costs[len(g.nodes)]["kernel"], "select_nms_fast_kernel (+tau, fallback select)", "merge_kernel"]
         agg = {}
         for i, c in enumerate(costs):
             if i < len(g.nodes):

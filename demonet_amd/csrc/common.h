@@ -150,7 +150,16 @@ struct PwArgs {
     long out_base;          // element offset of image 0 (head ops: level offset * columns)
     long long* stamps = nullptr;   // dev-only phase stamps
     int xq = 0;             // XCD grouping: images per group (0: plain mapping); see xcd_images_per_group
+    // Softmax in the epilogue of an fp32 class-head problem (grouped launch only, round 3): instead of the logits rows the tile's class
+    // scores go straight into the post-process's class-major array (stored order, PostLevels) and its score histogram; a channel tile
+    // then covers whole anchors (sm_apt = BC / K of them, set by the launcher). `out` is not written.
+    float* sm_scores = nullptr;    // [n][K-1][A]
+    unsigned* sm_hist = nullptr;   // [n][256], zeroed before the launch
+    int sm_K = 0, sm_A = 0, sm_off = 0, sm_aloc = 0, sm_apt = 0;      // classes incl. background, anchors per image, level offset, anchors per location
+    float sm_thr = 0.f; int sm_hb0 = 0, sm_nb = 0;                   // score threshold and the histogram's bin range (post_hist_range)
 };
+constexpr int DN_PP_HSHIFT = 19;      // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
+constexpr int DN_PP_HBINS = 256;      // bins kept: the top 256 (scores down to 2^-16); anything lower shares bin 0
 int launch_pointwise(const PwArgs& a, hipStream_t s);
 // register-direct schedule for short reductions (pwdirect.hip)
 bool pw_direct_supported(const PwArgs& a);
@@ -190,7 +199,7 @@ struct DwArgs {
 };
 bool depthwise_se_tail_supported(int c, int squeeze);
 int launch_depthwise(const DwArgs& a, hipStream_t s);
-int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s);
+int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_u32 = nullptr, int zero_count = 0);   // (optional: words the launch clears)
 int depthwise_pool_blocks(const DwArgs& a);       // workgroups per image == partial-sum rows per image
 
 struct StemArgs {
@@ -305,12 +314,15 @@ __device__ __forceinline__ int post_level_of(const PostLevels& lv, int a) {
     for (int i = 1; i < 8; ++i) l += (i < lv.n && a >= lv.off[i]) ? 1 : 0;
     return l;
 }
+__device__ __forceinline__ bool post_identity(const PostLevels& lv) { return lv.n == 1 && lv.aloc[0] == 1; }      // uniform: stored == canonical
 __device__ __forceinline__ int post_canon(const PostLevels& lv, int ap) {      // stored -> canonical
+    if (post_identity(lv)) return ap;
     const int l = post_level_of(lv, ap), r = ap - lv.off[l];
     const int anc = r / lv.hw[l], pix = r - anc * lv.hw[l];
     return lv.off[l] + pix * lv.aloc[l] + anc;
 }
 __device__ __forceinline__ int post_perm(const PostLevels& lv, int a) {        // canonical -> stored
+    if (post_identity(lv)) return a;
     const int l = post_level_of(lv, a), r = a - lv.off[l];
     const int pix = r / lv.aloc[l], anc = r - pix * lv.aloc[l];
     return lv.off[l] + anc * lv.hw[l] + pix;
@@ -329,4 +341,8 @@ struct PostArgs {
     int fused = 0;              // 1: the class scores and their histogram were written by the head launch (pointwise.hip, softmax epilogue)
 };
 size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets);
+// where the head launch's softmax epilogue must write (PwArgs::sm_*): the score array and the per-image histogram inside the workspace,
+// and the reachable histogram bins for a score threshold
+void postprocess_fused_targets(void* ws, int n, int A, int K, int topk, float** scores, unsigned** hist);
+void post_hist_range(float score_thresh, int* hb0, int* nb, int* clamped);
 int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev /* optional [4] phase boundaries */);

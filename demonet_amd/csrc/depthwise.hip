@@ -564,6 +564,7 @@ static int launch_dwl(const DwArgs& a, const DwlGeom& g, hipStream_t s) {
 // depthwise convs of all pyramid levels, both heads). blockIdx.x is flat over the problems' per-image block counts (x 8 with the
 // XCD grouping: every problem's range starts at a multiple of 8), blockIdx.y is the image slot.
 struct DwGroup {
+    unsigned* zero_u32; int zero_count;      // optional: words this launch clears (the score histogram of the head launch behind it)
     int count;
     int start[13];
     int nblocks[12];        // workgroups per image
@@ -572,6 +573,10 @@ struct DwGroup {
 
 template <int K, int S, int TW>
 __global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
+    if (g.zero_u32 && blockIdx.y == 0) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < g.zero_count) g.zero_u32[i] = 0u;
+    }
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 12; ++i)
@@ -601,9 +606,10 @@ bool dw_fill(DwArgs& a) {
 }
 
 template <int K, int S, int TW>
-int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
+int launch_dw_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_u32, int zero_count) {
     DwGroup g{};
     g.count = count;
+    g.zero_u32 = zero_u32; g.zero_count = zero_count;
     int acc = 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
@@ -614,6 +620,7 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
         acc += g.nblocks[i] * (arr[i].xq > 0 ? 8 : 1);
     }
     g.start[count] = acc;
+    DN_REQUIRE(!zero_u32 || (long)acc * 256 >= zero_count, "depthwise group: %d workgroups cannot clear %d words", acc, zero_count);
     dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
     hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
     return DN_OK;
@@ -1064,16 +1071,16 @@ int launch_depthwise(const DwArgs& a, hipStream_t s) {
     return DN_E_UNSUPPORTED;
 }
 
-int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s) {
+int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_u32, int zero_count) {
     DN_REQUIRE(count >= 1 && count <= 12, "depthwise group: %d problems", count);
     for (int i = 0; i < count; ++i) {
         DN_REQUIRE(arr[i].c % 8 == 0 && !arr[i].pool && arr[i].k == arr[0].k && arr[i].stride == arr[0].stride && arr[i].n == arr[0].n,
                    "depthwise group: problem %d is not compatible", i);
     }
-    if (arr[0].k == 3 && arr[0].stride == 1) return launch_dw_group<3, 1, 4>(arr, count, s);
-    if (arr[0].k == 3 && arr[0].stride == 2) return launch_dw_group<3, 2, 2>(arr, count, s);
-    if (arr[0].k == 5 && arr[0].stride == 1) return launch_dw_group<5, 1, 4>(arr, count, s);
-    return launch_dw_group<5, 2, 2>(arr, count, s);
+    if (arr[0].k == 3 && arr[0].stride == 1) return launch_dw_group<3, 1, 4>(arr, count, s, zero_u32, zero_count);
+    if (arr[0].k == 3 && arr[0].stride == 2) return launch_dw_group<3, 2, 2>(arr, count, s, zero_u32, zero_count);
+    if (arr[0].k == 5 && arr[0].stride == 1) return launch_dw_group<5, 1, 4>(arr, count, s, zero_u32, zero_count);
+    return launch_dw_group<5, 2, 2>(arr, count, s, zero_u32, zero_count);
 }
 
 int depthwise_pool_blocks(const DwArgs& a) {

@@ -920,6 +920,30 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     };
     int ev = ev0;
     hipStream_t const main_stream = s;
+    // Softmax in the epilogue of the grouped class-head launch (DN_HEAD_SOFTMAX=1, opt-in; pointwise.hip): the 1x1 class heads write the
+    // class scores and their histogram straight into the post-process workspace -- the logits (n x A x K fp32: 75 MB per 64 images) are
+    // neither written nor read back. Only for whole forwards whose heads run as ONE grouped 1x1 launch behind the grouped depthwise
+    // launch (the SSDLite models); forward_heads keeps the unfused path, which is what the parity tests of the logits read.
+    // MEASURED (round 3, batch 64) and left OFF: bit-identical detections (tests/test_gpu_model.py::test_softmax_in_the_head_epilogue...),
+    // but the head launch goes from 92 to 161 us while the softmax launch it replaces costs 46 (the box decode that remains: 7): the
+    // softmax is ~2 600 vector instructions per thread of exp / divide / histogram work, and in the epilogue of a 51 KB-LDS GEMM
+    // workgroup (3 per CU) it runs at a third of the occupancy of the stand-alone kernel (6 per CU, 24 waves) with nothing to overlap it;
+    // 0.741 -> 0.760 ms in flight, 0.985 -> 0.990 one at a time. The 150 MB of logits traffic it saves were not what bounds the step.
+    bool fuse_sm = false;
+    float* sm_scores = nullptr; unsigned* sm_hist = nullptr;
+    int sm_hb0 = 0, sm_nb = 0;
+    if (!heads_only && p->head_first >= 0 && !p->head_dw.empty() && !p->head_cls.empty() && p->head_early == 0 && !p->multi_stream &&
+        dn_knob("DN_HEAD_SOFTMAX", 0) != 0 && dn_knob("DN_HEAD_MERGE", 1) != 0 && d.num_classes <= 96 && d.score_thresh >= 0.f) {
+        fuse_sm = true;
+        for (int q : p->head_cls) fuse_sm &= p->ops[q].type == DN_OP_PW && p->ops[q].act == DN_ACT_NONE && p->ops[q].cout == d.anchors_per_loc[p->ops[q].level] * d.num_classes;
+        for (int q : p->head_reg) fuse_sm &= p->ops[q].type == DN_OP_PW;
+        fuse_sm &= p->head_reg.size() + p->head_cls.size() <= 12;
+        if (fuse_sm) {
+            int clamped;
+            postprocess_fused_targets(ws + L.post_off, n, d.num_anchors, d.num_classes, d.topk_candidates, &sm_scores, &sm_hist);
+            post_hist_range(d.score_thresh, &sm_hb0, &sm_nb, &clamped);
+        }
+    }
     const bool inl = p->head_inline == 2 || (p->head_inline == 1 && (chain & 1));
     const bool branch = !record && p->head_early > 0 && p->head_fork_op >= 0 && chain >= 0 && chain < 4 && (p->head_inline == 0 || inl);
     bool forked = false;
@@ -938,7 +962,8 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         if (!h_dw.empty()) {
             DwArgs arr[12];
             for (size_t q = 0; q < h_dw.size(); ++q) arr[q] = make_dw(p->ops[h_dw[q]]);
-            rc = launch_depthwise_group(arr, (int)h_dw.size(), hs);
+            // softmax in the class heads' epilogue: the depthwise group in front of them clears the per-image score histogram
+            rc = launch_depthwise_group(arr, (int)h_dw.size(), hs, fuse_sm ? sm_hist : nullptr, fuse_sm ? n * DN_PP_HBINS : 0);
             if (rc != DN_OK) return rc;
             for (int q : h_dw) hnote(q, seg);
             ++seg;
@@ -968,6 +993,12 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             std::stable_sort(lst.begin(), lst.end(), [&](int x, int y) { return p->ops[x].cout > p->ops[y].cout; });
             for (size_t q = 0; q < lst.size(); ++q) {
                 PwArgs pa = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
+                if (fuse_sm && !conv && p->ops[lst[q]].head == 1) {
+                    const dn_op_desc& ho = p->ops[lst[q]];
+                    pa.sm_scores = sm_scores; pa.sm_hist = sm_hist;
+                    pa.sm_K = d.num_classes; pa.sm_A = d.num_anchors; pa.sm_off = p->level_off[ho.level]; pa.sm_aloc = d.anchors_per_loc[ho.level];
+                    pa.sm_thr = d.score_thresh; pa.sm_hb0 = sm_hb0; pa.sm_nb = sm_nb;
+                }
                 if (conv && taken.count(lst[q])) continue;          // rides in another head's launch
                 if (conv && conv_head_big_supported(pa)) {
                     // the wide dense heads of the large levels: MFMA-bound, each on the run-staged 256x256 tile. The box head of the
@@ -1001,7 +1032,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                     const dn_tensor_desc& th = p->tensors[p->ops[lst[q]].in];
                     pb.cv_k = 1; pb.cv_stride = 1; pb.cv_pad = 0; pb.cv_dil = 1; pb.cv_h = pb.cv_ho = th.h; pb.cv_w = pb.cv_wo = th.w; pb.cv_cin = pb.cin;
                     pb.zeros = reinterpret_cast<const half_t*>(Wb + p->zeros_off);
-                    if (pw_head_big_supported(pb)) {
+                    if (!pa.sm_scores && pw_head_big_supported(pb)) {
                         rc = launch_pw_head_big(pb, hs);
                         if (rc != DN_OK) return rc;
                         hnote(lst[q], seg);
@@ -1272,16 +1303,19 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.score_thresh = d.score_thresh; a.nms_thresh = d.nms_thresh; a.topk = d.topk_candidates; a.dets = d.detections_per_img;
         a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = nullptr;
         a.packed = packed;
+        a.fused = fuse_sm ? 1 : 0;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         a.xq = xq;
-        a.lv.n = d.n_levels;                     // the class-major scores are stored anchor-major within a level (common.h PostLevels)
-        for (int l = 0; l < d.n_levels; ++l) {
+        // with the softmax in the head epilogue the class-major scores are stored anchor-major within a level (common.h PostLevels);
+        // the stand-alone softmax launch keeps the canonical order (default level table: its writes stay coalesced)
+        a.lv.n = fuse_sm ? d.n_levels : 1;
+        for (int l = 0; fuse_sm && l < d.n_levels; ++l) {
             const dn_tensor_desc& tl = p->tensors[d.level_tensor[l]];
             a.lv.off[l] = p->level_off[l];
             a.lv.hw[l] = tl.h * tl.w;
             a.lv.aloc[l] = d.anchors_per_loc[l];
         }
-        a.lv.off[d.n_levels] = d.num_anchors;
+        if (fuse_sm) a.lv.off[d.n_levels] = d.num_anchors;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
         if (rc) return rc;

@@ -50,7 +50,9 @@ __device__ __forceinline__ bool pw_tile_rows(const PwArgs& a, int flat, int tile
     return true;
 }
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false>
+// SM: softmax epilogue for the fp32 class-head problems that ask for it (PwArgs::sm_scores; grouped launch only). A template
+// parameter because its code costs the plain kernel two registers -- exactly the two that take it from 3 to 2 waves per SIMD.
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false, bool SM = false>
 __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, const int by) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
@@ -72,7 +74,8 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
     const int wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC;
     const int r = lane & 31, hh = lane >> 5;
-    const int n0 = by * BC;
+    // (softmax epilogue: a channel tile starts at an anchor boundary and covers sm_apt whole anchors -- its last BC - sm_apt * K columns are the next tile's)
+    const int n0 = (SM && a.sm_scores) ? by * a.sm_apt * a.sm_K : by * BC;
     const int M = mend, K = a.cin, NC = a.cout;      // rows beyond the group's end belong to another workgroup
     const int dbg = a.act >> 8;            // probe-only knobs: 1 = skip stores, 2 = skip global loads of x
     a.act &= 0xff;
@@ -423,6 +426,72 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             }
         }
         __syncthreads();
+        if (SM && a.sm_scores) {
+            // ---- softmax over the classes of every (pixel, anchor) of the tile, scores and histogram written where the post-process reads
+            // them (generalized_ssd.py:354 F.softmax; postprocess.hip softmax_decode_kernel does the same arithmetic in the same order on the
+            // logits this tile would have written: four lanes per row, strided maximum and sum, (s0 + s1) + (s2 + s3), true division).
+            const int KC = a.sm_K, Km1 = KC - 1;
+            const int ja = min(a.sm_apt, a.sm_aloc - by * a.sm_apt);        // anchors of this tile
+            int* rimg = reinterpret_cast<int*>(ot + BP * FROW);               // [BP] image of the row (-1: beyond the problem)
+            int* rpix = rimg + BP;                                            // [BP] pixel within the image
+            unsigned* lhist = reinterpret_cast<unsigned*>(rpix + BP);         // [4][256] histogram of the tile's first four images
+            const int img_first = m0 / a.hw;
+            for (int row = tid; row < BP; row += 256) {
+                const int m = m0 + row, img = m / a.hw;
+                rimg[row] = m < M ? img : -1;
+                rpix[row] = m - img * a.hw;
+            }
+            for (int i = tid; i < 4 * 256; i += 256) lhist[i] = 0u;
+            __syncthreads();
+            {
+                const int sub = tid & 3;
+                for (int pr = tid >> 2; pr < BP * ja; pr += 64) {
+                    const int row = pr % BP, j = pr / BP;
+                    float* base = &ot[row * FROW + j * KC];
+                    const bool live = rimg[row] >= 0;
+                    float mx = -INFINITY;
+                    if (live)
+                        for (int k = sub; k < KC; k += 4) mx = fmaxf(mx, base[k]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 1));
+                    mx = fmaxf(mx, __shfl_xor(mx, 2));
+                    float sm = 0.f;
+                    if (live)
+                        for (int k = sub; k < KC; k += 4) {
+                            const float e = expf(base[k] - mx);
+                            base[k] = e;
+                            sm += e;
+                        }
+                    sm += __shfl_xor(sm, 1);
+                    sm += __shfl_xor(sm, 2);
+                    if (sub == 0 && live) base[0] = sm;                      // the background column carries the row sum from here on
+                }
+            }
+            __syncthreads();
+            const int total = Km1 * ja * BP;
+            for (int idx = tid; idx < total; idx += 256) {
+                const int row = idx % BP, t = idx / BP;
+                const int j = t % ja, k = 1 + t / ja;
+                const int img = rimg[row];
+                if (img < 0) continue;
+                const float* base = &ot[row * FROW + j * KC];
+                const float sc = base[k] / base[0];
+                const int ap = a.sm_off + (by * a.sm_apt + j) * a.hw + rpix[row];        // stored order: anchor-major within the level (PostLevels)
+                a.sm_scores[((size_t)img * Km1 + (k - 1)) * a.sm_A + ap] = sc;
+                if (sc > a.sm_thr) {
+                    const int bin = min(max((int)(__float_as_uint(sc) >> DN_PP_HSHIFT) - a.sm_hb0, 0), a.sm_nb - 1);
+                    const int slot = img - img_first;
+                    if (slot < 4) atomicAdd(&lhist[slot * 256 + bin], 1u);
+                    else atomicAdd(&a.sm_hist[(size_t)img * 256 + bin], 1u);          // (a tile of a small level spans more images)
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < 4 * 256; i += 256) {
+                const unsigned v = lhist[i];
+                if (v) atomicAdd(&a.sm_hist[(size_t)(img_first + (i >> 8)) * 256 + (i & 255)], v);
+            }
+            PW_STAMP(3);
+            return;
+        }
         float* outp = reinterpret_cast<float*>(a.out);
         const bool pair_ok = ((NC | (int)(a.out_base & 1) | (int)(a.out_img_stride & 1)) & 1) == 0 &&
                              (reinterpret_cast<size_t>(outp) & 7) == 0;       // every row start 8-byte aligned
@@ -563,15 +632,15 @@ struct PwGroup {
     PwArgs a[12];
 };
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1>
-__global__ __launch_bounds__(256) void pw_group_kernel(PwGroup g) {
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SM = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SM && BP == 128 && BC == 96) ? 3 : 1))) void pw_group_kernel(PwGroup g) {
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 12; ++i)
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
     int m0, mend, by;       // (start[] are multiples of 8 when the XCD grouping is on: local % 8 == blockIdx.x % 8)
     if (!pw_tile_rows<BP>(g.a[p], blockIdx.x - g.start[p], g.gx[p], m0, mend, by)) return;
-    pw_body<BP, BC, WP, WC, CONV, BK, PF>(g.a[p], m0, mend, by);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF, false, SM>(g.a[p], m0, mend, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -873,6 +942,7 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     g.count = count;
     int acc = 0;
     bool all_xq = true;         // XCD grouping needs every problem's first workgroup at a multiple of 8: all problems or none
+    bool any_sm = false;
     for (int i = 0; i < count; ++i) all_xq &= arr[i].xq > 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
@@ -880,17 +950,34 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
         g.a[i].stamps = g_pw_stamps;        // dev hook (null unless tools/probe_head_stamps.py set it)
         g.start[i] = acc;
         g.gx[i] = pw_row_tiles(g.a[i], BP);
-        acc += (g.a[i].xq > 0 ? 8 * g.gx[i] : g.gx[i]) * dn_cdiv(arr[i].cout, BC);
+        int ctiles = dn_cdiv(arr[i].cout, BC);
+        if (arr[i].sm_scores) {
+            // softmax epilogue: whole anchors per channel tile
+            DN_REQUIRE(!CONV && arr[i].out_fp32 && arr[i].sm_K >= 2 && arr[i].sm_K <= BC && arr[i].sm_aloc >= 1 && arr[i].cout == arr[i].sm_aloc * arr[i].sm_K &&
+                       arr[i].sm_hist && arr[i].act == DN_ACT_NONE, "pointwise group: problem %d cannot take the softmax epilogue (K=%d, tile %d)", i, arr[i].sm_K, BC);
+            g.a[i].sm_apt = BC / arr[i].sm_K;
+            ctiles = dn_cdiv(arr[i].sm_aloc, g.a[i].sm_apt);
+            any_sm = true;
+        }
+        acc += (g.a[i].xq > 0 ? 8 * g.gx[i] : g.gx[i]) * ctiles;
     }
     g.start[count] = acc;
     size_t halfs = (size_t)2 * (BP + BC) * (BK + 8);
     bool any_fp32 = false;
     for (int i = 0; i < count; ++i) any_fp32 |= arr[i].out_fp32 != 0 || arr[i].residual != nullptr;
-    const size_t otile = any_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);
+    size_t otile = any_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);
+    if (any_sm) otile += (size_t)2 * (2 * BP + 4 * 256);        // softmax epilogue: image / pixel of every tile row, a four-image histogram (ints behind the fp32 tile)
     if (otile > halfs) halfs = otile;
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
-    if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>)));
     dn_note_kernel(GPF > 1 ? "pw_group_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_group_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK, GPF);
+    if constexpr (!CONV) {
+        if (any_sm) {
+            if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>)));
+            hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>), dim3(acc), dim3(256), lds, s, g);
+            return DN_OK;
+        }
+    }
+    if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>)));
     hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF>), dim3(acc), dim3(256), lds, s, g);
     return DN_OK;
 }

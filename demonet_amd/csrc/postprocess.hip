@@ -29,12 +29,41 @@ namespace {
 #define PP_STAMP(k) do { if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
-constexpr int HSHIFT = 19;                               // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
-constexpr int HBINS = 256;                               // bins kept: the top 256 (scores down to 2^-16); anything lower shares bin 0
+constexpr int HSHIFT = DN_PP_HSHIFT;                     // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
+constexpr int HBINS = DN_PP_HBINS;                       // bins kept: the top 256 (scores down to 2^-16); anything lower shares bin 0
+
+// Box decode alone (BoxCoder.decode_single + clip, _utils.py:187-224, generalized_ssd.py:362-363): what is left of P1 when the class
+// scores come from the head launch's epilogue. Same expressions as softmax_decode_kernel's tail.
+__global__ __launch_bounds__(256) void decode_boxes_kernel(const float* __restrict__ reg, const float* __restrict__ anchors, float4* __restrict__ boxes,
+                                                          int A, float img_w, float img_h, int nimg, int tiles, int xq) {
+    int n, atile;
+    if (!xcd_image_of(blockIdx.x, tiles, xq, nimg, n, atile)) return;
+    const int a = atile * 256 + threadIdx.x;
+    if (a >= A) return;
+    const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
+    const float4 an = reinterpret_cast<const float4*>(anchors)[a];
+    const float w = an.z - an.x, h = an.w - an.y;
+    const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
+    const float dx = rg.x / 10.f, dy = rg.y / 10.f;
+    const float dw = fminf(rg.z / 5.f, BBOX_XFORM_CLIP), dh = fminf(rg.w / 5.f, BBOX_XFORM_CLIP);
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    float4 b;
+    b.x = pcx - 0.5f * pw;
+    b.y = pcy - 0.5f * ph;
+    b.z = pcx + 0.5f * pw;
+    b.w = pcy + 0.5f * ph;
+    b.x = fminf(fmaxf(b.x, 0.f), img_w);
+    b.z = fminf(fmaxf(b.z, 0.f), img_w);
+    b.y = fminf(fmaxf(b.y, 0.f), img_h);
+    b.w = fminf(fmaxf(b.w, 0.f), img_h);
+    boxes[(size_t)n * A + a] = b;
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // P1
 // ------------------------------------------------------------------------------------------------------------
+template <bool PERM>      // PERM: scores stored anchor-major within a level (PostLevels); false: canonical order, no index code at all
 __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __restrict__ logits, const float* __restrict__ reg,
                                                             const float* __restrict__ anchors, float* __restrict__ scoresT,
                                                             float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
@@ -52,7 +81,8 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     const int a0 = atile * 64;
     PP_STAMP(8);
     const int na = min(64, A - a0);
-    if (tid < 64) pidx[tid] = post_perm(lv, min(a0 + tid, A - 1));      // (visible after the barrier behind the tile load)
+    constexpr bool ident = !PERM;
+    if (!ident && tid < 64) pidx[tid] = post_perm(lv, min(a0 + tid, A - 1));      // (visible after the barrier behind the tile load)
     const float* src = logits + ((size_t)n * A + a0) * K;
     const int total = na * K;
     {
@@ -109,7 +139,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
         const int k = 1 + (idx >> 6), a = idx & 63;
         if (a < na) {
             const float sc = tile[a * K + k] / rowsum[a];
-            scoresT[((size_t)n * Km1 + (k - 1)) * A + pidx[a]] = sc;
+            scoresT[((size_t)n * Km1 + (k - 1)) * A + (ident ? a0 + a : pidx[a])] = sc;
             if (sc > score_thr) atomicAdd(&lhist[min(max((int)(__float_as_uint(sc) >> HSHIFT) - hb0, 0), nb - 1)], 1u);
         }
     }
@@ -379,7 +409,7 @@ __device__ __forceinline__ void nms_serial_phase(const unsigned long long* cand,
 // ------------------------------------------------------------------------------------------------------------
 // P2: per (image, class)
 // ------------------------------------------------------------------------------------------------------------
-template <int NW>   // 64-candidate words: candidate capacity MC = 64*NW >= topk
+template <int NW, bool PERM>   // 64-candidate words: candidate capacity MC = 64*NW >= topk; PERM: the column is stored anchor-major within a level
 __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
                                                         int A, int Km1, float score_thr, float nms_thr, int topk,
                                                         float* __restrict__ keptScore, int* __restrict__ keptAnchor,
@@ -412,7 +442,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     for (int ap = tid; ap < A; ap += 256) {
         const float s = col[ap];
         const unsigned k = (s > score_thr) ? __float_as_uint(s) : 0u;     // strict > (generalized_ssd.py:371)
-        key[post_canon(lv, ap)] = k;                                       // the column is stored anchor-major within a level: back to the canonical order
+        key[PERM ? post_canon(lv, ap) : ap] = k;                                       // the column is stored anchor-major within a level: back to the canonical order
         local += (k != 0u);
     }
     {
@@ -539,7 +569,7 @@ __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ p
 // of the class is the top-k of this set), as long as the set fits the CAP-entry list; beyond that needFull[n] hands the image to
 // the full kernel. (With 24 732 anchors -- ssd512 -- one dominant class regularly has more than topk = 400 scores above the
 // cut-off: without the in-kernel cap every image of that model went through the full path, 3.0 of its 11.1 ms per batch.)
-template <int NW, int FT>
+template <int NW, int FT, bool PERM>
 __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
                                                              int A, int Km1, float score_thr, float nms_thr, int topk,
                                                              const unsigned* __restrict__ tauKey, int* __restrict__ needFull,
@@ -580,7 +610,7 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
                 const int ap = a0 + u * FT + tid;
                 if (ap < A) {
                     const unsigned pos = atomicAdd(&cnt_sh, 1u);
-                    const int a = post_canon(lv, ap);       // stored -> canonical anchor index (tie-break, box lookup, output)
+                    const int a = PERM ? post_canon(lv, ap) : ap;       // stored -> canonical anchor index (tie-break, box lookup, output)
                     if (pos < (unsigned)CAP) cand[pos] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
                 }
             }
@@ -804,8 +834,15 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
         dn_set_error("postprocess: %d anchors need %zu B of LDS (> 160 KiB)", a.A, lds);
         return DN_E_UNSUPPORTED;
     }
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW>)));
-    hipLaunchKernelGGL((select_nms_kernel<NW>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
+    const bool perm = !(a.lv.n == 1 && a.lv.aloc[0] == 1);
+    if (perm) {
+        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, true>)));
+        hipLaunchKernelGGL((select_nms_kernel<NW, true>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
+                           a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv);
+        return DN_OK;
+    }
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, false>)));
+    hipLaunchKernelGGL((select_nms_kernel<NW, false>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
                        a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv);
     return DN_OK;
 }
@@ -815,13 +852,13 @@ int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes,
                    float* keptScore, int* keptAnchor, int* keptCount, hipStream_t s) {
     // 512 threads: the column scan is one batch of loads for A <= 4096, and a heavy class (up to topk candidates) spreads its
     // IoU-mask rows over 8 waves instead of 4 -- the kernel's duration is the lifetime of its heaviest workgroups
-    if (dn_knob("DN_PP_FAST_THREADS", 512) == 256) {
-        hipLaunchKernelGGL((select_nms_fast_kernel<NW, 256>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), 0, s, scoresT, boxes, a.A, a.K - 1,
-                           a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv);
-        return DN_OK;
-    }
-    hipLaunchKernelGGL((select_nms_fast_kernel<NW, 512>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(512), 0, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv);
+    const bool perm = !(a.lv.n == 1 && a.lv.aloc[0] == 1);
+    const dim3 grid((a.K - 1) * xcd_image_slots(a.xq, a.n));
+#define DN_P2F(FT, PERM) hipLaunchKernelGGL((select_nms_fast_kernel<NW, FT, PERM>), grid, dim3(FT), 0, s, scoresT, boxes, a.A, a.K - 1, a.score_thresh, \
+                                            a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv)
+    if (dn_knob("DN_PP_FAST_THREADS", 512) == 256) { if (perm) DN_P2F(256, true); else DN_P2F(256, false); }
+    else { if (perm) DN_P2F(512, true); else DN_P2F(512, false); }
+#undef DN_P2F
     return DN_OK;
 }
 
@@ -832,6 +869,28 @@ size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
     const size_t Km1 = K - 1;
     return align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) +
            align256((size_t)n * Km1 * 4) + align256((size_t)n * dn_cdiv(A, 64) * HBINS * 4 + (size_t)n * 8);
+}
+
+void postprocess_fused_targets(void* ws, int n, int A, int K, int topk, float** scores, unsigned** hist) {
+    const size_t Km1 = K - 1;
+    unsigned char* p = reinterpret_cast<unsigned char*>(ws);
+    *scores = reinterpret_cast<float*>(p);
+    p += align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) + align256((size_t)n * Km1 * 4);
+    *hist = reinterpret_cast<unsigned*>(p);        // (the first n * 256 words of the per-tile histogram rows of the unfused path)
+}
+
+void post_hist_range(float score_thresh, int* hb0_out, int* nb_out, int* clamped_out) {
+    // histogram bins that scores in (score_thresh, 1] can reach (float bits >> HSHIFT is monotone for positive floats)
+    unsigned thr_bits, one_bits;
+    const float t = score_thresh > 0.f ? score_thresh : 0.f, one = 1.0f;
+    memcpy(&thr_bits, &t, 4);
+    memcpy(&one_bits, &one, 4);
+    const int top = (int)(one_bits >> HSHIFT);
+    const int hb_thr = (int)(thr_bits >> HSHIFT);
+    const int hb0 = hb_thr > top + 1 - HBINS ? hb_thr : top + 1 - HBINS;
+    *hb0_out = hb0;
+    *nb_out = top + 1 - hb0;
+    *clamped_out = hb_thr < hb0;
 }
 
 // DN_PP_FAST=0 disables the cut-off fast path (A/B and tests of the full path); DN_PP_WANT overrides the multiple of D.
@@ -883,27 +942,30 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     const int nw = (a.topk + 63) / 64;
 
     if (ev) (void)hipEventRecord(ev[0], s);
-    // histogram bins that scores in (score_thresh, 1] can reach (float bits >> HSHIFT is monotone for positive floats)
-    unsigned thr_bits, one_bits;
-    {
-        const float t = a.score_thresh > 0.f ? a.score_thresh : 0.f, one = 1.0f;
-        memcpy(&thr_bits, &t, 4);
-        memcpy(&one_bits, &one, 4);
-    }
-    const int top = (int)(one_bits >> HSHIFT);
-    const int hb_thr = (int)(thr_bits >> HSHIFT);
-    const int hb0 = hb_thr > top + 1 - HBINS ? hb_thr : top + 1 - HBINS;
-    const int clamped = hb_thr < hb0;
-    const int nb = top + 1 - hb0;
+    int hb0, nb, clamped;
+    post_hist_range(a.score_thresh, &hb0, &nb, &clamped);
     const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)nb * sizeof(unsigned);
     const int slots = xcd_image_slots(a.xq, a.n);
-    hipLaunchKernelGGL(softmax_decode_kernel, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                       scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,
-                       a.n, tiles, a.xq, a.lv);
+    int hist_rows = tiles;          // per-image rows of the histogram table tau_kernel adds up
+    if (a.fused) {
+        // the class scores and the per-image histogram are there already (head launch epilogue): only the boxes are left to decode
+        const int btiles = dn_cdiv(a.A, 256);
+        hipLaunchKernelGGL(decode_boxes_kernel, dim3(btiles * slots), dim3(256), 0, s, a.reg, a.anchors, boxes, a.A, a.img_w, a.img_h, a.n, btiles, a.xq);
+        hist_rows = 1;
+    } else {
+        if (!(a.lv.n == 1 && a.lv.aloc[0] == 1))
+            hipLaunchKernelGGL(softmax_decode_kernel<true>, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
+                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,
+                               a.n, tiles, a.xq, a.lv);
+        else
+            hipLaunchKernelGGL(softmax_decode_kernel<false>, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
+                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,
+                               a.n, tiles, a.xq, a.lv);
+    }
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
     if (fast) {
-        hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, tiles, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq);
+        hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, hist_rows, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq);
         if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
         else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);

@@ -523,6 +523,29 @@ def test_se_tail_in_depthwise_launch_matches_se_kernel(n, knob):
     assert (res["0"][1] - res["1"][1]).abs().max().item() < 4e-2
 
 
+@pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
+                                           ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 9)])
+def test_softmax_in_the_head_epilogue_is_bit_identical(name, ncls, kw, n, monkeypatch, pp_fast):
+    """DN_HEAD_SOFTMAX=1 (round 3; opt-in, measured slower -- plan.hip): the grouped 1x1 class-head launch computes the softmax of every (pixel, anchor) in its epilogue
+    and writes the class scores + their histogram straight into the post-process workspace (stored anchor-major within a level); the
+    logits never reach memory. Same arithmetic in the same order as softmax_decode_kernel on the logits the launch would have written:
+    detections (boxes, scores, labels, counts) equal bit for bit, with the cut-off path and with the full per-class path, for a batch
+    that runs as two sub-batch chains (37), and for K = 21 (four anchors per 96-column tile, 19 x 19 / 10 x 10 ... maps: tiles span images)."""
+    size = kw.get("image_size", 320)
+    imgs = torch.from_numpy(synth.images(91, n, size, size)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_HEAD_SOFTMAX", flag)
+        m = _model(name, num_classes=ncls, **kw)
+        res[flag] = [t.clone() for t in m.forward_batch(imgs)]
+        again = m.forward_batch(imgs)                       # graph replay
+        for a, b in zip(res[flag], again):
+            assert torch.equal(a, b)
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+    assert int(res["1"][3].sum()) > 0
+
+
 def test_class_head_on_the_256_tile_matches_grouped_launch():
     """DN_PW_HEAD_BIG=1 (opt-in, measured slower -- convbig.hip): the 1x1 class head of level 0 (672 -> 546) leaves the grouped head
     launch for the 256 x 256 MFMA tile with the fp32 epilogue; its reduction length 672 is not a multiple of the 64-deep stage (the
