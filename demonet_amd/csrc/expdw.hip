@@ -60,7 +60,9 @@ __device__ __forceinline__ void act_n(V& v, int act) {
 //     depthwise needs -- without a per-element inside test, bias add or select;
 //   * activations: one uniform switch per accumulator (act_n);
 //   * every global load is unconditional with a clamped address (a predicated load costs a branch and a conservative wait).
-template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD>
+// ONE (round 3): the workgroup's run is exactly one chunk (cexp == 72 taken whole by the wide variant): the chunk loop is not a loop, so the
+// next-chunk operands and the loop-carried liveness of the expand fragments go away -- the 72-channel block spilled 64 B per lane with them.
+template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD, bool ONE = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
             }
         }
         const int cnext = c0 + cw;
-        if (cnext < c_end) request_chunk(cnext, WIDE && c_end - cnext == EW);       // lands under the depthwise stage
+        if constexpr (!ONE) { if (cnext < c_end) request_chunk(cnext, WIDE && c_end - cnext == EW); }       // lands under the depthwise stage
         if constexpr (PROJ) {
             const int co = min(pc * 32 + r, a.cout - 1);
 #pragma unroll
@@ -336,8 +338,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
                 }
             }
         }
-        __syncthreads();        // Es / Wd / Bd / Ps / Ds are rewritten by the next chunk
+        __syncthreads();        // Es / Wd / Bd / Ps / Ds are rewritten by the next chunk (and by the staged output tile)
         if (c0 == c_begin) XD_STAMP(3);
+        if constexpr (ONE) break;
         c0 = cnext;
     }
     if constexpr (PROJ) {
@@ -390,6 +393,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD>
 int launch_kw(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
     const dim3 grid(a.xq > 0 ? 8 * tiles_x : tiles_x, tiles_y * zsplit, a.xq > 0 ? a.xq : a.n);
+    if constexpr (WD && PROJ && EXP && KSM <= 2) {
+        if (a.cexp == EW && dn_knob("DN_EXPDW_ONE", 1)) {          // the whole expanded width is one 72-channel chunk
+            DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD, true>)));
+            dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
+            hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD, true>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
+            return DN_OK;
+        }
+    }
     DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>)));
     dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
     hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
