@@ -393,8 +393,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD>
 int launch_kw(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
     const dim3 grid(a.xq > 0 ? 8 * tiles_x : tiles_x, tiles_y * zsplit, a.xq > 0 ? a.xq : a.n);
-    if constexpr (WD && PROJ && EXP && KSM <= 2) {
-        if (a.cexp == EW && dn_knob("DN_EXPDW_ONE", 1)) {          // the whole expanded width is one 72-channel chunk
+    if constexpr (PROJ && EXP && KSM <= 2) {
+        if ((WD ? a.cexp == EW : a.cexp <= 64) && dn_knob("DN_EXPDW_ONE", 1)) {          // the whole expanded width is one chunk (72 channels: the wide variant)
             DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD, true>)));
             dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
             hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD, true>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
