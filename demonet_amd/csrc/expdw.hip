@@ -63,7 +63,7 @@ __device__ __forceinline__ void act_n(V& v, int act) {
 // ONE (round 3): the workgroup's run is exactly one chunk (cexp == 72 taken whole by the wide variant): the chunk loop is not a loop, so the
 // next-chunk operands and the loop-carried liveness of the expand fragments go away -- the 72-channel block spilled 64 B per lane with them.
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD, bool ONE = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4 : 2, 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4 : 2, ONE ? 8 : 4))) void expdw_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int zsplit) {
     using G = ExpDwGeom<K, S, OH, OW>;
     constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
     constexpr bool WIDE = WD && PROJ && EXP && KSM <= 2;    // may take a last chunk of 72 channels whole (WD: cexp % 64 == 8 -- the extra
