@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     unsigned* lhist = reinterpret_cast<unsigned*>(rowsum + 64);
     __shared__ int pidx[64];                   // stored (anchor-major within the level) index of the tile's anchors
     // only bins [hb0, hb0 + nb) can be hit: scores lie in (score_thr, 1] (161 bins for score_thr = 0.001; nb <= HBINS)
-    if (threadIdx.x < nb) lhist[threadIdx.x] = 0u;
+    // bins [nb, nb + K-1), when they fit the 256-entry row, count each class's passing scores: tau_kernel ranks the classes by them
+    const int ccb = (nb + K - 1 <= HBINS) ? nb : -1;
+    if (threadIdx.x < nb + (ccb >= 0 ? K - 1 : 0)) lhist[threadIdx.x] = 0u;
     const int tid = threadIdx.x;
     int n, atile;                              // flat grid [image slot][anchor tile] (XCD grouping: common.h)
     if (!xcd_image_of(blockIdx.x, tiles, xq, nimg, n, atile)) return;
@@ -137,17 +139,22 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     const int Km1 = K - 1;
     for (int idx = tid; idx < Km1 * 64; idx += 256) {
         const int k = 1 + (idx >> 6), a = idx & 63;
+        bool pass = false;
         if (a < na) {
             const float sc = tile[a * K + k] / rowsum[a];
             scoresT[((size_t)n * Km1 + (k - 1)) * A + (ident ? a0 + a : pidx[a])] = sc;
-            if (sc > score_thr) atomicAdd(&lhist[min(max((int)(__float_as_uint(sc) >> HSHIFT) - hb0, 0), nb - 1)], 1u);
+            pass = sc > score_thr;
+            if (pass) atomicAdd(&lhist[min(max((int)(__float_as_uint(sc) >> HSHIFT) - hb0, 0), nb - 1)], 1u);
         }
+        // a wave's 64 lanes hold the 64 anchors of ONE class per iteration, and no other wave or iteration sees that class
+        const unsigned long long m = __ballot(pass);
+        if (ccb >= 0 && a == 0) lhist[ccb + k - 1] = (unsigned)__popcll(m);
     }
     __syncthreads();
     PP_STAMP(11);
     // this workgroup's histogram goes to its own row; tau_kernel adds the rows. (Device-scope atomics into one per-image table
     // made a few workgroups per launch wait 15-25 us on the hot bins: the kernel's whole tail.)
-    phist[(((size_t)n * tiles + atile) << 8) + threadIdx.x] = (threadIdx.x < nb) ? lhist[threadIdx.x] : 0u;
+    phist[(((size_t)n * tiles + atile) << 8) + threadIdx.x] = (threadIdx.x < nb + (ccb >= 0 ? Km1 : 0)) ? lhist[threadIdx.x] : 0u;
     if (tid < na) {
         const int a = a0 + tid;
         const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
@@ -534,7 +541,8 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
 // with score < tau ranks below them and cannot appear in the output. Otherwise needFull[n] triggers the full path.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ phist, int tiles, int hb0, int clamped, unsigned want,
-                                                 unsigned* __restrict__ tauKey, int* __restrict__ needFull, int nimg, int xq) {
+                                                 unsigned* __restrict__ tauKey, int* __restrict__ needFull, int nimg, int xq,
+                                                 int nb, int Km1, int* __restrict__ order) {
     __shared__ unsigned part[256];
     const int tid = threadIdx.x;
     int n, unused;
@@ -552,13 +560,25 @@ __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ p
     part[tid] = s;
     __syncthreads();
     unsigned above = 0;
-    for (int t = tid + 1; t < 256; ++t) above += part[t];
+    for (int t = tid + 1; t < nb; ++t) above += part[t];
     // the unique thread where the suffix count (from the top bin down) crosses `want`: tau = lower edge of its bin. Bin 0 of a
     // clamped table also holds every lower score -> tau 0 (take everything above the score threshold).
-    if (above < want && above + s >= want) tauKey[n] = (clamped && tid == 0) ? 0u : (unsigned)(hb0 + tid) << HSHIFT;
+    if (tid < nb && above < want && above + s >= want) tauKey[n] = (clamped && tid == 0) ? 0u : (unsigned)(hb0 + tid) << HSHIFT;
+    // classes by descending count of passing scores (ties: ascending class): the per-class workgroups of the next launch are
+    // dispatched in this order, the heavy ones first, so the launch does not end on a late-started heavy class. No counts
+    // (fused epilogue, or the row has no room): all zero -> identity.
+    if (nb + Km1 <= HBINS) {
+        if (tid >= nb && tid < nb + Km1) {
+            int rank = 0;
+            for (int t = nb; t < nb + Km1; ++t) rank += (part[t] > s || (part[t] == s && t < tid)) ? 1 : 0;
+            order[(size_t)n * Km1 + rank] = tid - nb;
+        }
+    } else {
+        for (int c = tid; c < Km1; c += 256) order[(size_t)n * Km1 + c] = c;
+    }
     if (tid == 0) {
         unsigned total = 0;
-        for (int t = 0; t < 256; ++t) total += part[t];
+        for (int t = 0; t < nb; ++t) total += part[t];
         if (total < want) tauKey[n] = 0u;        // fewer passing scores than wanted: take everything
         needFull[n] = 0;
     }
@@ -574,7 +594,8 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
                                                              int A, int Km1, float score_thr, float nms_thr, int topk,
                                                              const unsigned* __restrict__ tauKey, int* __restrict__ needFull,
                                                              float* __restrict__ keptScore, int* __restrict__ keptAnchor,
-                                                             int* __restrict__ keptCount, long long* __restrict__ stamps, int nimg, int xq, PostLevels lv) {
+                                                             int* __restrict__ keptCount, long long* __restrict__ stamps, int nimg, int xq, PostLevels lv,
+                                                             const int* __restrict__ order) {
     constexpr int MC = 64 * NW;
     constexpr int CAP = (64 * NW * NW < 2048) ? 64 * NW * NW : 2048;      // candidate list (>= MC); the sort scratch aliases the IoU mask
     static_assert(CAP >= MC && CAP <= MC * NW, "sort scratch must fit the mask array");
@@ -586,8 +607,22 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
     __shared__ float carea[MC];
     __shared__ unsigned cnt_sh;
     const int tid = threadIdx.x;
-    int n, cls;                          // flat grid [image slot][class]
-    if (!xcd_image_of(blockIdx.x, Km1, xq, nimg, n, cls)) return;
+    int n, cls;
+    if (order) {
+        // flat grid [rank][image slot]: every image's heaviest class first (tau_kernel's order), the light ones fill in behind
+        const int flat = blockIdx.x;
+        int rank;
+        if (xq > 0) {
+            const int w = flat >> 3;
+            rank = w / xq;
+            n = (flat & 7) * xq + (w - rank * xq);
+        } else {
+            rank = flat / nimg;
+            n = flat - rank * nimg;
+        }
+        if (n >= nimg) return;
+        cls = order[(size_t)n * Km1 + rank];
+    } else if (!xcd_image_of(blockIdx.x, Km1, xq, nimg, n, cls)) return;      // flat grid [image slot][class]
     const float* col = scoresT + ((size_t)n * Km1 + cls) * A;
     const unsigned tau = tauKey[n];
     PP_STAMP(0);
@@ -849,13 +884,13 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
 
 template <int NW>
 int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes, const unsigned* tauKey, int* needFull,
-                   float* keptScore, int* keptAnchor, int* keptCount, hipStream_t s) {
+                   float* keptScore, int* keptAnchor, int* keptCount, const int* order, hipStream_t s) {
     // 512 threads: the column scan is one batch of loads for A <= 4096, and a heavy class (up to topk candidates) spreads its
     // IoU-mask rows over 8 waves instead of 4 -- the kernel's duration is the lifetime of its heaviest workgroups
     const bool perm = !(a.lv.n == 1 && a.lv.aloc[0] == 1);
     const dim3 grid((a.K - 1) * xcd_image_slots(a.xq, a.n));
 #define DN_P2F(FT, PERM) hipLaunchKernelGGL((select_nms_fast_kernel<NW, FT, PERM>), grid, dim3(FT), 0, s, scoresT, boxes, a.A, a.K - 1, a.score_thresh, \
-                                            a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv)
+                                            a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv, order)
     if (dn_knob("DN_PP_FAST_THREADS", 512) == 256) { if (perm) DN_P2F(256, true); else DN_P2F(256, false); }
     else { if (perm) DN_P2F(512, true); else DN_P2F(512, false); }
 #undef DN_P2F
@@ -868,7 +903,7 @@ size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
     (void)dets;
     const size_t Km1 = K - 1;
     return align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) +
-           align256((size_t)n * Km1 * 4) + align256((size_t)n * dn_cdiv(A, 64) * HBINS * 4 + (size_t)n * 8);
+           align256((size_t)n * Km1 * 4) + align256((size_t)n * dn_cdiv(A, 64) * HBINS * 4 + (size_t)n * (8 + 4 * Km1));
 }
 
 void postprocess_fused_targets(void* ws, int n, int A, int K, int topk, float** scores, unsigned** hist) {
@@ -932,6 +967,7 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     unsigned* phist = reinterpret_cast<unsigned*>(p);                      // [n][tiles][HBINS], then tauKey[n], needFull[n]
     unsigned* tauKey = phist + (size_t)a.n * tiles * HBINS;
     int* needFull = reinterpret_cast<int*>(tauKey + a.n);
+    int* order = needFull + a.n;                                           // [n][K-1] classes, heaviest first (tau_kernel)
 
     const int fast = dn_knob("DN_PP_FAST", 1);
     // candidates per image kept by the cut-off, as a multiple of D. Any value is exact (too few survivors -> device-side
@@ -944,7 +980,7 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     if (ev) (void)hipEventRecord(ev[0], s);
     int hb0, nb, clamped;
     post_hist_range(a.score_thresh, &hb0, &nb, &clamped);
-    const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)nb * sizeof(unsigned);
+    const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)HBINS * sizeof(unsigned);
     const int slots = xcd_image_slots(a.xq, a.n);
     int hist_rows = tiles;          // per-image rows of the histogram table tau_kernel adds up
     if (a.fused) {
@@ -965,12 +1001,14 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
     if (fast) {
-        hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, hist_rows, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq);
-        if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
-        else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
-        else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
-        else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
-        else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, s);
+        hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, hist_rows, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq,
+                           nb, (int)Km1, order);
+        const int* ord = dn_knob("DN_PP_ORDER", 1) ? order : nullptr;      // heaviest classes first (0: class order)
+        if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
+        else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
+        else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
+        else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
+        else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         if (dn_knob("DN_MERGE_THREADS", 1024) == 256)
             hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
                                (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed, a.n, a.xq);
