@@ -34,6 +34,12 @@ const char* dn_last_kernel();
         }                                                                                    \
     } while (0)
 
+// ReLU / ReLU6 in ONE instruction each. fmaxf / fminf make hipcc quiet a possible signalling NaN first (`v_max_f32 v, v, v`) whenever the operand does
+// not come from an arithmetic instruction it knows -- MFMA results, inline-asm v_fma_mix_f32 sums -- i.e. two instructions per value in epilogues
+// that are bound by vector-instruction issue (round 3: 28 000 such pairs in the expdw object alone). Same values for every non-NaN input.
+__device__ __forceinline__ float dn_relu(float v) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ float dn_relu6(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
+
 __device__ __forceinline__ float dn_act(float v, int act) {
     // Hardswish x*relu6(x+3)/6, ReLU6 clamp [0,6] (mobilenetv3.py:72, ssd_mobilenetv3.py:31).
     // Branch-free: `act` is wave-uniform (a kernel argument), so the bounds and the selector are scalar selects computed once, and
@@ -114,13 +120,13 @@ template <typename V, int N>
 __device__ __forceinline__ void dn_act_n(V& v, int act) {
     if (act == DN_ACT_RELU) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < N; ++e) v[e] = dn_relu(v[e]);
     } else if (act == DN_ACT_RELU6) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+        for (int e = 0; e < N; ++e) v[e] = dn_relu6(v[e]);
     } else if (act == DN_ACT_HSWISH) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        for (int e = 0; e < N; ++e) v[e] = v[e] * dn_relu6(v[e] + 3.f) * (1.f / 6.f);
     }
 }
 

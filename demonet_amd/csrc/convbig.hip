@@ -48,10 +48,9 @@ __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[TC][TP], const PwA
                 const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
                 const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                 half4 hv;
-                hv[0] = (half_t)dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
-                hv[1] = (half_t)dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
-                hv[2] = (half_t)dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
-                hv[3] = (half_t)dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
+                dn_act_n<float[4], 4>(t4, a.act);
+                hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
                 *reinterpret_cast<half4*>(&ot[prow * ORW + cl]) = hv;
             }
         }
@@ -94,10 +93,9 @@ __device__ __forceinline__ void conv_epilogue_fp32(floatx16 (&acc)[TC][TP], cons
                         const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
                         const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                         float4 v;
-                        v.x = dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
-                        v.y = dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
-                        v.z = dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
-                        v.w = dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                        float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
+                        dn_act_n<float[4], 4>(t4, a.act);
+                        v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
                         *reinterpret_cast<float4*>(&ot[prow * FROW + cl]) = v;
                     }
                 }
@@ -675,10 +673,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
                 const int cl = i * 32 + 8 * g + 4 * hh;
                 const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                 half4 hv;
-                hv[0] = (half_t)dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
-                hv[1] = (half_t)dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
-                hv[2] = (half_t)dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
-                hv[3] = (half_t)dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
+                dn_act_n<float[4], 4>(t4, a.act);
+                hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
                 *reinterpret_cast<half4*>(&ot[prow * 72 + cl]) = hv;
             }
     }

@@ -341,10 +341,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
                         const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
                         const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                         float4 v;
-                        v.x = dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
-                        v.y = dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
-                        v.z = dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
-                        v.w = dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                        float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
+                        dn_act_n<float[4], 4>(t4, a.act);
+                        v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
                         *reinterpret_cast<float4*>(&otf[prow * FROW + cl]) = v;
                     }
                 }
@@ -381,10 +380,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
                     const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
                     const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                     half4 hv;
-                    hv[0] = (half_t)dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
-                    hv[1] = (half_t)dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
-                    hv[2] = (half_t)dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
-                    hv[3] = (half_t)dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                    float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
+                    dn_act_n<float[4], 4>(t4, a.act);
+                    hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
                     *reinterpret_cast<half4*>(&ot[prow * OROW + cl]) = hv;
                 }
             }
@@ -417,10 +415,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
                     const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
                     const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                     float4 v;
-                    v.x = dn_act(acc[i][j][4 * g + 0] + bv.x, a.act);
-                    v.y = dn_act(acc[i][j][4 * g + 1] + bv.y, a.act);
-                    v.z = dn_act(acc[i][j][4 * g + 2] + bv.z, a.act);
-                    v.w = dn_act(acc[i][j][4 * g + 3] + bv.w, a.act);
+                    float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
+                    dn_act_n<float[4], 4>(t4, a.act);
+                    v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
                     *reinterpret_cast<float4*>(&ot[prow * FROW + cl]) = v;
                 }
             }
@@ -589,8 +586,7 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
                 const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
                 float v[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z,
                               acc[i][j][4 * g + 3] + bv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = dn_act(v[e], a.act);
+                dn_act_n<float[4], 4>(v, a.act);
                 if (dbg & 1) {
                     if (v[0] == 123.456f) reinterpret_cast<float*>(a.out)[0] = v[1];
                 } else if (a.out_fp32) {
@@ -802,8 +798,7 @@ __global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a, int tiles) {
                 if (c0 >= NC) continue;
                 float v[4] = {acc[j][4 * g + 0] + bv[g].x, acc[j][4 * g + 1] + bv[g].y, acc[j][4 * g + 2] + bv[g].z,
                               acc[j][4 * g + 3] + bv[g].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = dn_act(v[e], a.act);
+                dn_act_n<float[4], 4>(v, a.act);
                 if (a.out_fp32) {
                     float* o = reinterpret_cast<float*>(a.out) + obase[j] + c0;
 #pragma unroll

@@ -31,13 +31,13 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void act16(floatx16& v, int act) {
     if (act == DN_ACT_RELU) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 16; ++e) v[e] = dn_relu(v[e]);
     } else if (act == DN_ACT_RELU6) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+        for (int e = 0; e < 16; ++e) v[e] = dn_relu6(v[e]);
     } else if (act == DN_ACT_HSWISH) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        for (int e = 0; e < 16; ++e) v[e] = v[e] * dn_relu6(v[e] + 3.f) * (1.f / 6.f);
     }
 }
 

@@ -136,10 +136,9 @@ __global__ __launch_bounds__(TT) void tail_kernel(TailArgs a, int nimg) {
                             if (c < N) {            // cout % 8 == 0
                                 const float4 b = bq[g];
                                 half4 hv;
-                                hv[0] = (half_t)dn_act(acc[4 * g + 0] + b.x, o.act);
-                                hv[1] = (half_t)dn_act(acc[4 * g + 1] + b.y, o.act);
-                                hv[2] = (half_t)dn_act(acc[4 * g + 2] + b.z, o.act);
-                                hv[3] = (half_t)dn_act(acc[4 * g + 3] + b.w, o.act);
+                                float t4[4] = {acc[4 * g + 0] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w};
+                                dn_act_n<float[4], 4>(t4, o.act);
+                                hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
                                 *reinterpret_cast<half4*>(y + (size_t)r * (N + 8) + c) = hv;
                                 if (yg) *reinterpret_cast<half4*>(yg + (size_t)r * N + c) = hv;
                             }
@@ -209,8 +208,9 @@ __global__ __launch_bounds__(TT) void tail_kernel(TailArgs a, int nimg) {
                     }
                 }
                 half8 hv;
+                dn_act_n<float[8], 8>(acc, o.act);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = (half_t)dn_act(acc[e], o.act);
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)acc[e];
                 *reinterpret_cast<half8*>(y + (size_t)p * (C + 8) + cg * 8) = hv;
                 if (yg) *reinterpret_cast<half8*>(yg + (size_t)p * C + cg * 8) = hv;
             }

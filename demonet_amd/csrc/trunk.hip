@@ -137,10 +137,9 @@ __global__ __launch_bounds__(TT) void trunk_kernel(TrunkArgs a, int nimg) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             half4 hv;
-                            hv[0] = (half_t)dn_act(acc[4 * g + 0] + bv[g].x, B.act1);
-                            hv[1] = (half_t)dn_act(acc[4 * g + 1] + bv[g].y, B.act1);
-                            hv[2] = (half_t)dn_act(acc[4 * g + 2] + bv[g].z, B.act1);
-                            hv[3] = (half_t)dn_act(acc[4 * g + 3] + bv[g].w, B.act1);
+                            float t4[4] = {acc[4 * g + 0] + bv[g].x, acc[4 * g + 1] + bv[g].y, acc[4 * g + 2] + bv[g].z, acc[4 * g + 3] + bv[g].w};
+                            dn_act_n<float[4], 4>(t4, B.act1);
+                            hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
                             *reinterpret_cast<half4*>(erow + 8 * g) = hv;
                         }
                     }
