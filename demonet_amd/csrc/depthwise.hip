@@ -807,6 +807,191 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ p
     SE_STAMP(3);
 }
 
+// Round 3: the same three phases with every global load 16 bytes wide and ONE round trip per phase where the sizes allow (c % 8 == 0,
+// sq % 8 == 0 -- every squeeze-excitation of the zoo). A thread owns 8 adjacent outputs of an FC and a slice of its reduction axis: 14 loads
+// per thread and FC for the 672 / 168 blocks (the 4-byte form walked 56 rows in two batches of 32), the pooled partial rows are read as
+// float4 by (4 channels, row slice) threads in one batch, the first fc1 batch is requested together with the partial rows and the first fc2
+// batch before the fc1 slices are combined, so the kernel is three exposed round trips instead of six to seven. Weights are fp16 operands
+// of v_fma_mix_f32 against the fp32 mean / z (no conversions). Sums run in a different order than se_fc_kernel: equal up to fp32 rounding.
+__device__ __forceinline__ void se_fma8(float (&acc)[8], const unsigned __attribute__((ext_vector_type(4))) & w, float m) {
+    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * i]) : "v"(ww[i]), "v"(m));
+        asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * i + 1]) : "v"(ww[i]), "v"(m));
+    }
+}
+
+typedef float se_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned se_u4 __attribute__((ext_vector_type(4)));
+// 16-byte load from a uniform base + 32-bit byte offset, as an asm volatile statement: these keep their program order among themselves (LLVM sinks
+// ordinary loads to their first use -- the partial rows would land BEHIND the weight requests -- and a sched_barrier only binds the machine
+// scheduler), and the waits for them are written by hand below (the compiler does not count asm loads).
+__device__ __forceinline__ void se_load16(se_u4& v, const void* base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void se_load16(se_f4& v, const void* base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+}
+// "at most N vector-memory operations still in flight" with the registers the wait protects tied to it (their uses cannot move above it)
+template <int FB>
+__device__ __forceinline__ void se_wait_w(se_u4 (&a)[FB]) {       // every weight row of the batch has arrived
+    static_assert(FB == 14 || FB == 15, "operand lists below");
+    if constexpr (FB == 14)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                     "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]));
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                     "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]));
+}
+template <int FB, int PB, bool ALL>
+__device__ __forceinline__ void se_wait_p(se_f4 (&a)[PB]) {       // the partial rows have arrived; !ALL: the FB weight rows requested behind them stay in flight
+    static_assert(PB == 4 || PB == 6, "operand lists below");
+    if constexpr (PB == 6) {
+        if constexpr (ALL) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+        else if constexpr (FB == 14) asm volatile("s_waitcnt vmcnt(14)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+        else asm volatile("s_waitcnt vmcnt(15)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+    } else {
+        if constexpr (ALL) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+        else if constexpr (FB == 14) asm volatile("s_waitcnt vmcnt(14)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+        else asm volatile("s_waitcnt vmcnt(15)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    }
+}
+
+template <int FB, int PB>       // 16-byte weight rows / partial rows in flight per thread: (14, 6), or (15, 4) for the 960 / 240 blocks (29 - 30 rows per slice)
+__global__ __launch_bounds__(1024) void se_fc8_kernel(const float* __restrict__ partial, int nblk, const half_t* __restrict__ w1t,
+                                                    const float* __restrict__ b1, const half_t* __restrict__ w2t,
+                                                    const float* __restrict__ b2, float* __restrict__ scale,
+                                                    int c, int sq, float inv_pixels, long long* __restrict__ stamps, int nimg, int xq, int rot_step) {
+    extern __shared__ float sh[];      // mean[c], z[sq], part[max(RS * c, KS1 * sq, KS2 * c)]
+    float* mean = sh;
+    float* z = sh + c;
+    float* part = z + sq;
+    int n, unused;
+    if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
+    const int tid = threadIdx.x;
+    SE_STAMP(0);
+    // roles
+    const int C4 = c >> 2, RS = max(1, min(1024 / C4, nblk));
+    const int ic4 = tid % C4, rr = tid / C4;
+    const bool actm = rr < RS;
+    const int G1 = sq >> 3, KS1 = max(1, min(1024 / G1, c >> 3));          // >= 8 rows per slice; KS1 * sq <= 8192 floats of LDS
+    // (slice -> thread assignment rotated by the image: 64 workgroups walking the same weight rows in the same order at the same moment all
+    //  queue on the same L2 channel; the slices themselves, and the order they are combined in, do not change)
+    const int rot = rot_step * n;
+    const int j8 = tid % G1, r1s = tid / G1;
+    const bool act1 = r1s < KS1;
+    const int r1 = act1 ? (r1s + rot) % KS1 : r1s;
+    const int per1 = (c + KS1 - 1) / KS1;
+    const int i0 = min(r1 * per1, c), i1 = min(c, i0 + per1);
+    const int G2 = c >> 3, KS2 = max(1, min(1024 / G2, sq >> 3));
+    const int i8 = tid % G2, r2s = tid / G2;
+    const bool act2 = r2s < KS2;
+    const int r2 = act2 ? (r2s + rot) % KS2 : r2s;
+    const int per2 = (sq + KS2 - 1) / KS2;
+    const int j0 = min(r2 * per2, sq), j1 = min(sq, j0 + per2);
+    // (the two biases too: a compiler-generated load in front of the asm loads gets a full wait before the first of them)
+    float b1v, b2v;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(b1v) : "v"((unsigned)min(tid, sq - 1) * 4u), "s"(b1) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(b2v) : "v"((unsigned)min(tid, c - 1) * 4u), "s"(b2) : "memory");
+    // ---- requests: the partial rows of this thread's (4 channels, slice), then the first batch of its fc1 weight rows. Unconditional, clamped.
+    const float* pbase = partial + (size_t)n * nblk * c;
+    const unsigned pcol = (unsigned)min(ic4, C4 - 1) * 16u, prs = (unsigned)C4 * 16u;
+    const int rrc = min(rr, RS - 1);
+    se_f4 pv[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) se_load16(pv[u], pbase, pcol + (unsigned)min(rrc + u * RS, nblk - 1) * prs);
+    const unsigned w1col = (unsigned)min(j8, G1 - 1) * 16u, w1rs = (unsigned)G1 * 16u;
+    se_u4 wv[FB];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) se_load16(wv[u], w1t, w1col + (unsigned)min(i0 + u, c - 1) * w1rs);
+    // ---- pooled mean
+    {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        se_wait_p<FB, PB, false>(pv);
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const float ok = (rrc + u * RS < nblk) ? 1.f : 0.f;
+            t.x = fmaf(pv[u].x, ok, t.x); t.y = fmaf(pv[u].y, ok, t.y); t.z = fmaf(pv[u].z, ok, t.z); t.w = fmaf(pv[u].w, ok, t.w);
+        }
+        for (int bb = PB * RS; bb < nblk; bb += PB * RS) {         // more partial rows than one batch covers (uniform bound)
+#pragma unroll
+            for (int u = 0; u < PB; ++u) se_load16(pv[u], pbase, pcol + (unsigned)min(rrc + bb + u * RS, nblk - 1) * prs);
+            se_wait_p<FB, PB, true>(pv);
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const float ok = (rrc + bb + u * RS < nblk) ? 1.f : 0.f;
+                t.x = fmaf(pv[u].x, ok, t.x); t.y = fmaf(pv[u].y, ok, t.y); t.z = fmaf(pv[u].z, ok, t.z); t.w = fmaf(pv[u].w, ok, t.w);
+            }
+        }
+        if (actm) *reinterpret_cast<float4*>(&part[rr * c + ic4 * 4]) = t;
+        __syncthreads();
+        if (tid < c) {
+            float m = 0.f;
+            for (int q = 0; q < RS; ++q) m += part[q * c + tid];
+            mean[tid] = m * inv_pixels;
+        }
+        __syncthreads();
+    }
+    SE_STAMP(1);
+    const unsigned w2col = (unsigned)min(i8, G2 - 1) * 16u, w2rs = (unsigned)G2 * 16u;
+    // ---- fc1: z[j] = relu(b1[j] + sum_i w1t[i][j] * mean[i])
+    {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        se_wait_w<FB>(wv);
+        asm volatile("" : "+v"(b1v), "+v"(b2v));        // (their uses stay below the wait as well)
+#pragma unroll
+        for (int u = 0; u < FB; ++u) se_fma8(acc, wv[u], (i0 + u < i1) ? mean[i0 + u] : 0.f);
+        for (int bb = FB; bb < per1; bb += FB) {                    // (uniform bound)
+#pragma unroll
+            for (int u = 0; u < FB; ++u) se_load16(wv[u], w1t, w1col + (unsigned)min(i0 + bb + u, c - 1) * w1rs);
+            se_wait_w<FB>(wv);
+#pragma unroll
+            for (int u = 0; u < FB; ++u) se_fma8(acc, wv[u], (i0 + bb + u < i1) ? mean[i0 + bb + u] : 0.f);
+        }
+        // the first fc2 batch is on its way while the slices are combined
+#pragma unroll
+        for (int u = 0; u < FB; ++u) se_load16(wv[u], w2t, w2col + (unsigned)min(j0 + u, sq - 1) * w2rs);
+        if (act1) {
+            *reinterpret_cast<float4*>(&part[r1 * sq + j8 * 8]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(&part[r1 * sq + j8 * 8 + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        __syncthreads();
+        if (tid < sq) {
+            float a = b1v;                             // (requested first, long arrived: se_wait_w above waited for everything)
+            for (int q = 0; q < KS1; ++q) a += part[q * sq + tid];
+            z[tid] = dn_relu(a);
+        }
+        __syncthreads();
+    }
+    SE_STAMP(2);
+    // ---- fc2: scale[i] = hardsigmoid(b2[i] + sum_j w2t[j][i] * z[j])
+    {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        se_wait_w<FB>(wv);
+#pragma unroll
+        for (int u = 0; u < FB; ++u) se_fma8(acc, wv[u], (j0 + u < j1) ? z[j0 + u] : 0.f);
+        for (int bb = FB; bb < per2; bb += FB) {
+#pragma unroll
+            for (int u = 0; u < FB; ++u) se_load16(wv[u], w2t, w2col + (unsigned)min(j0 + bb + u, sq - 1) * w2rs);
+            se_wait_w<FB>(wv);
+#pragma unroll
+            for (int u = 0; u < FB; ++u) se_fma8(acc, wv[u], (j0 + bb + u < j1) ? z[j0 + bb + u] : 0.f);
+        }
+        if (act2) {
+            *reinterpret_cast<float4*>(&part[r2 * c + i8 * 8]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(&part[r2 * c + i8 * 8 + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        __syncthreads();
+        if (tid < c) {
+            float a = b2v;
+            for (int q = 0; q < KS2; ++q) a += part[q * c + tid];
+            scale[(size_t)n * c + tid] = dn_relu6(a + 3.f) * (1.f / 6.f);
+        }
+    }
+    SE_STAMP(3);
+}
+
 // ---- stem: dense kxk conv on the NCHW fp32 image, normalisation on load, NHWC fp16 out ------------------
 // One thread per output pixel, all COUT channels. The weights are wave-uniform: indexing the kernel-argument pointer
 // with compile-time offsets makes hipcc fetch them with s_load (scalar cache) and feed them as SGPR operands of
@@ -1100,6 +1285,19 @@ bool depthwise_se_tail_supported(int c, int squeeze) { return c % 8 == 0 && sque
 int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b1, const void* w2t, const float* b2, float* scale,
                  int n, int c, int squeeze, int pool_pixels, hipStream_t s, int xq) {
     DN_REQUIRE(c <= 1024 && squeeze <= 256 && c % 2 == 0 && squeeze % 2 == 0, "se: c=%d squeeze=%d outside the kernel's range (even, <= 1024 / 256)", c, squeeze);
+    if (c % 8 == 0 && squeeze % 8 == 0 && c >= 8 && squeeze >= 8 && dn_knob("DN_SE_FC8", 1)) {
+        const int C4 = c >> 2, RS = std::max(1, std::min(1024 / C4, nblk));
+        const int KS1 = std::max(1, std::min(1024 / (squeeze >> 3), c >> 3)), KS2 = std::max(1, std::min(1024 / (c >> 3), squeeze >> 3));
+        const size_t pf = (size_t)std::max(std::max(RS * c, KS1 * squeeze), KS2 * c);
+        dn_note_kernel("se_fc8_kernel");
+        const int per1 = dn_cdiv(c, KS1), per2 = dn_cdiv(squeeze, KS2);
+        const bool wide = (per1 > 14 || per2 > 14) && nblk <= 4 * RS;          // two batches of 15 instead of three of 14
+        auto k = wide ? se_fc8_kernel<15, 4> : se_fc8_kernel<14, 6>;
+        hipLaunchKernelGGL(k, dim3(xq > 0 ? 8 * xq : n), dim3(1024), (size_t)(c + squeeze + pf) * sizeof(float), s, partial, nblk,
+                           reinterpret_cast<const half_t*>(w1t), b1, reinterpret_cast<const half_t*>(w2t), b2, scale, c, squeeze,
+                           1.0f / (float)pool_pixels, g_se_stamps, n, xq, dn_knob("DN_SE_ROT", 5));
+        return DN_OK;
+    }
     dn_note_kernel("se_fc_kernel");
     hipLaunchKernelGGL(se_fc_kernel, dim3(xq > 0 ? 8 * xq : n), dim3(1024), (size_t)(c + squeeze + 2048) * sizeof(float), s, partial, nblk,
                        reinterpret_cast<const unsigned*>(w1t), b1, reinterpret_cast<const unsigned*>(w2t), b2, scale, c, squeeze,

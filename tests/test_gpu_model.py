@@ -497,14 +497,16 @@ def test_se_fold_matches_separate_se_kernel(n):
     assert (res["0"][1] - res["1"][1]).abs().max().item() < 4e-2
 
 
-@pytest.mark.parametrize("knob", ["DN_SE_IN_DW", "DN_SE_SMALL"])
+@pytest.mark.parametrize("knob", ["DN_SE_IN_DW", "DN_SE_SMALL", "DN_SE_FC8"])
 @pytest.mark.parametrize("n", [3, 37])
 def test_se_tail_in_depthwise_launch_matches_se_kernel(n, knob):
     """DN_SE_IN_DW=1 (opt-in, measured slower -- plan.hip): the FCs of the large squeeze-excitations run in the last workgroup of
     the pooling depthwise launch (device-scope atomic publish + ticket) instead of the se_fc launch; DN_SE_SMALL=1 does that for the
     small squeeze-excitations only (instead of the projection-prologue fold) and runs their projections on the register-direct
     kernel with the scale applied to its x fragments. Same arithmetic up to the order of the fp32 sums, i.e. the decorrelation
-    noise of test_se_fold_matches_separate_se_kernel; a second forward checks that the counters were left at zero."""
+    noise of test_se_fold_matches_separate_se_kernel; a second forward checks that the counters were left at zero.
+    DN_SE_FC8 (round 3, default on): the se_fc launch with 16-byte loads, asm-ordered requests and hand-written waits (se_fc8_kernel)
+    against the 4-byte form (se_fc_kernel): the same three phases with the K slices cut differently."""
     imgs = torch.from_numpy(synth.images(67, n, 320, 320)).cuda()
     res = {}
     for flag in ("0", "1"):
