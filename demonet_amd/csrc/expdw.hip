@@ -430,7 +430,10 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     int cpw = chunks;
     while (!proj && cpw > 1 && (long)tiles * a.n * dn_cdiv(chunks, cpw) < want) --cpw;
     a.chunks_per_wg = cpw;
-    a.stamps = g_xd_stamps;
+    {   // dev: DN_EXPDW_STAMP_SEL = 10 * H + stride stamps only the launches of that shape (every launch writes the same buffer)
+        const int sel = g_xd_stamps ? dn_knob("DN_EXPDW_STAMP_SEL", 0) : 0;
+        a.stamps = (sel == 0 || sel == 10 * a.H + S) ? g_xd_stamps : nullptr;
+    }
     if (proj) {
         // the output tile is staged over the E .. depthwise-output buffers (everything between the X rows and the project bias)
         const size_t avail = ((exp ? (size_t)G::ROWS * EW : 0) + K * K * EW + (size_t)DROWS * EW) * sizeof(half_t) + (EW + NT / 64 * 64) * sizeof(float);
