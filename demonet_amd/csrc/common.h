@@ -186,6 +186,8 @@ struct DwArgs;
 bool pw_dw_direct_supported(const PwArgs& a, const DwArgs& d);      // depthwise 3x3 + the 1x1 behind it in one register-direct launch (pwdirect.hip)
 int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s);
 int launch_pw_head_big(const PwArgs& a, hipStream_t s);
+bool head_xs_supported(const PwArgs& a);      // X-stationary 1x1 class head of a large level (pointwise.hip)
+int launch_head_xs(const PwArgs& a, hipStream_t s);
 
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;

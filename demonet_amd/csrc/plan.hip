@@ -1032,6 +1032,14 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                     const dn_tensor_desc& th = p->tensors[p->ops[lst[q]].in];
                     pb.cv_k = 1; pb.cv_stride = 1; pb.cv_pad = 0; pb.cv_dil = 1; pb.cv_h = pb.cv_ho = th.h; pb.cv_w = pb.cv_wo = th.w; pb.cv_cin = pb.cin;
                     pb.zeros = reinterpret_cast<const half_t*>(Wb + p->zeros_off);
+                    if (head_xs_supported(pa)) {
+                        rc = launch_head_xs(pa, hs);
+                        if (rc != DN_OK) return rc;
+                        hnote(lst[q], seg);
+                        ++seg;
+                        if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
+                        continue;
+                    }
                     if (!pa.sm_scores && pw_head_big_supported(pb)) {
                         rc = launch_pw_head_big(pb, hs);
                         if (rc != DN_OK) return rc;

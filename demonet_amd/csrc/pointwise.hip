@@ -859,6 +859,225 @@ int launch_cfg(const PwArgs& a, hipStream_t s) {
     return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 2);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// X-stationary 1x1 class head of a LARGE pyramid level (round 3): SSDLite level 0 is 672 -> 546 on 20 x 20 pixels, a quarter of the
+// network's multiply-adds, and the tiled kernel above spends ~1.4 us per 32-deep K stage on it (global -> LDS -> barrier -> 6 MFMAs per
+// wave, three workgroups per CU; each 128 x 96 tile re-reads its pixel rows for every one of the 6 channel tiles: 620 MB through L2
+// for a 34 MB input). Here a 512-thread workgroup owns `bp` consecutive pixels (bp divides h*w: the strip lies in one image and its
+// [bp][cout] fp32 output block is ONE contiguous run of the logits array):
+//   1. the strip's rows x[bp][K] go to LDS once (row stride K + 8 halfs = an odd number of 16-byte slots), every load in flight together;
+//   2. wave w = channel-tile pair w (64 output columns) x all row tiles: per 16-deep K step two A fragments come straight from L2 out of the
+//      fragment-major weight copy (1 KB contiguous per wave load, chunks of KC steps double-buffered in registers) and four B fragments
+//      from LDS feed eight MFMAs -- 64 B/clk of LDS reads and 32 B/clk of L1 per CU at full MFMA rate; a pair beyond the eighth is split
+//      by row tile over the waves so that every SIMD runs the same number of matrix instructions;
+//   3. the finished columns leave through LDS (over the dead strip) in two passes as row-contiguous 8-byte runs.
+// One accumulator per output, K walked in order, bias added in fp32 afterwards: the same arithmetic as pw_body, logits equal bit for bit
+// (test_head_xs_logits_bit_identical).
+// MEASURED (round 3, batch 64) and left OFF (DN_HEAD_XS=1 opts in): 45 us for the level-0 class head + 42 us for the rest of the grouped launch against
+// 88 - 90 us for the grouped launch with it: one forward at a time 0.938 -> 0.934 ms, in flight level (0.712 / 0.711). tools/probe_head_xs.py, per
+// workgroup: strip 5.5 us (34 MB at the HBM rate: it is the depthwise group's output), the split units 7.7 us (four dependent L2 round trips of ~2 us with
+// every CU walking the same weight rows), the pairs 11 us (two waves per SIMD x 4.5 us of matrix instructions), output 7.6 us (56 MB at the HBM rate) --
+// with 136 KB of LDS there is ONE workgroup per CU and nothing overlaps its four phases, where the tiled kernel overlaps three workgroups per CU. What it
+// would take: the phases of two half-size strips pipelined inside one workgroup (the output staging then has no room in LDS), or 128 registers per wave.
+template <int NR, int KC>
+__device__ __forceinline__ void head_xs_task(const PwArgs& a, const half_t* xs, int KP, int NCH, int rows, int nt0, int NT, int j0,
+                                             int lane, floatx16 (&acc)[2][NR]) {
+    const int r = lane & 31, hh = lane >> 5;
+    const int KS = NCH * KC;
+    const half_t* w0 = a.wfrag + (size_t)nt0 * KS * 512 + lane * 8;
+    const half_t* w1 = a.wfrag + (size_t)min(nt0 + 1, NT - 1) * KS * 512 + lane * 8;
+    const half_t* xr[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) xr[j] = xs + min((j0 + j) * 32 + r, rows - 1) * KP + hh * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    half8 wa[2][KC], wb[2][KC], wc[2][KC];
+    auto load_w = [&](half8 (&wf)[2][KC], int ch) {        // unconditional, clamped chunk index (a load behind a branch costs a full wait at the join)
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            wf[0][u] = *reinterpret_cast<const half8*>(w0 + (size_t)(ch * KC + u) * 512);
+            wf[1][u] = *reinterpret_cast<const half8*>(w1 + (size_t)(ch * KC + u) * 512);
+        }
+    };
+    auto compute = [&](const half8 (&wf)[2][KC], int ch) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const half8 xf = *reinterpret_cast<const half8*>(xr[j] + (ch * KC + u) * 16);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][u], xf, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][u], xf, acc[1][j], 0, 0, 0);
+            }
+        }
+    };
+    // three register sets: two chunks (2 * KC K steps) of weight requests are in flight behind the chunk being multiplied
+    load_w(wa, 0);
+    load_w(wb, min(1, NCH - 1));
+    for (int ch = 0; ch < NCH; ch += 3) {
+        load_w(wc, min(ch + 2, NCH - 1));
+        __builtin_amdgcn_sched_barrier(0);          // requests stay in front of the matrix instructions
+        compute(wa, ch);
+        load_w(wa, min(ch + 3, NCH - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < NCH) compute(wb, ch + 1);
+        load_w(wb, min(ch + 4, NCH - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 2 < NCH) compute(wc, ch + 2);
+    }
+}
+
+// one (channel tile, row tile) unit with the WHOLE reduction requested up front in two halves (few matrix instructions, pure latency otherwise):
+// the channel tiles beyond the eight pairs -- for 546 columns: tile 16 and the two columns of tile 17 -- one unit per wave
+template <int KH>
+__device__ __forceinline__ void head_xs_unit(const PwArgs& a, const half_t* xs, int KP, int KS, int rows, int nt, int j0, int lane, floatx16& acc) {
+    const int r = lane & 31, hh = lane >> 5;
+    const half_t* w0 = a.wfrag + (size_t)nt * KS * 512 + lane * 8;
+    const half_t* xr = xs + min(j0 * 32 + r, rows - 1) * KP + hh * 8;
+    half8 wa[KH], wb[KH];
+#pragma unroll
+    for (int u = 0; u < KH; ++u) wa[u] = *reinterpret_cast<const half8*>(w0 + (size_t)min(u, KS - 1) * 512);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = 0; k0 < KS; k0 += 2 * KH) {       // (uniform) chunks of KH steps, the next one requested before this one is multiplied
+#pragma unroll
+        for (int u = 0; u < KH; ++u) wb[u] = *reinterpret_cast<const half8*>(w0 + (size_t)min(k0 + KH + u, KS - 1) * 512);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KH; ++u)
+            if (k0 + u < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[u], *reinterpret_cast<const half8*>(xr + (k0 + u) * 16), acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < KH; ++u) wa[u] = *reinterpret_cast<const half8*>(w0 + (size_t)min(k0 + 2 * KH + u, KS - 1) * 512);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KH; ++u)
+            if (k0 + KH + u < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u], *reinterpret_cast<const half8*>(xr + (k0 + KH + u) * 16), acc, 0, 0, 0);
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(512) void head_xs_kernel(PwArgs a, int bp, int tiles) {
+    constexpr int RT = 4;                           // row tiles of 32 pixels (bp <= 128)
+    constexpr int KH = 11;                          // head_xs_unit: chunks of 11 K steps, two register sets
+    extern __shared__ __attribute__((aligned(16))) half_t xs[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int K = a.cin, NC = a.cout, KP = K + 8, KS = K >> 4, NCH = KS / KC;
+    int m0, mend;
+    if (a.xq > 0) {
+        const int g = blockIdx.x & 7, t = blockIdx.x >> 3;
+        const int r0 = g * a.xq * a.hw;
+        mend = min(a.m, r0 + a.xq * a.hw);
+        m0 = r0 + t * bp;
+    } else {
+        m0 = blockIdx.x * bp;
+        mend = a.m;
+    }
+    if (m0 >= mend) return;
+    const int rows = min(bp, mend - m0);
+    PW_STAMP(0);
+    // ---- 1. the strip: every 16-byte piece of it in flight at once (17 per thread for 100 x 672), one round trip
+    {
+        constexpr int NL = 17;
+        const int CPR = K >> 3, total = rows * CPR;
+        const half_t* xg = a.x + (size_t)m0 * K;
+        for (int c0 = 0; c0 < total; c0 += 512 * NL) {
+            uint4 v[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) v[u] = *reinterpret_cast<const uint4*>(xg + (size_t)min(c0 + u * 512 + tid, total - 1) * 8);
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int c = c0 + u * 512 + tid;
+                if (c < total) {
+                    const int row = c / CPR, q = c - row * CPR;
+                    *reinterpret_cast<uint4*>(&xs[row * KP + q * 8]) = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    PW_STAMP(1);
+    const int NT = (NC + 31) >> 5;
+    const int img = m0 / a.hw;
+    float* obase = reinterpret_cast<float*>(a.out) + (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m0 - img * a.hw) * NC;   // [rows][NC]
+    // ---- 2a. channel tiles beyond the eight pairs: one (tile, row tile) unit per wave, straight to memory (34 columns of 546)
+    for (int q = wave; q < (NT - 16) * RT; q += 8) {
+        const int nt = 16 + q / RT, j0 = q - (q / RT) * RT;
+        if (j0 * 32 >= rows) continue;
+        floatx16 acc1;
+        head_xs_unit<KH>(a, xs, KP, KS, rows, nt, j0, lane, acc1);
+        const int row = j0 * 32 + r;
+        if (row < rows) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = nt * 32 + 8 * g + 4 * hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < NC) obase[(size_t)row * NC + c0 + e] = acc1[4 * g + e] + a.bias[c0 + e];
+            }
+        }
+    }
+    PW_STAMP(2);
+    // ---- 2b. this wave's pair, all row tiles
+    floatx16 acc[2][RT];
+    const bool mine = 2 * wave < min(NT, 16);
+    if (mine) head_xs_task<RT, KC>(a, xs, KP, NCH, rows, 2 * wave, NT, 0, lane, acc);
+    PW_STAMP(3);
+    // ---- 3. out through LDS (over the dead strip): pairs 0..4 (columns 0..319), then 5..7. The copy keeps a fixed column pair per thread and
+    //         walks the rows (no division per element), LDS reads of four rows ahead of their stores
+    float* ot = reinterpret_cast<float*>(xs);
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p_lo = pass ? 5 : 0, p_hi = pass ? 8 : 5;
+        const int col0 = p_lo * 64, ncol = min(NC, p_hi * 64) - col0;
+        if (ncol <= 0) break;
+        const int OW = (p_hi - p_lo) * 64 + 4;
+        __syncthreads();                            // the strip (pass 0) / the first half (pass 1) is no longer read
+        if (mine && wave >= p_lo && wave < p_hi) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = (2 * wave + i) * 32 + 8 * g + 4 * hh;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c0 + 3 < NC) bv = *reinterpret_cast<const float4*>(a.bias + c0);
+                    else {
+                        if (c0 < NC) bv.x = a.bias[c0];
+                        if (c0 + 1 < NC) bv.y = a.bias[c0 + 1];
+                        if (c0 + 2 < NC) bv.z = a.bias[c0 + 2];
+                    }
+#pragma unroll
+                    for (int j = 0; j < RT; ++j) {
+                        const int row = j * 32 + r;
+                        if (row < rows)
+                            *reinterpret_cast<float4*>(&ot[row * OW + (c0 - col0)]) =
+                                make_float4(acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
+                    }
+                }
+        }
+        __syncthreads();
+        const int c2 = ncol >> 1;                   // (cout and the pass boundaries are even: whole float2 runs, 8-byte aligned)
+        const int rpi = 512 / c2;                   // rows per iteration of the workgroup
+        const int rsub = tid / c2, q = tid - rsub * c2;
+        if (rsub < rpi) {
+            const float* src = ot + 2 * q;
+            float* dst = obase + col0 + 2 * q;
+            for (int row0 = rsub; row0 < rows; row0 += 4 * rpi) {
+                float2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(src + min(row0 + u * rpi, rows - 1) * OW);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (row0 + u * rpi < rows) *reinterpret_cast<float2*>(dst + (size_t)(row0 + u * rpi) * NC) = v[u];
+            }
+        }
+        PW_STAMP(4 + pass);
+    }
+}
+
 }  // namespace
 
 // Tile choice: these GEMMs are latency/HBM-bound, not MFMA-bound, so what matters is (a) enough workgroups to fill
@@ -942,7 +1161,7 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
         if (!all_xq) g.a[i].xq = 0;
-        g.a[i].stamps = g_pw_stamps;        // dev hook (null unless tools/probe_head_stamps.py set it)
+        g.a[i].stamps = dn_knob("DN_PW_GROUP_STAMPS", 1) ? g_pw_stamps : nullptr;        // dev hook (null unless tools/probe_head_stamps.py set it)
         g.start[i] = acc;
         g.gx[i] = pw_row_tiles(g.a[i], BP);
         int ctiles = dn_cdiv(arr[i].cout, BC);
@@ -1090,3 +1309,33 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     }
     return launch_select<true>(a, s);
 }
+
+// the X-stationary class-head kernel: fp32 head output with a fragment-major weight copy, a strip length that divides the map, K in whole
+// chunks, at most 9 channel-tile pairs (8 waves + one split pair) and enough strips to give every CU one
+static int head_xs_strip(const PwArgs& a) {
+    for (int bp : {100, 128, 96, 80, 64})
+        if (a.hw % bp == 0 && (size_t)bp * (a.cin + 8) * 2 <= 150 * 1024 && (size_t)bp * (5 * 64 + 4) * 4 <= (size_t)bp * (a.cin + 8) * 2) return bp;
+    return 0;
+}
+bool head_xs_supported(const PwArgs& a) {
+    if (!dn_knob("DN_HEAD_XS", 0)) return false;       // opt-in: measured level with the tiled kernel (below)
+    if (!a.out_fp32 || !a.wfrag || a.residual || a.se || a.act != DN_ACT_NONE || a.sm_scores) return false;
+    if (a.cin % 48 != 0 || a.cout % 2 != 0 || a.cout <= 256 || a.cout > 9 * 64) return false;
+    const int bp = head_xs_strip(a);
+    return bp > 0 && a.m / bp >= dn_knob("DN_HEAD_XS_MIN", 128);
+}
+static int g_head_xs_launches = 0;
+extern "C" __attribute__((visibility("default"))) int dn_debug_head_xs_launches() { return g_head_xs_launches; }      // tests: the path was taken
+int launch_head_xs(const PwArgs& a, hipStream_t s) {
+    ++g_head_xs_launches;
+    const int bp = head_xs_strip(a);
+    DN_REQUIRE(bp > 0, "head_xs: no strip length for %d pixels x %d channels", a.hw, a.cin);
+    const int tiles = a.xq > 0 ? a.xq * a.hw / bp : a.m / bp;
+    const size_t lds = (size_t)bp * (a.cin + 8) * sizeof(half_t);
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(head_xs_kernel<3>)));
+    dn_note_kernel("head_xs_kernel<3>");
+    const_cast<PwArgs&>(a).stamps = g_pw_stamps;
+    hipLaunchKernelGGL(head_xs_kernel<3>, dim3(a.xq > 0 ? 8 * tiles : tiles), dim3(512), lds, s, a, bp, tiles);
+    return DN_OK;
+}
+

@@ -92,7 +92,7 @@ class LoweredModel:
                 wf = (w * s[:, None]).astype(np.float16)
                 o.w_off = blob.add(wf)
                 o.b_off = blob.add(b.astype(np.float32))
-                if nd.cin % 8 == 0 and not nd.head:
+                if nd.cin % 8 == 0 and (not nd.head or nd.head == 1):
                     # second copy in MFMA-fragment order for the kernels that stream weights straight from L2 into A fragments
                     # (tail.hip): [cout tile of 32][16-deep K step][lane = (k half, channel)][8 halfs] -> each wave-wide load is
                     # 1 KB contiguous instead of 32 row pieces of 32 B

@@ -525,6 +525,28 @@ def test_se_tail_in_depthwise_launch_matches_se_kernel(n, knob):
     assert (res["0"][1] - res["1"][1]).abs().max().item() < 4e-2
 
 
+@pytest.mark.parametrize("n", [64, 37])
+def test_head_xs_logits_bit_identical(n, monkeypatch):
+    """DN_HEAD_XS=1 (round 3; opt-in, measured level -- pointwise.hip head_xs_kernel): the 1x1 class head of pyramid level 0 runs X-stationary (the
+    pixel strip resident in LDS, the weights streamed from the fragment-major copy into MFMA fragments, output staged through LDS) instead of as
+    128 x 96 tiles of the grouped launch. One accumulator per output, K walked in the same order: logits and box regressions equal bit for bit
+    (n = 64: 256 strips; n = 37: two sub-batch chains, the plain and the XCD-grouped mapping)."""
+    import ctypes
+    from demonet_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    imgs = torch.from_numpy(synth.images(23, n, 320, 320)).cuda()
+    res, launches = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_HEAD_XS", flag)
+        monkeypatch.setenv("DN_HEAD_XS_MIN", "64")
+        m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+        before = raw.dn_debug_head_xs_launches()
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        launches[flag] = raw.dn_debug_head_xs_launches() - before
+    assert launches["0"] == 0 and launches["1"] >= 1, launches
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
 @pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
                                            ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 9)])
 def test_softmax_in_the_head_epilogue_is_bit_identical(name, ncls, kw, n, monkeypatch, pp_fast):
