@@ -348,7 +348,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
 }
 
 template <int K, int S, int TW, int POOL, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 4) ? 3 : 1))) void dw_kernel(DwArgs a, int nblocks) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 4) ? (K == 3 ? 4 : 3) : 1))) void dw_kernel(DwArgs a, int nblocks) {
     int img, bx;
     if (!xcd_image_of2(a.xq, a.n, img, bx)) return;
     dw_body<K, S, TW, POOL, MODE>(a, bx, nblocks, img);
@@ -571,8 +571,8 @@ struct DwGroup {
     DwArgs a[12];
 };
 
-template <int K, int S, int TW>
-__global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
+template <int K, int S, int TW, int MODE = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 4) && K == 3 ? 4 : 1))) void dw_group_kernel(DwGroup g) {
     if (g.zero_u32 && blockIdx.y == 0) {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < g.zero_count) g.zero_u32[i] = 0u;
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void dw_group_kernel(DwGroup g) {
     if (a.xq > 0) { img = (rel & 7) * a.xq + blockIdx.y; bx = rel >> 3; }
     else { img = blockIdx.y; bx = rel; }
     if (img >= a.n) return;
-    dw_body<K, S, TW, 0, 0>(a, bx, g.nblocks[p], img);
+    dw_body<K, S, TW, 0, MODE>(a, bx, g.nblocks[p], img);
 }
 
 template <int K, int S, int TW>
@@ -622,7 +622,8 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_
     g.start[count] = acc;
     DN_REQUIRE(!zero_u32 || (long)acc * 256 >= zero_count, "depthwise group: %d workgroups cannot clear %d words", acc, zero_count);
     dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
-    hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
+    if (dn_knob("DN_DW_PIPE3", 1)) hipLaunchKernelGGL((dw_group_kernel<K, S, TW, 4>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
     return DN_OK;
 }
 
@@ -644,7 +645,7 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
     const int cls = a.pool ? (a.se_scale ? 4 : 2) : 1;
     const int kf = dn_knob("DN_DW_K", 0);
     const bool rows1 = (dn_knob("DN_DW_ROWS", 0) & cls) != 0 && (kf == 0 || kf == K);
-    const bool pipe = !rows1 && K == 5 && (dn_knob("DN_DW_PIPE", 7) & cls) != 0;      // software-pipelined rows (5x5 only: 3x3 already takes its three rows in one round trip); default on (round 3: 29 -> 25.7 us per 40 x 40 launch, stress-tested)
+    const bool pipe = !rows1 && (K == 5 ? (dn_knob("DN_DW_PIPE", 7) & cls) != 0 : (dn_knob("DN_DW_PIPE3", 7) & cls) != 0);      // software-pipelined rows, default on, stress-tested. 5x5 (DN_DW_PIPE): one exposed round trip instead of three, 29 -> 25.7 us per 40 x 40 launch. 3x3 (DN_DW_PIPE3): the batched form already takes its three rows in one round trip, but two row sets instead of three are 127 registers instead of 140 -- 4 waves per SIMD: the head group 36.4 -> 33.8 us
     const size_t lds = a.pool ? pool_lds : 0;
     if (a.pool && g_dw_dbg_count > 0) {
         for (int i = 0; i < g_dw_dbg_count; ++i)
@@ -658,13 +659,11 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
         }
         return DN_OK;
     }
-    if constexpr (K == 5) {
-        if (pipe) {
-            if (a.pool && a.se_scale) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 4>), grid, dim3(256), lds, s, a, nblocks);
-            else if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 4>), grid, dim3(256), lds, s, a, nblocks);
-            else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 4>), grid, dim3(256), lds, s, a, nblocks);
-            return DN_OK;
-        }
+    if (pipe) {
+        if (a.pool && a.se_scale) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 4>), grid, dim3(256), lds, s, a, nblocks);
+        else if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 4>), grid, dim3(256), lds, s, a, nblocks);
+        else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 4>), grid, dim3(256), lds, s, a, nblocks);
+        return DN_OK;
     }
     if (a.pool && a.se_scale) {
         if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 1>), grid, dim3(256), lds, s, a, nblocks);

@@ -16,6 +16,7 @@
 //      bytes per pixel and chunk -- plus optional per-tile channel sums for the squeeze-excitation pool (fixed order).
 // The halo recompute of step 2 (1.1x .. 1.9x) rides on MFMA throughput the path does not otherwise use.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "common.h"
 
@@ -420,9 +421,10 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     ExpDwArgs a = a0;
     const bool proj = a.w3 != nullptr, exp = a.w1 != nullptr;
     constexpr int DROWS = (OH * OW + 31) / 32 * 32;
-    const size_t lds = ((size_t)G::ROWS * a.xw + 8 + (exp ? (size_t)G::ROWS * EW : 0) + K * K * EW + (proj ? (size_t)DROWS * EW : 0)) * sizeof(half_t) +
+    const size_t lds0 = ((size_t)G::ROWS * a.xw + 8 + (exp ? (size_t)G::ROWS * EW : 0) + K * K * EW + (proj ? (size_t)DROWS * EW : 0)) * sizeof(half_t) +
                        (EW + NT / 64 * 64 + (proj ? 256 : 0)) * sizeof(float);
-    DN_REQUIRE(lds <= 160 * 1024, "expand+depthwise: LDS %zu B exceeds 160 KB", lds);
+    const size_t lds = std::min<size_t>(160 * 1024, lds0 + (size_t)dn_knob("DN_EXPDW_LDS_PAD", 0) * 1024);      // dev knob: reserve more (occupancy experiments)
+    DN_REQUIRE(lds0 <= 160 * 1024, "expand+depthwise: LDS %zu B exceeds 160 KB", lds0);
     // split the 64-channel chunks over grid.y until there are enough workgroups to fill the chip a few times over
     // (not with a project stage: it sums over all chunks inside the workgroup)
     const int tiles_x = dn_cdiv(a.Wo, OW), tiles_y = dn_cdiv(a.Ho, OH), tiles = tiles_x * tiles_y, chunks = dn_cdiv(a.cexp, 64);
