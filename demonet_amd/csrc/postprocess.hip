@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include "common.h"
 
 static long long* g_pp_stamps = nullptr;     // dev hook: per-workgroup phase stamps of select_nms (dn_debug_pp_stamps)
@@ -207,6 +208,7 @@ __device__ __forceinline__ void radix_pick_digit(const unsigned* hist, unsigned 
             else { digit = 252 - 4 * l; rem = need - before - h0 - h1 - h2; }
             sh[0] = digit;
             sh[1] = rem;
+            sh[2] = hist[digit];        // size of the chosen bin (rem == size: the whole bin is taken, lower digits need no pass)
         }
     }
 }
@@ -417,14 +419,10 @@ __device__ __forceinline__ void nms_serial_phase(const unsigned long long* cand,
 // P2: per (image, class)
 // ------------------------------------------------------------------------------------------------------------
 template <int NW, bool PERM>   // 64-candidate words: candidate capacity MC = 64*NW >= topk; PERM: the column is stored anchor-major within a level
-__global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
-                                                        int A, int Km1, float score_thr, float nms_thr, int topk,
-                                                        float* __restrict__ keptScore, int* __restrict__ keptAnchor,
-                                                        int* __restrict__ keptCount, const int* __restrict__ needFull,
-                                                        long long* stamps, int nimg, int xq, PostLevels lv) {
-    int n, cls;                          // flat grid [image slot][class]; cls 0..Km1-1 (label = cls + 1)
-    if (!xcd_image_of(blockIdx.x, Km1, xq, nimg, n, cls)) return;
-    if (needFull && !needFull[n]) return;      // the fast path already produced this image's result
+__device__ __forceinline__ void select_nms_one(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
+                                               int A, int Km1, float score_thr, float nms_thr, int topk,
+                                               float* __restrict__ keptScore, int* __restrict__ keptAnchor,
+                                               int* __restrict__ keptCount, long long* stamps, PostLevels lv, const int n, const int cls) {
     constexpr int MC = 64 * NW;
     constexpr int SORTN = (NW <= 1) ? 64 : (NW <= 2) ? 128 : (NW <= 4) ? 256 : 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -532,6 +530,34 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     PP_STAMP(6);
     if (tid < 64) nms_serial_phase<NW>(cand, mask, removed, M, keptScore + obase, keptAnchor + obase, keptCount + (size_t)n * Km1 + cls);
     PP_STAMP(7);
+}
+
+
+template <int NW, bool PERM>
+__global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
+                                                        int A, int Km1, float score_thr, float nms_thr, int topk,
+                                                        float* __restrict__ keptScore, int* __restrict__ keptAnchor,
+                                                        int* __restrict__ keptCount, const int* __restrict__ needFull,
+                                                        long long* stamps, int nimg, int xq, PostLevels lv, int islots) {
+    // islots == 0: flat grid [image slot][class], one (image, class) per workgroup; cls 0..Km1-1 (label = cls + 1).
+    // islots > 0 (the fallback behind the cut-off pass, usually with no flagged image at all): grid [islots][class], a workgroup walks the images
+    // slot, slot + islots, ... and works on the flagged ones -- 8 x 90 workgroups that look at 8 flags each instead of 64 x 90 that look at one.
+    if (islots > 0) {
+        const int slot = blockIdx.x / Km1, cls1 = blockIdx.x - slot * Km1;
+        bool any = false;
+        for (int n1 = slot; n1 < nimg; n1 += islots) any |= needFull[n1] != 0;
+        if (!any) return;
+        for (int n1 = slot; n1 < nimg; n1 += islots) {
+            if (!needFull[n1]) continue;
+            select_nms_one<NW, PERM>(scoresT, boxes, A, Km1, score_thr, nms_thr, topk, keptScore, keptAnchor, keptCount, stamps, lv, n1, cls1);
+            __syncthreads();                    // the next image reuses the workgroup's LDS
+        }
+        return;
+    }
+    int n, cls;
+    if (!xcd_image_of(blockIdx.x, Km1, xq, nimg, n, cls)) return;
+    if (needFull && !needFull[n]) return;      // the fast path already produced this image's result
+    select_nms_one<NW, PERM>(scoresT, boxes, A, Km1, score_thr, nms_thr, topk, keptScore, keptAnchor, keptCount, stamps, lv, n, cls);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -758,13 +784,19 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
     // The survivors' (score, slot) keys are fetched ONCE into LDS when they fit (a few thousand at most with the cut-off path): the
     // four radix passes and the compaction then run out of LDS instead of repeating a binary search and a dependent global load
     // per entry and pass (the kernel was five exposed memory round trips long: 20 us per launch at any batch size).
+    // (round 3: the survivor's anchor and label are fetched in the same round trip and kept beside the key, whose low word is then the survivor's
+    //  index e -- monotone in the slot f, so ties break exactly as before -- : the output gather is one dependent load shorter)
     constexpr int LCAP = 3072;
     __shared__ unsigned long long lkey[LCAP];
+    __shared__ int lanc[LCAP];
+    __shared__ unsigned short llab[LCAP];
     const bool in_lds = total <= (unsigned)LCAP;
     if (in_lds) {
         for (int e = tid; e < (int)total; e += MT) {
             const unsigned f = (unsigned)slot_of(e);
-            lkey[e] = ((unsigned long long)__float_as_uint(ks[f]) << 32) | (unsigned long long)(0xFFFFFFFFu - f);
+            lkey[e] = ((unsigned long long)__float_as_uint(ks[f]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)e);
+            lanc[e] = ka[f];
+            llab[e] = (unsigned short)(f / (unsigned)topk + 1u);
         }
         __syncthreads();
     }
@@ -783,7 +815,13 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
             __syncthreads();
             prefix |= sh[0] << shift;
             need = sh[1];
+            const bool whole = sh[1] == sh[2];
             __syncthreads();
+            if (whole && shift > 0) {        // the whole bin is taken: every key >= prefix (lower digits zero) is in, nothing is left to split
+                prefix -= 1u;
+                need = 0;
+                break;
+            }
         }
         T = prefix;
         quota = need;
@@ -799,7 +837,7 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
                 if (in_lds) {
                     const unsigned long long kv0 = lkey[e];
                     k = (unsigned)(kv0 >> 32);
-                    f = 0xFFFFFFFFu - (unsigned)(kv0 & 0xFFFFFFFFull);
+                    f = (unsigned)e;            // (the key's low word: the survivor index)
                 } else {
                     f = (unsigned)slot_of(e);
                     k = __float_as_uint(ks[f]);
@@ -829,8 +867,8 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
             const unsigned long long kv = fin[i];
             const unsigned f = 0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull);
             s = __uint_as_float((unsigned)(kv >> 32));
-            lab = (long long)(f / (unsigned)topk) + 1;
-            anc = ka[f];
+            if (in_lds) { lab = (long long)llab[f]; anc = lanc[f]; }
+            else { lab = (long long)(f / (unsigned)topk) + 1; anc = ka[f]; }
             b = boxes[(size_t)n * A + anc];
             b.x *= sx; b.z *= sx; b.y *= sy; b.w *= sy;        // resize_boxes (transform.py:286-291)
         }
@@ -870,15 +908,17 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
         return DN_E_UNSUPPORTED;
     }
     const bool perm = !(a.lv.n == 1 && a.lv.aloc[0] == 1);
+    // behind the cut-off pass (needFull given) only flagged images are worked on -- usually none: a small grid whose workgroups walk the images
+    const int islots = (needFull && dn_knob("DN_PP_FALLBACK_SLOTS", 8) > 0) ? std::min(a.n, dn_knob("DN_PP_FALLBACK_SLOTS", 8)) : 0;
     if (perm) {
         DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, true>)));
-        hipLaunchKernelGGL((select_nms_kernel<NW, true>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                           a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv);
+        hipLaunchKernelGGL((select_nms_kernel<NW, true>), dim3((a.K - 1) * (islots > 0 ? islots : xcd_image_slots(a.xq, a.n))), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
+                           a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv, islots);
         return DN_OK;
     }
     DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, false>)));
-    hipLaunchKernelGGL((select_nms_kernel<NW, false>), dim3((a.K - 1) * xcd_image_slots(a.xq, a.n)), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv);
+    hipLaunchKernelGGL((select_nms_kernel<NW, false>), dim3((a.K - 1) * (islots > 0 ? islots : xcd_image_slots(a.xq, a.n))), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
+                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv, islots);
     return DN_OK;
 }
 
