@@ -156,7 +156,7 @@ def cpu_baseline(name, graph, seed, budget_s=24.0):
     best = max(variants, key=lambda v: v["images_per_sec"])
     best_py = max((v for v in variants if v["postprocess"] == "python"), key=lambda v: v["images_per_sec"])
     net = min(variants, key=lambda v: v["network_ms_per_img"])
-    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": cores, "threads": best["threads"], "kind": "port",
+    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": best["threads"], "host_cpus": cores, "kind": "port",      # cores = the threads the reported variant actually used
             "cpu_model": cpu_model,
             "postprocess": best["postprocess"],
             # the checker's own post-process (Python / numpy loops), for comparison with earlier rounds' lines:
