@@ -52,7 +52,7 @@ __device__ __forceinline__ bool pw_tile_rows(const PwArgs& a, int flat, int tile
 
 // SM: softmax epilogue for the fp32 class-head problems that ask for it (PwArgs::sm_scores; grouped launch only). A template
 // parameter because its code costs the plain kernel two registers -- exactly the two that take it from 3 to 2 waves per SIMD.
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false, bool SM = false>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false, bool SM = false, bool FK = false>
 __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, const int by) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
@@ -66,7 +66,10 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
     float* bsh = reinterpret_cast<float*>(lds_raw);
     constexpr int SEF_FLOATS = SEF ? 832 : 0;           // scale[2][128], mean[2][128], z[2][32], fc1 partials[2][4][32]
     float* sef = bsh + BC;
-    half_t* lds_dyn = lds_raw + 2 * BC + 2 * SEF_FLOATS;
+    // FK with an SE scale vector (a.se): the scales of the tile's (at most two) images sit in LDS, [2][K] floats behind the bias
+    const int FKSE_FLOATS = (FK && a.se) ? 2 * a.cin : 0;
+    float* sesc = bsh + BC + SEF_FLOATS;
+    half_t* lds_dyn = lds_raw + 2 * BC + 2 * SEF_FLOATS + 2 * FKSE_FLOATS;
     half_t (*lds)[(BP + BC) * LDS_ROW] = reinterpret_cast<half_t (*)[(BP + BC) * LDS_ROW]>(lds_dyn);
 
     const int tid = threadIdx.x;
@@ -150,6 +153,63 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             sw[i] = v;
         }
     };
+    // FK (round 3, template flag set by the launcher when every problem of the launch has K % BK == 0, no SE-scaled staging and arrays below 2 GB):
+    // the K loop without bound tests -- chunk byte offsets formed once, rows beyond the problem CLAMPED instead of predicated (their products land in
+    // rows / columns the epilogue never stores), a stage = NX + NW unconditional loads at offset + 2 k0. The three-stage ring is spelled out as NAMED
+    // register sets: as arrays hipcc kept its weight half in scratch memory with a run-time slot index (88 -> 167 us).
+    unsigned xo[NX], wo[NWc];
+    if constexpr (FK) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, q = c - row * CPR;
+            xo[i] = ((unsigned)min(m0 + min(row, BP - 1), M - 1) * (unsigned)K + (unsigned)q * 8u) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, q = c - row * CPR;
+            wo[i] = ((unsigned)min(n0 + min(row, BC - 1), NC - 1) * (unsigned)K + (unsigned)q * 8u) * 2u;
+        }
+    }
+    // (plain ext-vector values, not HIP's uint4 struct: its copies are memcpy calls on allocas, and with the lifetime markers of the inlined lambdas
+    //  SROA left the weight sets in scratch memory -- 88 -> 167 us)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_fast = [&](u32x4 (&sx)[NX], u32x4 (&sw)[NWc], int k0) __attribute__((always_inline)) {
+        const char* xb = reinterpret_cast<const char*>(a.x);
+        const char* wb = reinterpret_cast<const char*>(a.w);
+        const unsigned ko = (unsigned)k0 * 2u;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) sx[i] = *reinterpret_cast<const u32x4*>(xb + (xo[i] + ko));
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sw[i] = *reinterpret_cast<const u32x4*>(wb + (wo[i] + ko));
+    };
+    int se_split = 0x7fffffff;              // FK + a.se: first row of the tile that belongs to the second image
+    auto store_fast = [&](const u32x4 (&sx)[NX], const u32x4 (&sw)[NWc], int b, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, q = c - row * CPR;
+            u32x4 v = sx[i];
+            if (a.se) {
+                // SE scale applied as the rows are staged: (half)((float)x * s), the rounding of the general path (load_into) -- there the
+                // product sat right behind the load and every stage waited for its own memory round trip
+                const float* sp = sesc + (row >= se_split ? K : 0) + k0 + q * 8;
+                const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+                half8 hv = *reinterpret_cast<half8*>(&v);
+                hv[0] = (half_t)((float)hv[0] * s0.x); hv[1] = (half_t)((float)hv[1] * s0.y); hv[2] = (half_t)((float)hv[2] * s0.z); hv[3] = (half_t)((float)hv[3] * s0.w);
+                hv[4] = (half_t)((float)hv[4] * s1.x); hv[5] = (half_t)((float)hv[5] * s1.y); hv[6] = (half_t)((float)hv[6] * s1.z); hv[7] = (half_t)((float)hv[7] * s1.w);
+                v = *reinterpret_cast<u32x4*>(&hv);
+            }
+            if (row < BP) *reinterpret_cast<u32x4*>(&lds[b][row * LDS_ROW + q * 8]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / CPR, q = c - row * CPR;
+            if (row < BC) *reinterpret_cast<u32x4*>(&lds[b][(BP + row) * LDS_ROW + q * 8]) = sw[i];
+        }
+    };
     int sef_split = 0x7fffffff;             // SEF: first row of the tile that belongs to the second image
     auto store_from = [&](const uint4 (&sx)[NX], const uint4 (&sw)[NWc], int b, int k0 = 0) {
 #pragma unroll
@@ -212,7 +272,65 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             }
         }
     };
-    if constexpr (PF > 1) {
+    auto mfma_full = [&](int b) __attribute__((always_inline)) {       // every K step of the stage exists: no tail test between the steps
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            half8 xf[TP], wf[TC];
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+                xf[j] = *reinterpret_cast<const half8*>(&lds[b][((wp * TP + j) * 32 + r) * LDS_ROW + ks * 16 + hh * 8]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+                wf[i] = *reinterpret_cast<const half8*>(&lds[b][(BP + (wc * TC + i) * 32 + r) * LDS_ROW + ks * 16 + hh * 8]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if constexpr (FK && (PF == 3 || PF == 4) && !SEF) {
+        u32x4 x0[NX], x1[NX], x2[NX], x3[PF == 4 ? NX : 1], w0[NWc], w1[NWc], w2[NWc], w3[PF == 4 ? NWc : 1];
+        load_fast(x0, w0, 0);
+        if (KT > 1) load_fast(x1, w1, BK);
+        if (KT > 2) load_fast(x2, w2, 2 * BK);
+        if constexpr (PF == 4) { if (KT > 3) load_fast(x3, w3, 3 * BK); }
+        if (a.se) {
+            const int img0 = m0 / a.hw, img_last = (min(m0 + BP, M) - 1) / a.hw;       // (the launcher checks hw >= BP: at most two images per tile)
+            se_split = (img0 + 1) * a.hw - m0;
+            for (int t = tid; t < 2 * K; t += 256) {
+                const int im = t >= K ? 1 : 0;
+                sesc[t] = (img0 + im <= img_last) ? a.se[(size_t)(img0 + im) * K + (t - im * K)] : 0.f;
+            }
+            __syncthreads();
+        }
+        store_fast(x0, w0, 0, 0);
+        __syncthreads();
+        PW_STAMP(1);
+        // stage kt sits in LDS buffer kt & 1; set (kt + 1) % PF holds stage kt + 1, set kt % PF is free for stage kt + PF
+#define PW_FK_STAGE(KT_, XN, WN, XF, WF)                                                            \
+        if ((KT_) < KT) {                                                                            \
+            mfma_full((KT_) & 1);                                                                    \
+            if ((KT_) + 1 < KT) store_fast(XN, WN, ((KT_) + 1) & 1, ((KT_) + 1) * BK);                \
+            if ((KT_) + PF < KT) load_fast(XF, WF, ((KT_) + PF) * BK);                               \
+            __syncthreads();                                                                         \
+        }
+        if constexpr (PF == 3) {
+            for (int kt0 = 0; kt0 < KT; kt0 += 3) {
+                PW_FK_STAGE(kt0, x1, w1, x0, w0)
+                PW_FK_STAGE(kt0 + 1, x2, w2, x1, w1)
+                PW_FK_STAGE(kt0 + 2, x0, w0, x2, w2)
+            }
+        } else {
+            for (int kt0 = 0; kt0 < KT; kt0 += 4) {
+                PW_FK_STAGE(kt0, x1, w1, x0, w0)
+                PW_FK_STAGE(kt0 + 1, x2, w2, x1, w1)
+                PW_FK_STAGE(kt0 + 2, x3, w3, x2, w2)
+                PW_FK_STAGE(kt0 + 3, x0, w0, x3, w3)
+            }
+        }
+#undef PW_FK_STAGE
+    } else if constexpr (PF > 1) {
         // Register ring of PF stages: every stage's global loads are requested PF stages before their use. For short K
         // (KT <= PF) that is everything up front -- ONE exposed memory round trip per workgroup instead of one per 32-deep
         // stage; for long K the latency hides behind PF stages of MFMA work. The LDS double buffer and its barriers stay.
@@ -611,11 +729,11 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
     PW_STAMP(3);
 }
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false, bool FK = false>
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a, int tiles) {
     int m0, mend, by;
     if (!pw_tile_rows<BP>(a, blockIdx.x, tiles, m0, mend, by)) return;
-    pw_body<BP, BC, WP, WC, CONV, BK, PF, SEF>(a, m0, mend, by);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF, SEF, false, FK>(a, m0, mend, by);
 }
 
 // Grouped launch: up to 12 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
@@ -628,15 +746,15 @@ struct PwGroup {
     PwArgs a[12];
 };
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SM = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((SM && BP == 128 && BC == 96) ? 3 : 1))) void pw_group_kernel(PwGroup g) {
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SM = false, bool FK = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((SM || FK) && BP == 128 && BC == 96) ? 3 : 1))) void pw_group_kernel(PwGroup g) {
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 12; ++i)
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
     int m0, mend, by;       // (start[] are multiples of 8 when the XCD grouping is on: local % 8 == blockIdx.x % 8)
     if (!pw_tile_rows<BP>(g.a[p], blockIdx.x - g.start[p], g.gx[p], m0, mend, by)) return;
-    pw_body<BP, BC, WP, WC, CONV, BK, PF, false, SM>(g.a[p], m0, mend, by);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF, false, SM, FK>(g.a[p], m0, mend, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -841,6 +959,15 @@ int launch_bk(const PwArgs& a, hipStream_t s, int nbuf) {
     if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK, PF, SEF>)));
     dn_note_kernel(SEF ? "pw_kernel<%d,%d,%d,%d,%s,%d,%d,true>" : PF > 1 ? "pw_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC,
                    CONV ? "true" : "false", BK, PF);
+    if constexpr (!CONV && !SEF && (PF == 3 || PF == 4)) {
+        // the bound-test-free K loop (pw_body FK): whole 32-deep stages, no SE-scaled staging, 32-bit byte offsets
+        if (dn_knob("DN_PW_FASTK", 1) && a.cin % BK == 0 && (!a.se || a.hw >= BP) && !(a.act >> 8) && (size_t)a.m * a.cin < (1u << 30) && (size_t)a.cout * a.cin < (1u << 30)) {
+            const size_t lds_fk = lds + (a.se ? (size_t)2 * a.cin * sizeof(float) : 0);      // + the SE scales of the tile's two images
+            if (lds_fk > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_kernel<BP, BC, WP, WC, CONV, BK, PF, SEF, true>)));
+            hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK, PF, SEF, true>), grid, dim3(256), lds_fk, s, a, tiles);
+            return DN_OK;
+        }
+    }
     hipLaunchKernelGGL((pw_kernel<BP, BC, WP, WC, CONV, BK, PF, SEF>), grid, dim3(256), lds, s, a, tiles);
     return DN_OK;
 }
@@ -1188,6 +1315,17 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
         if (any_sm) {
             if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>)));
             hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>), dim3(acc), dim3(256), lds, s, g);
+            return DN_OK;
+        }
+    }
+    if constexpr (!CONV && GPF == 3) {
+        // every problem on the bound-test-free K loop (whole 32-deep stages, no SE-scaled staging, 32-bit byte offsets): the instantiation that holds nothing else
+        bool fk = dn_knob("DN_PW_FASTK", 1) != 0;
+        for (int i = 0; i < count; ++i)
+            fk &= arr[i].cin % BK == 0 && !arr[i].se && !(arr[i].act >> 8) && (size_t)arr[i].m * arr[i].cin < (1u << 30) && (size_t)arr[i].cout * arr[i].cin < (1u << 30);
+        if (fk) {
+            if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, false, true>)));
+            hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, false, true>), dim3(acc), dim3(256), lds, s, g);
             return DN_OK;
         }
     }
