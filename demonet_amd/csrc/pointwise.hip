@@ -1265,6 +1265,15 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         // request the stages 4 ahead through the register ring of the short-K pointwise variant
         if (dn_knob("DN_CONV_SMALL_PF", 1) && a.cout > 32 && wgs(64, 64) < dn_knob("DN_CONV_SMALL_WGS", 512)) return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
     }
+    if constexpr (!CONV) {
+        // a 1x1 layer with few workgroups and a long K (the first extras layer: 480 -> 256 on 10 x 10) is a chain of exposed round trips with the plain
+        // double buffer: stages requested 4 ahead on the bound-test-free loop. Measured (round 3): the launch 18.8 -> 14 us, one forward at a time -5 us,
+        // with three forwards in flight 0.2 - 0.3 % slower in three of three pairs: opt-in
+        if (dn_knob("DN_PW_LONGK_PF", 0) && a.cin % 32 == 0 && a.cin >= 256 && a.cout > 32 && wgs(64, 64) < 1500) {
+            const_cast<PwArgs&>(a).stamps = g_pw_stamps;
+            return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
+        }
+    }
     const int t128 = dn_knob("DN_CONV_T128", 300);      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
     if (wgs(128, 128) >= (CONV ? t128 : 1500)) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
     if (wgs(128, 64) >= 1500 || a.cout % 128 > 64 || a.cout % 128 == 0) {
