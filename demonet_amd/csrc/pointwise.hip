@@ -194,20 +194,21 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             if (a.se) {
                 // SE scale applied as the rows are staged: (half)((float)x * s), the rounding of the general path (load_into) -- there the
                 // product sat right behind the load and every stage waited for its own memory round trip
-                const float* sp = sesc + (row >= se_split ? K : 0) + k0 + q * 8;
+                const float* sp = sesc + (min(row, BP - 1) >= se_split ? K : 0) + k0 + q * 8;
                 const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
                 half8 hv = *reinterpret_cast<half8*>(&v);
                 hv[0] = (half_t)((float)hv[0] * s0.x); hv[1] = (half_t)((float)hv[1] * s0.y); hv[2] = (half_t)((float)hv[2] * s0.z); hv[3] = (half_t)((float)hv[3] * s0.w);
                 hv[4] = (half_t)((float)hv[4] * s1.x); hv[5] = (half_t)((float)hv[5] * s1.y); hv[6] = (half_t)((float)hv[6] * s1.z); hv[7] = (half_t)((float)hv[7] * s1.w);
                 v = *reinterpret_cast<u32x4*>(&hv);
             }
-            if (row < BP) *reinterpret_cast<u32x4*>(&lds[b][row * LDS_ROW + q * 8]) = v;
+            // (unconditional: a chunk beyond the tile was LOADED from the clamped row, so it rewrites that row's piece with the same bytes -- no branch)
+            *reinterpret_cast<u32x4*>(&lds[b][min(row, BP - 1) * LDS_ROW + q * 8]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int c = tid + 256 * i;
             const int row = c / CPR, q = c - row * CPR;
-            if (row < BC) *reinterpret_cast<u32x4*>(&lds[b][(BP + row) * LDS_ROW + q * 8]) = sw[i];
+            *reinterpret_cast<u32x4*>(&lds[b][(BP + min(row, BC - 1)) * LDS_ROW + q * 8]) = sw[i];
         }
     };
     int sef_split = 0x7fffffff;             // SEF: first row of the tile that belongs to the second image
