@@ -119,6 +119,36 @@ def test_pointwise_streaming_bit_identical_to_direct(m, cin, cout, hw, act, monk
     assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().max()) > 0
 
 
+
+@pytest.mark.parametrize("m,cin,cout,hw,se,res", [(19200, 480, 112, 400, True, False), (25600 + 37, 672, 112, 25637, False, False),
+                                                  (9 * 400, 672, 112, 400, True, True), (6400, 480, 256, 100, False, False),
+                                                  (13 * 100 + 0, 960, 160, 100, True, False)])
+def test_pointwise_fast_k_loop_bit_identical(m, cin, cout, hw, se, res, monkeypatch):
+    """DN_PW_FASTK (round 3, default on): the tiled 1x1 kernel's K loop without bound tests (offsets formed once, clamped rows, named register ring) and, for
+    SE-scaled inputs, the scales applied from LDS as the rows are staged instead of behind each load. Same products in the same order, the same
+    (half)((float)x * s) rounding: outputs equal bit for bit, for ragged last tiles, XCD-grouped batches and tiles that span two images.
+    (DN_PW_LONGK_PF routes the long-K case to the 4-stage form; the strip kernel is switched off so that every shape takes the tiled kernel.)"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(m + cin)
+    nimg = m // hw
+    x = torch.randn(m, cin, generator=g).half().cuda()
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).half()
+    b = torch.randn(cout, generator=g).cuda()
+    s = torch.rand(nimg, cin, generator=g).cuda() if se else None
+    r = torch.randn(m, cout, generator=g).half().cuda() if res else None
+    wd = w.cuda()
+    monkeypatch.setenv("DN_PW_XS", "0")
+    monkeypatch.setenv("DN_PW_LONGK_PF", "1")
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_PW_FASTK", flag)
+        out = torch.zeros(m, cout, dtype=torch.half, device="cuda")
+        L.check(lib.dn_pointwise_conv(_ptr(x), _ptr(wd), _ptr(None), _ptr(b), _ptr(r), _ptr(s), _ptr(out), m, cin, cout, hw, 0, 0, 0,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dn_pointwise_conv")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().max()) > 0
+
 DW_CASES = [
     # n, h, w, c, k, s, act
     (2, 20, 20, 16, 3, 1, 1),

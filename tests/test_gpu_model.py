@@ -525,6 +525,19 @@ def test_se_tail_in_depthwise_launch_matches_se_kernel(n, knob):
     assert (res["0"][1] - res["1"][1]).abs().max().item() < 4e-2
 
 
+@pytest.mark.parametrize("n", [64, 37, 3])
+def test_head_group_fast_k_loop_bit_identical(n, monkeypatch):
+    """DN_PW_FASTK on the grouped head launch (all levels' 1x1 heads, fp32 rows) and on the SE-scaled projections of the backbone: head outputs of the
+    whole model equal bit for bit with the general K loop."""
+    imgs = torch.from_numpy(synth.images(29, n, 320, 320)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_PW_FASTK", flag)
+        m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
 @pytest.mark.parametrize("n", [64, 37])
 def test_head_xs_logits_bit_identical(n, monkeypatch):
     """DN_HEAD_XS=1 (round 3; opt-in, measured level -- pointwise.hip head_xs_kernel): the 1x1 class head of pyramid level 0 runs X-stationary (the
