@@ -782,8 +782,12 @@ __global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a, int tiles) {
     // ---- stage the pixel strip (zero-filled beyond M / K), 8 independent 16-B loads per thread per batch
     const int CPR = KS * 2;                     // 16-B chunks per row (incl. zero padding up to KS*16)
     const int total = BP * CPR;
+    // (round 3: the SE scales of a chunk are requested TOGETHER with the chunk, clamped and unconditional -- they used to be loaded behind the wait for the
+    //  batch's rows: a second dependent round trip per batch)
+    const bool has_se = a.se != nullptr;
     for (int c0 = 0; c0 < total; c0 += 256 * 8) {
         uint4 v[8];
+        float4 s0[8], s1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = c0 + u * 256 + tid;
@@ -792,6 +796,11 @@ __global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a, int tiles) {
             uint4 t = make_uint4(0, 0, 0, 0);
             if (c < total && m < M && k < K) t = *reinterpret_cast<const uint4*>(a.x + (size_t)m * K + k);
             v[u] = t;
+            if (has_se) {
+                const float* sp = a.se + (size_t)(min(m, M - 1) / a.hw) * K + min(k, K - 8);
+                s0[u] = *reinterpret_cast<const float4*>(sp);
+                s1[u] = *reinterpret_cast<const float4*>(sp + 4);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -799,13 +808,12 @@ __global__ __launch_bounds__(256) void pw_xs_kernel(PwArgs a, int tiles) {
             if (c < total) {
                 const int row = c / CPR, q = c - row * CPR;
                 uint4 t = v[u];
-                if (a.se) {
+                if (has_se) {
                     const int m = m0 + row, k = q * 8;
                     if (m < M && k < K) {
-                        const float* sp = a.se + (size_t)(m / a.hw) * K + k;
                         half8 hv = *reinterpret_cast<half8*>(&t);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) hv[e] = (half_t)((float)hv[e] * sp[e]);
+                        hv[0] = (half_t)((float)hv[0] * s0[u].x); hv[1] = (half_t)((float)hv[1] * s0[u].y); hv[2] = (half_t)((float)hv[2] * s0[u].z); hv[3] = (half_t)((float)hv[3] * s0[u].w);
+                        hv[4] = (half_t)((float)hv[4] * s1[u].x); hv[5] = (half_t)((float)hv[5] * s1[u].y); hv[6] = (half_t)((float)hv[6] * s1[u].z); hv[7] = (half_t)((float)hv[7] * s1[u].w);
                         t = *reinterpret_cast<uint4*>(&hv);
                     }
                 }
