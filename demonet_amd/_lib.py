@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdemonet_hip.so")
+LIB_PATH = os.environ.get("DEMONET_HIP_LIB") or os.path.join(_HERE, "lib", "libdemonet_hip.so")      # (DEMONET_HIP_LIB: a dev build of the SAME C ABI, e.g. `python -m demonet_amd.build --stamps`)
 DN_ABI_VERSION = 1
 
 DN_OP = dict(stem=1, pw=2, dw=3, se=4, conv=5, maxpool=6, l2norm=7)

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdemonet_hip.so")
-SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "trunk.hip", "pwdirect.hip", "loss.hip"]
+SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "trunk.hip", "pwdirect.hip", "loss.hip", "headfuse.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, not AGPRs -- the small-tile kernels otherwise spend a v_accvgpr_read per
 # accumulator value on the way to their epilogues (not for convbig.hip: its 256 x 256 tiles need the AGPR half of the file)
 VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
@@ -28,6 +28,21 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_stamps(verbose=True):
+    """Dev build: lib/libdemonet_hip_stamps.so = the same objects with headfuse.hip compiled with -DDN_DEV_STAMPS (per-workgroup phase cycle
+    sums, tools/probe_headfuse.py). Load it with DEMONET_HIP_LIB=<path>; the product library never carries the stamps."""
+    build(verbose=verbose)
+    obj = os.path.join(LIBDIR, "headfuse_stamps.o")
+    cmd = [HIPCC] + COMMON + ["-DDN_DEV_STAMPS", "-c", os.path.join(CSRC, "headfuse.hip"), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "headfuse.hip"] + [obj]
+    out = os.path.join(LIBDIR, "libdemonet_hip_stamps.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 def build(force=False, verbose=True):
@@ -56,4 +71,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_stamps() if "--stamps" in sys.argv else build(force="--force" in sys.argv))

@@ -188,6 +188,19 @@ int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s);
 int launch_pw_head_big(const PwArgs& a, hipStream_t s);
 bool head_xs_supported(const PwArgs& a);      // X-stationary 1x1 class head of a large level (pointwise.hip)
 int launch_head_xs(const PwArgs& a, hipStream_t s);
+// SSDLite heads, depthwise 3x3 inside the 1x1 GEMM's operand staging: every level, both heads, one launch (headfuse.hip).
+// Index 0 = class head, 1 = box head; both read the level's feature map x.
+struct HeadFuseLevel {
+    const half_t* x;                 // [n][H][W][C]
+    const half_t* wdg;               // the class head's depthwise 3x3 weights in GROUP-major order [C / 8][9 taps][8] fp16 (dn_op_desc::w2_off of its DW op)
+    const unsigned char* wslot;      // [C / 32] slots of 1 KB: the box head's group-major depthwise weights of the chunk (576 B), its bias [32] fp32, the class head's bias [32] fp32 (dn_op_desc::b2_off of the class head's DW op)
+    const half_t* wf[2]; const float* bias[2];    // 1x1 weights in fragment-major order (dn_op_desc::w2_off), bias [nc]
+    float* out[2]; long out_img_stride[2], out_base[2];     // fp32 head arrays: elements between images, element offset of image 0's level rows
+    int nc[2];                       // output channels (anchors per location x classes, x 4)
+    int n, H, W, C, act;             // act: the depthwise activation
+};
+bool head_fused_level_supported(const HeadFuseLevel& l);
+int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s);
 
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;

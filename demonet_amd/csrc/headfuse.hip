@@ -1,0 +1,433 @@
+// SSDLite prediction heads of ALL pyramid levels, both heads, in ONE launch: depthwise 3x3 + BN + ReLU6 computed inside the operand
+// staging of the 1x1 GEMM behind it (round 4).
+//
+// reference ops replaced: `_prediction_block` (ssd_mobilenetv3.py:27-36: depthwise 3x3 ConvBNActivation -> 1x1 conv) of the class and
+// the box head of every level, and the view / permute / reshape / cat of generalized_ssd.py:60-74 (the fp32 rows leave in final layout).
+// Before: dw_group_kernel wrote both heads' depthwise outputs (83 MB per 64 images) for pw_group_kernel to read back, 128 x 96 tiles
+// re-reading their pixel rows once per channel tile.
+//
+// CDNA4 mapping. A workgroup (4 waves) owns 64 consecutive pixels of the flattened (image, y, x) order and ALL output channels of both
+// heads (546 + 24 -> 18 + 1 channel tiles of 32): wave w accumulates channel tiles w, w + 4, ... x two 32-pixel tiles (<= 160 fp32
+// accumulator registers), so a pixel's depthwise values are computed ONCE per head. K (the feature channels) is walked in chunks of 32:
+//   1. the chunk's input rows -- the tile's 64 pixels plus W + 1 pixels either side, ONE run that holds all nine taps of every pixel --
+//      go to LDS by LDS-DMA, pixel-major with the four 8-channel groups of a pixel XOR-swizzled over its four 16-byte slots (16 whole
+//      cache lines per DMA instruction, conflict-free tap reads);
+//   2. depthwise: thread = (8-channel group = wave, pixel = lane) reads its nine taps once (addresses formed once per workgroup; a tap
+//      outside the image reads a zero slot, which is the zero padding), and runs both heads over them: bias first, taps in (ky, kx)
+//      order through v_fma_mix_f32 (fp16 operands, fp32 accumulate), ReLU6, ONE rounding to fp16 -- the arithmetic of dw_kernel bit for
+//      bit. The 8-channel group is wave-uniform, so a head's depthwise weights and bias are the same for the wave's 64 pixels: the class
+//      head's come through the scalar cache into SGPR operands (44 SGPRs, requested one phase ahead -- both heads that way would need 88
+//      live at once), the box head's ride in the LDS-DMA of the x run (704 B per chunk) and are read as wave-wide broadcasts;
+//   3. the fp16 values go to LDS in the same plane layout, where they ARE the B fragments of v_mfma_f32_32x32x16_f16 (lane = pixel,
+//      8 consecutive k per half wave); the A fragments come straight from L2 out of the fragment-major weight copy (1 KB per wave load,
+//      requested before the depthwise phase). Accumulation order = pw_group_kernel's (one accumulator per output, K ascending in 16-deep
+//      steps, bias added in fp32 at the end): logits and box regressions are bit-identical to the two-launch path.
+// One barrier per chunk (B tiles and x runs double-buffered). Epilogue: straight from the accumulators, 32 contiguous bytes per pixel and store.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int HF_P = 64;            // pixels per workgroup
+constexpr int HF_RUNP = 128;        // run pixels per plane (64 + 2 (W + 1) <= 128: W <= 31)
+constexpr int HF_ZOFF = 4 * HF_RUNP * 16;         // zero slot inside an x buffer
+constexpr int HF_WOFF = HF_ZOFF + 64;             // 1 KB slot: the box head's depthwise weights of the chunk [4 groups][9][8] halfs, its bias [32] floats, the class head's bias [32] floats
+constexpr int HF_XS = HF_WOFF + 1024;             // bytes per x buffer: four planes + the zero slot + the weight slot
+constexpr int HF_BS = 4 * HF_P * 16;              // bytes per B tile (one head, one buffer)
+constexpr int HF_LDS = 2 * HF_XS + 4 * HF_BS;     // 18 560 + 16 384 B
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));      // a head row starts at an 8-byte boundary
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) u32x4* cp_u4;
+typedef const __attribute__((address_space(4))) u32x16* cp_u16;
+
+struct HfLevel {
+    const half_t* x;                 // [n][H][W][C]
+    const half_t* wd;                // the class head's depthwise weights, group-major [C / 8][9 taps][8] fp16
+    const unsigned char* wslot;      // [C / 32][1 KB]: the box head's depthwise weights + bias and the class head's bias of every chunk (HeadFuseLevel::wslot)
+    const half_t* wf[2];             // 1x1 weights, fragment-major [ceil(nc/32)][C/16][2][32][8] (plan.py::fragment_major)
+    const float* bias[2];            // [nc]
+    float* out[2];                   // logits / box regressions, element offset of image 0 already added
+    unsigned out_img_stride[2];      // elements between images
+    int nc[2];
+    int H, W, C, hw, m;              // m = n * hw
+    int act;                         // depthwise activation
+    int tiles;                       // 64-pixel tiles per XCD group (plain mapping: of the whole level)
+    int ct0;                         // channel tiles of the class head; the box head is tile ct0
+};
+struct HfGroup {
+    int count, xq;
+    int start[9];
+    long long* stamps;               // dev builds only (-DDN_DEV_STAMPS, tools/probe_headfuse.py): per-workgroup phase cycle sums
+    HfLevel lv[8];
+};
+#ifdef DN_DEV_STAMPS
+#define HF_T(var) const long long var = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define HF_T(var)
+#endif
+
+// acc[0..7] += x[0..7] * w[0..7]: fp16 x in a VGPR quad, fp16 w in an SGPR quad (uniform per wave), fp32 accumulate
+__device__ __forceinline__ void hf_fma8(float (&acc)[8], const u32x4& x, const u32x4& w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[2 * i]) : "v"(x[i]), "s"(w[i]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * i + 1]) : "v"(x[i]), "s"(w[i]));
+    }
+}
+
+__device__ __forceinline__ void hf_fma8v(float (&acc)[8], const u32x4& x, const u32x4& w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[2 * i]) : "v"(x[i]), "v"(w[i]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * i + 1]) : "v"(x[i]), "v"(w[i]));
+    }
+}
+
+template <int TCW>
+__global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hf_lds[];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
+    const HfLevel& L = g.lv[p];
+    const int flat = blockIdx.x - g.start[p];
+    int m0, mend;
+    if (g.xq > 0) {
+        const int grp = flat & 7, t = flat >> 3;
+        const int r0 = grp * g.xq * L.hw;
+        mend = min(L.m, r0 + g.xq * L.hw);
+        m0 = r0 + t * HF_P;
+    } else {
+        m0 = flat * HF_P;
+        mend = L.m;
+    }
+    if (m0 >= mend) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int C = L.C, W = L.W, H = L.H;
+    const int NCH = C >> 5;
+
+    // ---- per-workgroup constants of the depthwise phase: the nine tap addresses of (group = wave, pixel = lane)
+    // (three 10-bit slot numbers per register: nine registers held across the loop were what spilled -- and a scratch reload is a VMEM
+    //  operation that waits in order behind the A-fragment requests)
+    unsigned tap3[3] = {0u, 0u, 0u};
+    {
+        const int mp = min(m0 + lane, mend - 1);
+        const int img = mp / L.hw, rem = mp - img * L.hw;
+        const int y = rem / W, x = rem - y * W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = x + kx - 1;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const int P = lane + (W + 1) + (ky - 1) * W + (kx - 1);          // run pixel of the tap
+                const unsigned slot = ok ? (unsigned)(4 * P + (wave ^ ((P >> 2) & 3))) : (unsigned)(HF_ZOFF / 16);
+                tap3[ky] |= slot << (10 * kx);
+            }
+    }
+    auto tap_addr = [&](int t) -> unsigned { return ((tap3[t / 3] >> (10 * (t % 3))) & 1023u) * 16u; };
+    // x run in LDS: [run pixel][4 slots of 16 B], the 8-channel group g of run pixel P in slot g ^ ((P >> 2) & 3) -- a wave's tap read (64 consecutive
+    // pixels, one group) then touches every bank once, and one LDS-DMA instruction covers 16 whole pixels = 16 cache lines (as four planes it was 64
+    // lines per instruction: the launch was bound by L1 tag lookups). Wave w fills run pixels [32 w, 32 w + 32) with two instructions; run pixels are
+    // clamped into the level (a tap that is used never reads a clamped pixel).
+    unsigned xoff[2];                // byte offsets from L.x (the launcher checks the level is < 2 GB)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int P = (2 * wave + i) * 16 + (lane >> 2);
+        const int mp = min(max(m0 - (W + 1) + P, 0), L.m - 1);
+        xoff[i] = ((unsigned)mp * (unsigned)C + (unsigned)(((lane & 3) ^ ((P >> 2) & 3)) * 8)) * 2u;
+    }
+    if (tid < 8) *reinterpret_cast<unsigned*>(hf_lds + (tid >> 2) * HF_XS + HF_ZOFF + (tid & 3) * 4) = 0u;
+    // LDS-DMA behind the compiler's back (inline asm): as a builtin, hipcc orders every later ds_read behind the DMA's LDS write with
+    // s_waitcnt vmcnt(0) -- the taps of chunk c would wait for the run of chunk c + 1. The DMA is published by the counted wait + barrier
+    // at the end of the depthwise phase (below); its target buffer was last read before the previous barrier.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)hf_lds;
+    auto glds16 = [&](const void* gsrc, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    };
+    const unsigned aoff = (unsigned)lane * 16u;
+    const unsigned char* const xbase = reinterpret_cast<const unsigned char*>(L.x);
+    auto stage_x = [&](int c) {
+        const unsigned dst = lds0 + (c & 1) * HF_XS;
+        glds16(xbase + (xoff[0] + (unsigned)c * 64u), dst + wave * 2048);
+        glds16(xbase + (xoff[1] + (unsigned)c * 64u), dst + wave * 2048 + 1024);
+        // the chunk's weight slot (832 B of its 1 KB in the blob: box-head depthwise weights + bias, class-head bias), one instruction of wave 3
+        if (wave == 3) glds16(L.wslot + ((unsigned)c * 1024u + aoff), dst + HF_WOFF);
+    };
+
+    // channel tiles of this wave: wave + 4 i. Tiles i < TCW - 1 are class tiles; the last one is a class tile, the box tile or nothing.
+    const int tlast = wave + 4 * (TCW - 1);
+    const bool last_reg = tlast == L.ct0, last_on = tlast <= L.ct0;
+    const int KS = C >> 4;
+    // A fragments: [tile][K step][lane][8] halfs. Buffer loads: descriptor of the head's weight copy (SGPRs), tile + K-step offset as the scalar
+    // offset, lane * 16 B as the ONE vector offset of every load (as global loads hipcc kept a 64-bit address pair per tile alive: 10 registers)
+    const __amdgpu_buffer_rsrc_t ars0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(L.wf[0]), 0, L.ct0 * KS * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(L.wf[1]), 0, KS * 1024, 0x00020000);
+    unsigned atile[TCW];             // byte offset of the tile's first K step (uniform)
+#pragma unroll
+    for (int i = 0; i < TCW; ++i) {
+        const int t = wave + 4 * i;
+        const bool reg = (i == TCW - 1) && last_reg;
+        atile[i] = reg ? 0u : (unsigned)(min(t, L.ct0 - 1) * KS) * 1024u;
+    }
+    auto load_a = [&](int i, int kstep) -> half8 {
+        const u32x4 v = ((i == TCW - 1) && last_reg) ? __builtin_amdgcn_raw_buffer_load_b128(ars1, aoff, atile[i] + (unsigned)kstep * 1024u, 0)
+                                                     : __builtin_amdgcn_raw_buffer_load_b128(ars0, aoff, atile[i] + (unsigned)kstep * 1024u, 0);
+        return __builtin_bit_cast(half8, v);
+    };
+    const unsigned blast = last_reg ? (unsigned)HF_BS : 0u;       // B tile of the last channel tile: the box head's or the class head's
+
+    floatx16 acc[TCW][2];
+#pragma unroll
+    for (int i = 0; i < TCW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // the class head's depthwise weights of a chunk: 144 contiguous bytes of the group-major copy -> three scalar loads (uniform address)
+    u32x16 w0a, w0b;
+    u32x4 w0c;
+    auto load_w0 = [&](int c) {
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(L.wd) + (size_t)(c * 4 + wave) * 144;
+        w0a = *(cp_u16)(wp);
+        w0b = *(cp_u16)(wp + 64);
+        w0c = *(cp_u4)(wp + 128);
+    };
+    auto w0tap = [&](int t) -> u32x4 {
+        u32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int d = 4 * t + e; r[e] = d < 16 ? w0a[d] : (d < 32 ? w0b[d - 16] : w0c[d - 32]); }
+        return r;
+    };
+
+#ifdef DN_DEV_STAMPS
+    long long st_dw = 0, st_wait = 0, st_mm = 0;
+    const long long st_begin = (long long)__builtin_amdgcn_s_memtime();
+    const long long st_begin_rt = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    stage_x(0);
+    load_w0(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    HF_T(st_loop);
+
+    unsigned char* const bb = hf_lds + 2 * HF_XS;
+    for (int c = 0; c < NCH; ++c) {
+        const int PAR = c & 1;
+        HF_T(st0);
+        // this chunk's A fragments, first K step: requested now, consumed behind the depthwise phase
+        half8 af0[TCW], af1[TCW];
+#pragma unroll
+        for (int i = 0; i < TCW; ++i) af0[i] = load_a(i, 2 * c);
+        // ---- depthwise of both heads over the chunk's 8-channel group `wave`, pixel `lane`: kernel row by kernel row (three taps and the
+        //      box head's three weight rows in registers at a time)
+        {
+            const unsigned char* xb = hf_lds + PAR * HF_XS;
+            const unsigned char* wb = xb + HF_WOFF + wave * 144;
+            // (opaque per iteration: hipcc otherwise hoists the nine unpacked tap addresses out of the loop -- nine registers again)
+            asm volatile("" : "+v"(tap3[0]), "+v"(tap3[1]), "+v"(tap3[2]));
+            const float4 bl4 = *reinterpret_cast<const float4*>(xb + HF_WOFF + 576 + wave * 32);
+            const float4 bh4 = *reinterpret_cast<const float4*>(xb + HF_WOFF + 576 + wave * 32 + 16);
+            const float4 cl4 = *reinterpret_cast<const float4*>(xb + HF_WOFF + 704 + wave * 32);
+            const float4 ch4 = *reinterpret_cast<const float4*>(xb + HF_WOFF + 704 + wave * 32 + 16);
+            float a0[8] = {cl4.x, cl4.y, cl4.z, cl4.w, ch4.x, ch4.y, ch4.z, ch4.w}, a1[8] = {bl4.x, bl4.y, bl4.z, bl4.w, bh4.x, bh4.y, bh4.z, bh4.w};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                u32x4 tap[3], wv[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    tap[kx] = *reinterpret_cast<const u32x4*>(xb + tap_addr(ky * 3 + kx));
+                    wv[kx] = *reinterpret_cast<const u32x4*>(wb + (ky * 3 + kx) * 16);
+                }
+                // The LDS-DMA of the next chunk goes out HERE, not at the top of the loop: hipcc waits for "every load older than this chunk's A
+                // requests" before it reuses their registers for the first LDS reads (a loop-header scoreboard merge) -- a wait that would
+                // otherwise sit on the DMA it cannot see.
+                if (ky == 0 && c + 1 < NCH) stage_x(c + 1);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) hf_fma8(a0, tap[kx], w0tap(ky * 3 + kx));      // class head: weights in SGPRs
+                if (ky == 2) {
+                    // second K step's A fragments: requested as soon as the last kernel row's operands are in registers
+#pragma unroll
+                    for (int i = 0; i < TCW; ++i) af1[i] = load_a(i, 2 * c + 1);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) hf_fma8v(a1, tap[kx], wv[kx]);                  // box head: weights broadcast from LDS
+                // keep the next row's 24 registers of LDS reads behind this row's multiply-adds: hoisted (hipcc does, for latency) they spill
+                // the tap addresses, and a scratch reload is a VMEM operation that waits in order behind the A-fragment requests
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            unsigned char* bout = bb + PAR * 2 * HF_BS + wave * (HF_P * 16) + lane * 16;
+            half8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o0[e] = (half_t)dn_relu6(a0[e]); o1[e] = (half_t)dn_relu6(a1[e]); }
+            *reinterpret_cast<half8*>(bout) = o0;
+            *reinterpret_cast<half8*>(bout + HF_BS) = o1;
+        }
+        HF_T(st1);
+        // the LDS-DMA of chunk c + 1 is older than the TCW loads requested behind it (the second K step's A fragments): all but those are complete
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TCW) : "memory");
+        __syncthreads();            // B tiles of chunk c written, x run + box-head weights of chunk c + 1 landed
+        HF_T(st2);
+        load_w0(min(c + 1, NCH - 1));       // next chunk's scalar operands: in flight under the matrix phase
+        // ---- GEMM over the chunk: two 16-deep steps
+        {
+            const unsigned char* bc = bb + PAR * 2 * HF_BS;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8 bf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const half8*>(bc + (unsigned)((2 * s + hh) * (HF_P * 16) + (32 * j + r) * 16));
+#pragma unroll
+                for (int i = 0; i < TCW - 1; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s ? af1[i] : af0[i], bf[j], acc[i][j], 0, 0, 0);
+                if (last_on) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const half8 bl = *reinterpret_cast<const half8*>(bc + blast + (unsigned)((2 * s + hh) * (HF_P * 16) + (32 * j + r) * 16));
+                        acc[TCW - 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(s ? af1[TCW - 1] : af0[TCW - 1], bl, acc[TCW - 1][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#ifdef DN_DEV_STAMPS
+        asm volatile("" : "+v"(acc[0][0]));
+        const long long st3 = (long long)__builtin_amdgcn_s_memtime();
+        st_dw += st1 - st0; st_wait += st2 - st1; st_mm += st3 - st2;
+#endif
+    }
+#ifdef DN_DEV_STAMPS
+    const long long st_end_loop = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // ---- epilogue: straight from the accumulators. Lane (r, hh) holds pixel r of each pixel tile and channels 8 g + 4 hh .. + 3 of each channel
+    // tile in registers 4 g .. 4 g + 3: one 16-byte store per (tile, g) -- the two half waves write adjacent pieces, 32 contiguous bytes per
+    // pixel and instruction. (Through a per-wave LDS slab as row-contiguous float2 runs it was 80 dependent LDS round trips per wave: 20 000
+    // cycles of a 100 000-cycle workgroup.) Rows are 8-byte aligned only (nc * 4 B = 2184): global_store_dwordx4 needs dword alignment.
+    unsigned ro[2][2];
+    bool rok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + 32 * j + r;
+        const int img = m / L.hw, pix = m - img * L.hw;
+        rok[j] = m < mend;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ro[h][j] = (unsigned)img * L.out_img_stride[h] + (unsigned)pix * (unsigned)L.nc[h];
+    }
+#pragma unroll
+    for (int i = 0; i < TCW; ++i) {
+        const bool reg = (i == TCW - 1) && last_reg;
+        if (i == TCW - 1 && !last_on) break;
+        const int ct = reg ? 0 : wave + 4 * i;
+        const int nc = reg ? L.nc[1] : L.nc[0];
+        const float* bias = reg ? L.bias[1] : L.bias[0];
+        float* outp = reg ? L.out[1] : L.out[0];
+        float bv[16];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[4 * gq + e] = bias[min(32 * ct + 8 * gq + 4 * hh + e, nc - 1)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* orow = outp + (reg ? ro[1][j] : ro[0][j]);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ch = 32 * ct + 8 * gq + 4 * hh;
+                floatx4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] + bv[4 * gq + e];
+                if (rok[j]) {
+                    if (ch + 4 <= nc) *reinterpret_cast<f32x4_a8*>(orow + ch) = v;
+                    else if (ch + 2 <= nc) *reinterpret_cast<float2*>(orow + ch) = make_float2(v[0], v[1]);       // (nc even, nc % 4 == 2: the last pair)
+                }
+            }
+        }
+    }
+#ifdef DN_DEV_STAMPS
+    if (g.stamps && tid == 0) {
+        long long* sp = g.stamps + (size_t)blockIdx.x * 12;
+        sp[8] = st_begin_rt;
+        sp[9] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+        sp[10] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+        sp[0] = st_loop - st_begin; sp[1] = st_dw; sp[2] = st_wait; sp[3] = st_mm; sp[4] = st_end_loop - st_loop;
+        sp[5] = (long long)__builtin_amdgcn_s_memtime() - st_end_loop; sp[6] = NCH; sp[7] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+}  // namespace
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+bool head_fused_level_supported(const HeadFuseLevel& l) {
+    if (l.C % 32 != 0 || l.C < 32 || l.W > 31 || l.W < 1 || l.H < 1 || l.act != DN_ACT_RELU6) return false;
+    if (l.nc[1] > 32 || l.nc[0] < 1 || l.nc[1] < 1 || !l.wdg || !l.wslot) return false;
+    for (int h = 0; h < 2; ++h) {
+        // rows leave as float2 runs: every row start 8-byte aligned
+        if ((l.nc[h] & 1) || (l.out_img_stride[h] & 1) || (l.out_base[h] & 1) || (reinterpret_cast<size_t>(l.out[h]) & 7)) return false;
+        if ((unsigned long long)l.n * (unsigned long long)l.out_img_stride[h] >= 0xffffffffull) return false;
+        if (!l.wf[h] || !l.bias[h]) return false;
+    }
+    const int tiles = dn_cdiv(l.nc[0], 32) + 1;
+    return dn_cdiv(tiles, 4) <= 5 && (unsigned long long)l.n * l.H * l.W * l.C < 0x80000000ull;
+}
+
+#ifdef DN_DEV_STAMPS
+static long long* g_hf_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) void dn_debug_hf_stamps(void* dev_ptr) { g_hf_stamps = (long long*)dev_ptr; }
+#endif
+static int g_head_fused_launches = 0;
+extern "C" __attribute__((visibility("default"))) int dn_debug_head_fused_launches() { return g_head_fused_launches; }      // tests: the path was taken
+
+int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s) {
+    DN_REQUIRE(count >= 1 && count <= 8, "fused heads: %d levels", count);
+    HfGroup g{};
+    g.count = count; g.xq = xq;
+    int acc = 0, tcw = 0;
+    for (int i = 0; i < count; ++i) {
+        const HeadFuseLevel& l = lv[i];
+        DN_REQUIRE(head_fused_level_supported(l), "fused heads: level %d unsupported (C=%d W=%d nc=%d/%d)", i, l.C, l.W, l.nc[0], l.nc[1]);
+        HfLevel& d = g.lv[i];
+        d.x = l.x; d.wd = l.wdg; d.wslot = l.wslot;
+        for (int h = 0; h < 2; ++h) {
+            d.wf[h] = l.wf[h]; d.bias[h] = l.bias[h];
+            d.out[h] = l.out[h] + l.out_base[h];
+            d.out_img_stride[h] = (unsigned)l.out_img_stride[h];
+            d.nc[h] = l.nc[h];
+        }
+        d.H = l.H; d.W = l.W; d.C = l.C; d.hw = l.H * l.W; d.m = l.n * d.hw; d.act = l.act;
+        d.ct0 = dn_cdiv(l.nc[0], 32);
+        const int t4 = dn_cdiv(d.ct0 + 1, 4);
+        DN_REQUIRE(i == 0 || t4 == tcw, "fused heads: levels differ in channel tiles per wave (%d vs %d)", t4, tcw);
+        tcw = t4;
+        d.tiles = xq > 0 ? dn_cdiv((long)xq * d.hw, HF_P) : dn_cdiv(d.m, HF_P);
+        g.start[i] = acc;
+        acc += d.tiles * (xq > 0 ? 8 : 1);
+    }
+    g.start[count] = acc;
+#ifdef DN_DEV_STAMPS
+    g.stamps = g_hf_stamps;
+#endif
+    dn_note_kernel("head_fused_kernel<%d>", tcw);
+    ++g_head_fused_launches;
+    const dim3 grid(acc), block(256);
+    switch (tcw) {
+        case 1: hipLaunchKernelGGL((head_fused_kernel<1>), grid, block, HF_LDS, s, g); break;
+        case 2: hipLaunchKernelGGL((head_fused_kernel<2>), grid, block, HF_LDS, s, g); break;
+        case 3: hipLaunchKernelGGL((head_fused_kernel<3>), grid, block, HF_LDS, s, g); break;
+        case 4: hipLaunchKernelGGL((head_fused_kernel<4>), grid, block, HF_LDS, s, g); break;
+        case 5: hipLaunchKernelGGL((head_fused_kernel<5>), grid, block, HF_LDS, s, g); break;
+        default: DN_REQUIRE(false, "fused heads: %d channel tiles per wave", tcw);
+    }
+    return DN_OK;
+}

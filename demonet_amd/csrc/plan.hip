@@ -959,6 +959,65 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         for (int q : p->head_dw) if (p->op_wait_level[q] >= lv0 && p->op_wait_level[q] < lv1) h_dw.push_back(q);
         for (int q : p->head_cls) if (p->ops[q].level >= lv0 && p->ops[q].level < lv1) h_cls.push_back(q);
         for (int q : p->head_reg) if (p->ops[q].level >= lv0 && p->ops[q].level < lv1) h_reg.push_back(q);
+        // SSDLite heads (depthwise 3x3 -> 1x1, class and box head per level): ONE launch with the depthwise computed inside the 1x1 GEMM's
+        // operand staging (headfuse.hip) -- no depthwise output in HBM, no second launch. DN_HEAD_FUSE=0 keeps the two grouped launches
+        // (the reference path of the bit-identity test).
+        if (!fuse_sm && dn_knob("DN_HEAD_FUSE", 1) != 0 && !h_dw.empty() && !h_cls.empty() && !h_reg.empty()) {
+            HeadFuseLevel fl[8];
+            int nl = 0;
+            std::vector<int> members;
+            for (size_t q = 0; q < h_cls.size() && nl < 8; ++q) {
+                // a level joins when its class and box head are both (depthwise 3x3 stride 1 -> 1x1) chains on the level's feature map
+                const dn_op_desc& oc = p->ops[h_cls[q]];
+                int qr = -1;
+                for (int u : h_reg) if (p->ops[u].level == oc.level) qr = u;
+                if (qr < 0 || oc.type != DN_OP_PW || p->ops[qr].type != DN_OP_PW) continue;
+                const dn_op_desc& orr = p->ops[qr];
+                int dc = -1, dr = -1;
+                for (int u : h_dw) { if (p->ops[u].out == oc.in) dc = u; if (p->ops[u].out == orr.in) dr = u; }
+                if (dc < 0 || dr < 0) continue;
+                const dn_op_desc &odc = p->ops[dc], &odr = p->ops[dr];
+                if (odc.in != odr.in || odc.k != 3 || odr.k != 3 || odc.stride != 1 || odr.stride != 1 || odc.pad != 1 || odr.pad != 1 || odc.dil != 1 ||
+                    odr.dil != 1 || odc.act != odr.act || odc.cin != odr.cin || oc.cin != odc.cin || orr.cin != odc.cin || oc.act != DN_ACT_NONE ||
+                    orr.act != DN_ACT_NONE || oc.se >= 0 || orr.se >= 0 || oc.residual >= 0 || orr.residual >= 0 || oc.w2_off < 0 || orr.w2_off < 0 ||
+                    odc.pool >= 0 || odr.pool >= 0) continue;
+                const dn_tensor_desc& ti = p->tensors[odc.in];
+                HeadFuseLevel& f = fl[nl];
+                f.x = reinterpret_cast<const half_t*>(tptr(odc.in));
+                const dn_op_desc* op[2] = {&oc, &orr};
+                for (int hsel = 0; hsel < 2; ++hsel) {
+                    const PwArgs pa = make_pw(*op[hsel]);
+                    f.wf[hsel] = pa.wfrag; f.bias[hsel] = pa.bias;
+                    f.out[hsel] = reinterpret_cast<float*>(pa.out); f.out_img_stride[hsel] = pa.out_img_stride; f.out_base[hsel] = pa.out_base;
+                    f.nc[hsel] = pa.cout;
+                }
+                f.wdg = odc.w2_off >= 0 ? reinterpret_cast<const half_t*>(Wb + odc.w2_off) : nullptr;
+                f.wslot = odc.b2_off >= 0 ? Wb + odc.b2_off : nullptr;
+                f.n = n; f.H = ti.h; f.W = ti.w; f.C = odc.cin; f.act = odc.act;
+                if (!head_fused_level_supported(f)) continue;
+                // DN_HEAD_FUSE_MINHW: levels with fewer pixels per image stay on the grouped launches. The fused workgroups take 512 residency
+                // slots (2 per CU); at batch 64 levels 0 - 1 are 504 of them, every further workgroup starts a second round of the whole launch
+                if (ti.h * ti.w < dn_knob("DN_HEAD_FUSE_MINHW", 0)) continue;
+                if (nl > 0 && (dn_cdiv(f.nc[0], 32) + 4) / 4 != (dn_cdiv(fl[0].nc[0], 32) + 4) / 4) continue;      // (one instantiation per launch: channel tiles per wave)
+                ++nl;
+                members.push_back(dc); members.push_back(dr); members.push_back(h_cls[q]); members.push_back(qr);
+            }
+            if (nl > 0) {
+                rc = launch_head_fused(fl, nl, xq, hs);
+                if (rc != DN_OK) return rc;
+                for (int q : members) hnote(q, seg);
+                ++seg;
+                if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
+                // what did not join (the V2 model's last level is a plain 1x1 conv) takes the grouped launches below
+                auto drop = [&](std::vector<int>& v) {
+                    std::vector<int> keep;
+                    for (int q : v) if (std::find(members.begin(), members.end(), q) == members.end()) keep.push_back(q);
+                    v.swap(keep);
+                };
+                drop(h_dw); drop(h_cls); drop(h_reg);
+                if (h_cls.empty() && h_reg.empty() && h_dw.empty()) return DN_OK;
+            }
+        }
         if (!h_dw.empty()) {
             DwArgs arr[12];
             for (size_t q = 0; q < h_dw.size(); ++q) arr[q] = make_dw(p->ops[h_dw[q]]);

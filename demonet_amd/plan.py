@@ -73,6 +73,7 @@ class LoweredModel:
         for i, t in enumerate(g.tensors):
             self.tensors[i] = _lib.TensorDesc(t.c, t.h, t.w, _lib.DN_T[t.kind])
         ops = []
+        head_inputs = {nd.inp for nd in g.nodes if nd.head}          # tensors a head op reads: the depthwise outputs of the SSDLite heads
         for nd in g.nodes:
             o = _lib.OpDesc()
             o.type = _lib.DN_OP[nd.op]
@@ -92,16 +93,21 @@ class LoweredModel:
                 wf = (w * s[:, None]).astype(np.float16)
                 o.w_off = blob.add(wf)
                 o.b_off = blob.add(b.astype(np.float32))
-                if nd.cin % 8 == 0 and (not nd.head or nd.head == 1):
+                if nd.cin % 8 == 0:
                     # second copy in MFMA-fragment order for the kernels that stream weights straight from L2 into A fragments
-                    # (tail.hip): [cout tile of 32][16-deep K step][lane = (k half, channel)][8 halfs] -> each wave-wide load is
-                    # 1 KB contiguous instead of 32 row pieces of 32 B
+                    # (tail.hip, the strip kernel, headfuse.hip -- class AND box heads): [cout tile of 32][16-deep K step][lane = (k half, channel)][8 halfs]
+                    # -> each wave-wide load is 1 KB contiguous instead of 32 row pieces of 32 B
                     o.w2_off = blob.add(fragment_major(wf))
             elif nd.op == "dw":
                 w = _np(state_dict, nd.conv_key + ".weight").reshape(nd.cin, nd.k * nd.k)
                 s, b = _fold(state_dict, nd, nd.cin)
-                o.w_off = blob.add((w * s[:, None]).T.astype(np.float16))  # [k*k][c]
+                wf = (w * s[:, None]).astype(np.float16)                   # [c][k*k]
+                o.w_off = blob.add(np.ascontiguousarray(wf.T))             # [k*k][c]
                 o.b_off = blob.add(b.astype(np.float32))
+                if nd.out in head_inputs and nd.k == 3 and nd.cin % 8 == 0:
+                    # second copy in GROUP-major order for the fused head launch (headfuse.hip): [c / 8][9 taps][8] -- the nine taps of an
+                    # 8-channel group are 144 contiguous bytes (three scalar loads / one piece of an LDS-DMA instead of nine strided rows)
+                    o.w2_off = blob.add(np.ascontiguousarray(wf.reshape(nd.cin // 8, 8, 9).transpose(0, 2, 1)))
             elif nd.op == "se":
                 w1 = _np(state_dict, nd.fc1_key + ".weight").reshape(nd.squeeze, nd.cin)
                 w2 = _np(state_dict, nd.fc2_key + ".weight").reshape(nd.cin, nd.squeeze)
@@ -124,6 +130,30 @@ class LoweredModel:
             else:
                 raise ValueError(nd.op)
             ops.append(o)
+        # SSDLite heads, fused launch (headfuse.hip): per level ONE array of 1 KB slots, one per 32-channel chunk -- the box head's depthwise
+        # weights of the chunk [4 groups][9 taps][8] fp16 (576 B), its bias [32] fp32, the class head's bias [32] fp32, zero pad -- what one
+        # LDS-DMA instruction of the kernel copies per chunk. Stored as b2_off of the class head's depthwise op.
+        by_out = {nd.out: i for i, nd in enumerate(g.nodes)}
+        heads = {}
+        for nd in g.nodes:
+            if nd.op == "pw" and nd.head and nd.inp in by_out and g.nodes[by_out[nd.inp]].op == "dw":
+                heads.setdefault(nd.level, {})[nd.head] = by_out[nd.inp]
+        for lvl, hd in heads.items():
+            if 1 not in hd or 2 not in hd:
+                continue
+            ic, ir = hd[1], hd[2]
+            nc_, nr_ = g.nodes[ic], g.nodes[ir]
+            if nc_.inp != nr_.inp or nc_.cin != nr_.cin or nc_.k != 3 or nr_.k != 3 or nc_.cin % 32 != 0 or ops[ir].w2_off < 0:
+                continue
+            C_ = nc_.cin
+            wr = np.frombuffer(blob.bytes()[ops[ir].w2_off:ops[ir].w2_off + C_ * 18], dtype=np.float16).reshape(C_ // 32, 288)
+            br = np.frombuffer(blob.bytes()[ops[ir].b_off:ops[ir].b_off + C_ * 4], dtype=np.float32).reshape(C_ // 32, 32)
+            bc = np.frombuffer(blob.bytes()[ops[ic].b_off:ops[ic].b_off + C_ * 4], dtype=np.float32).reshape(C_ // 32, 32)
+            slot = np.zeros((C_ // 32, 1024), dtype=np.uint8)
+            slot[:, 0:576] = wr.view(np.uint8).reshape(C_ // 32, 576)
+            slot[:, 576:704] = br.view(np.uint8).reshape(C_ // 32, 128)
+            slot[:, 704:832] = bc.view(np.uint8).reshape(C_ // 32, 128)
+            ops[ic].b2_off = blob.add(slot)
         self.ops = (_lib.OpDesc * len(ops))(*ops)
         self.blob = blob.bytes()
         grid = [(g.t(f).h, g.t(f).w) for f in g.features]

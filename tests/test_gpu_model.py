@@ -552,12 +552,43 @@ def test_head_xs_logits_bit_identical(n, monkeypatch):
     for flag in ("0", "1"):
         monkeypatch.setenv("DN_HEAD_XS", flag)
         monkeypatch.setenv("DN_HEAD_XS_MIN", "64")
+        monkeypatch.setenv("DN_HEAD_FUSE", "0")          # (an alternative of the two-launch head path)
         m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
         before = raw.dn_debug_head_xs_launches()
         res[flag] = [t.clone() for t in m.forward_heads(imgs)]
         launches[flag] = raw.dn_debug_head_xs_launches() - before
     assert launches["0"] == 0 and launches["1"] >= 1, launches
     assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
+@pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 64), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
+                                           ("ssdlite320_mobilenet_v3_large", 91, {}, 3), ("ssdlite320_mobilenet_v3_large", 21, {}, 9),
+                                           ("ssd_lite_mobilenet_v2", 91, {}, 16), ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 9)])
+def test_fused_head_launch_is_bit_identical(name, ncls, kw, n, monkeypatch):
+    """Round 4 (headfuse.hip, default on): the heads of every pyramid level -- depthwise 3x3 + ReLU6 and the 1x1 behind it, class and box head -- run as ONE
+    launch with the depthwise computed inside the GEMM's operand staging (`_prediction_block`, ssd_mobilenetv3.py:27-36; generalized_ssd.py:60-74).
+    Same arithmetic at the same rounding points as dw_group_kernel + pw_group_kernel (bias first, taps in (ky, kx) order, fp32 accumulate, one rounding
+    to fp16; one accumulator per output, K ascending, bias added last): logits and box regressions equal BIT FOR BIT -- batch 64 (XCD grouping, 8 images
+    per group), 37 (two sub-batch chains, ragged groups), 3 (plain mapping, tiles spanning images on every level), K = 21 (two channel tiles per wave
+    instead of five), the V2 model (other channel counts) and its 300 x 300 form (19 x 19 / 10 x 10 ... maps)."""
+    import ctypes
+    from demonet_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    size = kw.get("image_size", 320)
+    imgs = torch.from_numpy(synth.images(29, n, size, size)).cuda()
+    res, launches = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_HEAD_FUSE", flag)
+        m = _model(name, num_classes=ncls, **kw)
+        before = raw.dn_debug_head_fused_launches()
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        launches[flag] = raw.dn_debug_head_fused_launches() - before
+        again = m.forward_heads(imgs)                       # graph replay
+        assert torch.equal(res[flag][0], again[0]) and torch.equal(res[flag][1], again[1])
+    assert launches["0"] == 0 and launches["1"] >= 1, launches
+    assert torch.isfinite(res["1"][0]).all() and torch.isfinite(res["1"][1]).all()
+    assert torch.equal(res["0"][0], res["1"][0]), (res["0"][0] - res["1"][0]).abs().max().item()
+    assert torch.equal(res["0"][1], res["1"][1]), (res["0"][1] - res["1"][1]).abs().max().item()
 
 
 @pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
