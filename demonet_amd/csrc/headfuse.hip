@@ -56,7 +56,7 @@ struct HfLevel {
     int nc[2];
     int H, W, C, hw, m;              // m = n * hw
     int act;                         // depthwise activation
-    int tiles;                       // 64-pixel tiles per XCD group (plain mapping: of the whole level)
+    int tiles;                       // 64-pixel tiles per XCD group; 0: this level uses the plain mapping (tiles of the whole level)
     int ct0;                         // channel tiles of the class head; the box head is tile ct0
 };
 struct HfGroup {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
     const HfLevel& L = g.lv[p];
     const int flat = blockIdx.x - g.start[p];
     int m0, mend;
-    if (g.xq > 0) {
+    if (g.xq > 0 && L.tiles > 0) {
         const int grp = flat & 7, t = flat >> 3;
         const int r0 = grp * g.xq * L.hw;
         mend = min(L.m, r0 + g.xq * L.hw);
@@ -410,9 +410,13 @@ int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s)
         const int t4 = dn_cdiv(d.ct0 + 1, 4);
         DN_REQUIRE(i == 0 || t4 == tcw, "fused heads: levels differ in channel tiles per wave (%d vs %d)", t4, tcw);
         tcw = t4;
-        d.tiles = xq > 0 ? dn_cdiv((long)xq * d.hw, HF_P) : dn_cdiv(d.m, HF_P);
+        // XCD grouping (a group of xq images per workgroup residue mod 8) only where a group fills whole tiles: on the small maps the ragged last
+        // tile of every group is most of the level (5 x 5: 32 workgroups instead of 25) and every workgroup beyond the 512 resident ones starts
+        // a second round of the launch
+        const bool grouped = xq > 0 && (long)xq * d.hw >= 4 * HF_P;
+        d.tiles = grouped ? dn_cdiv((long)xq * d.hw, HF_P) : 0;
         g.start[i] = acc;
-        acc += d.tiles * (xq > 0 ? 8 : 1);
+        acc += grouped ? d.tiles * 8 : dn_cdiv(d.m, HF_P);
     }
     g.start[count] = acc;
 #ifdef DN_DEV_STAMPS

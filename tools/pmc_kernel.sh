@@ -3,7 +3,7 @@
 # program directly after `--`), averaged per launch -> gpurun_out/<tag>/pmc_<name>.txt
 #   usage: tools/pmc_kernel.sh <tag> <name> <kernel regex> [env K=V ...] -- [bench args]
 # Groups: SQ issue / wait split, SQ pipes, LDS, L1 (TCP) and L2 (TCC) requests. Counter names that this rocprofv3 does not know are
-# reported by the pass that asked for them (log_pmc_<name>_<i>.txt) and simply missing from the table.
+# reported by the pass that asked for them (log_pmc_<name>_<i>.txt) and simply missing from the table. TA_* counters are left out: they abort rocprofv3 here.
 TAG=$1; NAME=$2; REGEX=$3; shift 3
 ENVS=()
 while [ "$1" != "--" ] && [ $# -gt 0 ]; do ENVS+=("$1"); shift; done
@@ -21,10 +21,14 @@ GROUPS_=(
  "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum"
  "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_WRITE_sum"
  "GRBM_GUI_ACTIVE GRBM_COUNT"
+ "TD_TD_BUSY_sum TD_TC_STALL_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+ "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum"
+ "TCC_BUSY_avr TCC_TAG_STALL_sum TCC_CYCLE_sum TCC_EA0_RDREQ_32B_sum"
 )
 i=0
 for g in "${GROUPS_[@]}"; do
-  rocprofv3 --pmc $g --kernel-trace --output-format csv -d /tmp/pk_$NAME/$i -o p -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/log_pmc_${NAME}_$i.txt 2>&1
+  # (every pass under its own timeout: a TA_* group aborted rocprofv3 on this image and its finalization then hung for the whole call)
+  timeout 180 rocprofv3 --pmc $g --kernel-trace --output-format csv -d /tmp/pk_$NAME/$i -o p -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/log_pmc_${NAME}_$i.txt 2>&1
   i=$((i+1))
 done
 python3 - "$REGEX" /tmp/pk_$NAME $OUT/pmc_$NAME.txt <<'PY'

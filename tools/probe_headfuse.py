@@ -24,6 +24,9 @@ m = models.load_synthetic(models.ssdlite320_mobilenet_v3_large(num_classes=91), 
 m.set_graph_mode(False) if hasattr(m, "set_graph_mode") else None
 os.environ["DN_GRAPH"] = "0"
 imgs = torch.from_numpy(synth.images(5, n, 320, 320)).cuda()
+m.forward_heads(imgs)
+if os.environ.get("PROBE_CHAINS"):       # e.g. 1: the whole batch as ONE chain (what a forward in flight runs)
+    _lib.check(L.dn_set_chains(C.c_void_p(m._handle), int(os.environ["PROBE_CHAINS"])))
 for _ in range(3):
     m.forward_heads(imgs)
 torch.cuda.synchronize()
@@ -55,3 +58,9 @@ for c in np.unique(cu):
 pk = np.array([v[0] for v in peak.values()])
 print(f"  compute units used {len(peak)}; workgroups alive at once per CU: max {pk.max()}, mean {pk.mean():.2f}; workgroups per CU: max {max(v[1] for v in peak.values())}")
 print(f"  kernel span first START - last END {(s[:, 7].max() - s[:, 8].min()) * 0.01:.1f} us; mean workgroup life {((s[:, 7] - s[:, 8]) * 0.01).mean():.1f} us")
+
+# timeline: workgroups alive per 5-us bin
+t0 = s[:, 8].min()
+bins = np.arange(0, (s[:, 7].max() - t0) * 0.01 + 5, 5.0)
+alive = [int(((s[:, 8] - t0) * 0.01 <= b + 2.5).sum() - ((s[:, 7] - t0) * 0.01 <= b + 2.5).sum()) for b in bins]
+print("  alive at t =", " ".join(f"{int(b)}:{a}" for b, a in zip(bins, alive)))
