@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdemonet_hip.so")
-SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "trunk.hip", "pwdirect.hip", "loss.hip", "headfuse.hip"]
+SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "pwdirect.hip", "loss.hip", "headfuse.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, not AGPRs -- the small-tile kernels otherwise spend a v_accvgpr_read per
 # accumulator value on the way to their epilogues (not for convbig.hip: its 256 x 256 tiles need the AGPR half of the file)
 VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]

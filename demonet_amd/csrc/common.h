@@ -156,13 +156,6 @@ struct PwArgs {
     long out_base;          // element offset of image 0 (head ops: level offset * columns)
     long long* stamps = nullptr;   // dev-only phase stamps
     int xq = 0;             // XCD grouping: images per group (0: plain mapping); see xcd_images_per_group
-    // Softmax in the epilogue of an fp32 class-head problem (grouped launch only, round 3): instead of the logits rows the tile's class
-    // scores go straight into the post-process's class-major array (stored order, PostLevels) and its score histogram; a channel tile
-    // then covers whole anchors (sm_apt = BC / K of them, set by the launcher). `out` is not written.
-    float* sm_scores = nullptr;    // [n][K-1][A]
-    unsigned* sm_hist = nullptr;   // [n][256], zeroed before the launch
-    int sm_K = 0, sm_A = 0, sm_off = 0, sm_aloc = 0, sm_apt = 0;      // classes incl. background, anchors per image, level offset, anchors per location
-    float sm_thr = 0.f; int sm_hb0 = 0, sm_nb = 0;                   // score threshold and the histogram's bin range (post_hist_range)
 };
 constexpr int DN_PP_HSHIFT = 19;      // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
 constexpr int DN_PP_HBINS = 256;      // bins kept: the top 256 (scores down to 2^-16); anything lower shares bin 0
@@ -181,13 +174,9 @@ bool conv_patch_pool_ok(int cin, int cout, int h, int w);
 int launch_conv_patch_pool(const PwArgs& a, hipStream_t s);      // a.pool_out set
 bool conv_head_big_supported(const PwArgs& a);
 int launch_conv_head_big(const PwArgs& a, hipStream_t s);
-bool pw_head_big_supported(const PwArgs& a);
 struct DwArgs;
 bool pw_dw_direct_supported(const PwArgs& a, const DwArgs& d);      // depthwise 3x3 + the 1x1 behind it in one register-direct launch (pwdirect.hip)
 int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s);
-int launch_pw_head_big(const PwArgs& a, hipStream_t s);
-bool head_xs_supported(const PwArgs& a);      // X-stationary 1x1 class head of a large level (pointwise.hip)
-int launch_head_xs(const PwArgs& a, hipStream_t s);
 // SSDLite heads, depthwise 3x3 inside the 1x1 GEMM's operand staging: every level, both heads, one launch (headfuse.hip).
 // Index 0 = class head, 1 = box head; both read the level's feature map x.
 struct HeadFuseLevel {
@@ -215,12 +204,11 @@ struct DwArgs {
     const half_t* se_w2t = nullptr; const float* se_b2 = nullptr;      // fc2 transposed [sq][c] fp16, bias [c]
     float* se_scale = nullptr; unsigned* se_counter = nullptr;
     int se_sq = 0; float se_inv = 0.f;                                 // squeeze width, 1 / pooled pixels
-    float* dbg = nullptr;                                              // dev-only (dn_debug_dw_table)
     int pool_rows = 0;                                                 // rows per image the plan sized `pool` for (0: the launcher's own choice)
 };
 bool depthwise_se_tail_supported(int c, int squeeze);
 int launch_depthwise(const DwArgs& a, hipStream_t s);
-int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_u32 = nullptr, int zero_count = 0);   // (optional: words the launch clears)
+int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s);
 int depthwise_pool_blocks(const DwArgs& a);       // workgroups per image == partial-sum rows per image
 
 struct StemArgs {
@@ -247,6 +235,7 @@ struct ConvArgs {
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 PwArgs conv_to_pw(const ConvArgs& c);
+int launch_poison(hipStream_t s);     // DN_POISON: NaN patterns into every LDS byte and vector register (dense.hip)
 int launch_maxpool(const half_t* x, half_t* out, int n, int h, int w, int c, int k, int stride, int pad, int ho, int wo,
                    hipStream_t s);
 int launch_l2norm(const half_t* x, const float* scale, half_t* out, long pixels, int c, hipStream_t s);
@@ -274,31 +263,6 @@ struct TailArgs {
 };
 int launch_tail(const TailArgs& a, int n, hipStream_t s);
 bool tail_op_supported(const dn_op_desc& o, int hin, int win, int hout, int wout);
-
-// run of inverted-residual blocks on the small maps, one workgroup per image (trunk.hip)
-constexpr int TRUNK_MAX_BLOCKS = 8;
-struct TrunkBlock {
-    int cin, cexp, cout, k, stride, pad, act1, act2, hin, hout, has_se, sq, has_res;
-    int w1f_off, b1_off, wd_off, bd_off, w3f_off, b3_off;      // byte offsets into the weight blob (expand / project: fragment-major copies)
-    int se_w1t_off, se_b1_off, se_w2t_off, se_b2_off;
-    int dsc_off;                    // halfs: this block's slice of the per-image scratch that parks the depthwise output of an SE block
-    int pad_;
-    half_t* feat_out;               // non-null: the expanded map is a pyramid feature, also written to HBM [n][hin*hin][cexp]
-    long feat_stride;               // halfs per image
-};
-struct TrunkArgs {
-    int count, xq;
-    int cin0, px0, cout_last, px_last;
-    const half_t* in0; long in0_stride;         // first block's input [n][pixels][cin], per-image stride in halfs
-    half_t* out; long out_stride;               // last block's output
-    half_t* dscratch; long dscratch_stride;     // [n][dscratch_stride] halfs
-    const half_t* weights;
-    long long* stamps;                          // dev-only
-    TrunkBlock blk[TRUNK_MAX_BLOCKS];
-};
-int launch_trunk(const TrunkArgs& a, int n, hipStream_t s);
-bool trunk_block_supported(int cin, int cexp, int cout, int k, int stride, int hin, int hout, int sq);
-size_t trunk_lds_bytes();
 
 // expand 1x1 + depthwise kxk in one launch (expdw.hip)
 struct ExpDwArgs {
@@ -359,11 +323,7 @@ struct PostArgs {
     void* ws; size_t ws_bytes;
     int xq = 0;                 // XCD grouping: images per group (0: plain mapping)
     PostLevels lv;              // default: one level with one anchor per location (stored order == canonical order)
-    int fused = 0;              // 1: the class scores and their histogram were written by the head launch (pointwise.hip, softmax epilogue)
 };
 size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets);
-// where the head launch's softmax epilogue must write (PwArgs::sm_*): the score array and the per-image histogram inside the workspace,
-// and the reachable histogram bins for a score threshold
-void postprocess_fused_targets(void* ws, int n, int A, int K, int topk, float** scores, unsigned** hist);
 void post_hist_range(float score_thresh, int* hb0, int* nb, int* clamped);
 int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev /* optional [4] phase boundaries */);

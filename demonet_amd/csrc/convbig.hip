@@ -799,30 +799,6 @@ int launch_conv_big(const PwArgs& a, hipStream_t s) {
     return DN_OK;
 }
 
-// The 1x1 class head of a large pyramid level (SSDLite: 672 -> 546 on the 20 x 20 map is a quarter of the network's MACs) on the
-// 256 x 256 tile with fp32 output. MEASURED and left off (DN_PW_HEAD_BIG=1 opts in): 120 us for the 64-image launch (156 TFLOP/s)
-// against 110 us for ALL head levels in the grouped 128 x 128-tile launch -- batch 64 0.792 -> 0.813 ms. The reduction is only 11
-// stages long, so the 256 KB fp32 epilogue of a workgroup (two passes through LDS, scattered 8-byte stores) weighs as much as its
-// main loop, and with one workgroup per CU nothing runs under it; 546 channels also waste 29 % of three 256-wide tiles.
-bool pw_head_big_supported(const PwArgs& a) {
-    const int on = dn_knob("DN_PW_HEAD_BIG", 0);
-    const int minwg = dn_knob("DN_PW_HEAD_BIG_MIN", 100);
-    if (!on || !a.out_fp32 || a.residual || a.se || !a.zeros || a.cv_k != 1 || a.cv_stride != 1 || a.cv_pad != 0 || a.cv_ho != a.cv_h || a.cv_wo != a.cv_w) return false;
-    if (a.cin % 8 || a.cin < 2 * GK || a.cin != a.cv_cin || (a.cout & 1)) return false;
-    if ((long)a.m * a.cin * 2 >= (1L << 31) || (long)(a.cout + a.cout_b) * a.cin * 2 >= (1L << 31)) return false;
-    const int tiles = dn_cdiv(a.cout + a.cout_b, BC);
-    return (a.cout + a.cout_b) * 10 >= tiles * BC * 6 && (long)dn_cdiv(a.m, BP) * tiles >= minwg;
-}
-
-int launch_pw_head_big(const PwArgs& a, hipStream_t s) {
-    const size_t otile = (size_t)2 * (BP / 2) * (BC + 4), st = (size_t)2 * GSTAGE;       // fp32 epilogue tile (two halves) / stage buffers, in halfs
-    const size_t lds = (st > otile ? st : otile) * sizeof(half_t) + BC * sizeof(float);
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_glds_kernel<true>)));
-    dn_note_kernel("conv_glds_kernel<head>");
-    hipLaunchKernelGGL(conv_glds_kernel<true>, dim3(dn_cdiv(a.m, BP), dn_cdiv(a.cout + a.cout_b, BC)), dim3(256), lds, s, a);
-    return DN_OK;
-}
-
 // Dense 3x3 heads with fp32 outputs (SSDHead, generalized_ssd.py:77-92) on the run-staged 256x256 tile; channel tiles beyond cout
 // compute on the last weight row and are not stored.
 bool conv_patch_pool_ok(int cin, int cout, int h, int w) {

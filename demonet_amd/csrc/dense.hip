@@ -163,3 +163,40 @@ int launch_u8hwc_to_planar(const unsigned char* in, float* out, float* scale_xy,
     hipLaunchKernelGGL(u8hwc_kernel, dim3(dn_cdiv(threads, 256)), dim3(256), 0, s, in, out, scale_xy, n, h, w, oh, ow);
     return DN_OK;
 }
+
+
+// ---- DN_POISON (correctness tooling, tests/test_gpu_pipeline.py::test_results_do_not_depend_on_stale_lds_or_registers): a launch that
+// leaves NaN patterns in every LDS byte and every vector register (VGPR and AGPR) of the compute units it lands on. plan.hip puts one in
+// front of every launch of a forward when the knob is set: a kernel that reads LDS or a register it has not written itself then
+// produces a different (NaN) result than in an undisturbed run. One 256-thread workgroup takes a whole CU (160 KB of LDS, 512
+// registers per lane: one wave per SIMD); 1024 of them pass over every CU.
+__global__ __launch_bounds__(256, 1) void poison_kernel(unsigned* sink) {
+    extern __shared__ unsigned poison_lds[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) poison_lds[i] = 0x7fc0dead;
+    unsigned v = 0x7fc0dead;
+    // every architectural VGPR and AGPR of the wave
+#define PZ4(b) "v_mov_b32 v" #b ", %0\n\tv_accvgpr_write_b32 a" #b ", %0\n\t"
+#define PZ(n) asm volatile("v_mov_b32 v" #n ", %0\n\tv_accvgpr_write_b32 a" #n ", %0" :: "v"(v) : "v" #n, "a" #n);
+#define PZ8(a, b, c, d, e, f, g, h) PZ(a) PZ(b) PZ(c) PZ(d) PZ(e) PZ(f) PZ(g) PZ(h)
+    PZ8(8, 9, 10, 11, 12, 13, 14, 15) PZ8(16, 17, 18, 19, 20, 21, 22, 23) PZ8(24, 25, 26, 27, 28, 29, 30, 31)
+    PZ8(32, 33, 34, 35, 36, 37, 38, 39) PZ8(40, 41, 42, 43, 44, 45, 46, 47) PZ8(48, 49, 50, 51, 52, 53, 54, 55) PZ8(56, 57, 58, 59, 60, 61, 62, 63)
+    PZ8(64, 65, 66, 67, 68, 69, 70, 71) PZ8(72, 73, 74, 75, 76, 77, 78, 79) PZ8(80, 81, 82, 83, 84, 85, 86, 87) PZ8(88, 89, 90, 91, 92, 93, 94, 95)
+    PZ8(96, 97, 98, 99, 100, 101, 102, 103) PZ8(104, 105, 106, 107, 108, 109, 110, 111) PZ8(112, 113, 114, 115, 116, 117, 118, 119)
+    PZ8(120, 121, 122, 123, 124, 125, 126, 127) PZ8(128, 129, 130, 131, 132, 133, 134, 135) PZ8(136, 137, 138, 139, 140, 141, 142, 143)
+    PZ8(144, 145, 146, 147, 148, 149, 150, 151) PZ8(152, 153, 154, 155, 156, 157, 158, 159) PZ8(160, 161, 162, 163, 164, 165, 166, 167)
+    PZ8(168, 169, 170, 171, 172, 173, 174, 175) PZ8(176, 177, 178, 179, 180, 181, 182, 183) PZ8(184, 185, 186, 187, 188, 189, 190, 191)
+    PZ8(192, 193, 194, 195, 196, 197, 198, 199) PZ8(200, 201, 202, 203, 204, 205, 206, 207) PZ8(208, 209, 210, 211, 212, 213, 214, 215)
+    PZ8(216, 217, 218, 219, 220, 221, 222, 223) PZ8(224, 225, 226, 227, 228, 229, 230, 231) PZ8(232, 233, 234, 235, 236, 237, 238, 239)
+    PZ8(240, 241, 242, 243, 244, 245, 246, 247) PZ8(248, 249, 250, 251, 252, 253, 254, 255)
+#undef PZ8
+#undef PZ
+#undef PZ4
+    __syncthreads();
+    if (sink && poison_lds[threadIdx.x] == 1u) sink[0] = v;      // (keeps the LDS stores alive; never true)
+}
+
+int launch_poison(hipStream_t s) {
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(poison_kernel)));
+    hipLaunchKernelGGL(poison_kernel, dim3(1024), dim3(256), 160 * 1024, s, (unsigned*)nullptr);
+    return DN_OK;
+}

@@ -11,18 +11,6 @@
 
 static long long* g_se_stamps = nullptr;     // dev hook (tools/probe_se.py)
 extern "C" __attribute__((visibility("default"))) void dn_debug_se_stamps(void* dev_ptr) { g_se_stamps = (long long*)dev_ptr; }
-// dev hook (tools/hunt_dw_rows.py): pooling launches whose partial-sum buffer is in the table also dump every thread's fp32 outputs and
-// pooled sums ([workgroup][256][TW * 8 + 8] floats) to buf + index * stride_bytes
-static const void* g_dw_dbg_pool[64];
-static int g_dw_dbg_count = 0;
-static unsigned char* g_dw_dbg_buf = nullptr;
-static size_t g_dw_dbg_stride = 0;
-extern "C" __attribute__((visibility("default"))) void dn_debug_dw_table(const void* const* pool_ptrs, int count, void* buf, size_t stride_bytes) {
-    g_dw_dbg_count = count < 64 ? (count > 0 ? count : 0) : 64;
-    for (int i = 0; i < g_dw_dbg_count; ++i) g_dw_dbg_pool[i] = pool_ptrs[i];
-    g_dw_dbg_buf = (unsigned char*)buf;
-    g_dw_dbg_stride = stride_bytes;
-}
 
 namespace {
 
@@ -162,7 +150,7 @@ __device__ __forceinline__ bool dw_se_tail_is_small(int c, int sq, int nblk) { r
 
 // POOL: 0 = none, 1 = per-workgroup channel sums for the squeeze-excitation, 2 = sums + the FCs in the image's last workgroup
 //   (dw_se_tail: its 16-row load batches need 114 registers, which capped EVERY pooling launch while the code was compiled into all of them).
-// MODE bit 0: one kernel row of loads at a time instead of the batched rows (DN_DW_ROWS; see RP below); bit 1: debug dump (dn_debug_dw_table).
+// MODE bit 2: software-pipelined kernel rows (below); 0: the batched rows.
 template <int K, int S, int TW, int POOL, int MODE>
 __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int nblocks, const int n) {
     constexpr int NIN = (TW - 1) * S + K;
@@ -206,7 +194,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
     // RP kernel rows are requested together before their first use: hipcc otherwise waits for each row's loads before
     // issuing the next row's (vmcnt(0) per row), i.e. K dependent memory round trips per thread. 3x3 takes all rows at once;
     // 5x5 two at a time (all five would need 260 VGPRs of staging).
-    constexpr int RP = (MODE & 1) ? 1 : ((K == 3) ? 3 : 2);
+    constexpr int RP = (K == 3) ? 3 : 2;
     const half_t* const wbase = a.w + c0;
     const half_t* const xbase = a.x + (size_t)n * a.h * a.w_ * a.c + c0;
     if constexpr ((MODE & 4) != 0) {
@@ -281,22 +269,8 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int bx, const int
             o[e] = (half_t)acc[t][e];
         }
         *reinterpret_cast<half8*>(orow + (unsigned)((ox0 + t) * a.c)) = o;
-        if constexpr ((MODE & 2) != 0) {
-            if (a.dbg) {
-                float* dp = a.dbg + ((size_t)(n * nblocks + bx) * 256 + threadIdx.x) * (TW * 8 + 8) + t * 8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dp[e] = acc[t][e];
-            }
-        }
     }
     }   // valid
-    if constexpr ((MODE & 2) != 0) {
-        if (a.dbg) {
-            float* dp = a.dbg + ((size_t)(n * nblocks + bx) * 256 + threadIdx.x) * (TW * 8 + 8) + TW * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dp[e] = psum[e];
-        }
-    }
     if constexpr (POOL != 0) {
         // SE squeeze (mobilenetv3.py:32 adaptive_avg_pool2d) fused as deterministic per-workgroup partial sums:
         // threads with equal channel group sit C8 apart; thread t < C8 adds them in a fixed order.
@@ -354,217 +328,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 4) 
     dw_body<K, S, TW, POOL, MODE>(a, bx, nblocks, img);
 }
 
-// ---- LDS-tiled depthwise for the 5x5 layers (round 3) --------------------------------------------------------------------------
-// The register-window kernel above re-reads every input row K times from L1 in K/RP dependent round trips at 2 - 3 waves per SIMD
-// (126 - 172 registers): the 5x5 launches ran at 1.2 - 2.0 TB/s, five times above their multiply-add floor. Here a workgroup owns an
-// OTH x OTW output tile of one image and a chunk of `cgw` consecutive 8-channel groups (<= 16: 128 - 256 contiguous bytes per pixel):
-//   1. the input halo tile, the chunk's K*K weight rows and its bias go to LDS in ONE round trip (every thread has all its 16-byte
-//      loads in flight together; zeros outside the image);
-//   2. item = (output row, strip of TW outputs, channel group), group fastest across lanes: per kernel row NIN + K conflict-free
-//      16-byte LDS reads feed TW * K * 8 v_fma_mix_f32 -- the arithmetic of dw_kernel in the same order (bias first, taps in (ky, kx)
-//      order, fp32 accumulate, one rounding), so the outputs are bit-identical to it;
-//   3. pooled sums: every item parks its 8 sums in LDS (over the dead input tile), one thread per channel group adds them in a fixed
-//      order -> one partial row per TILE ([n][tiles][c], chunks write disjoint channels of the row).
-// ~100 registers, LDS 20 - 52 KB per workgroup -> 3 - 6 workgroups per CU. POOL as in dw_body (2 = SE FCs in the image's last workgroup).
-// MEASURED (round 3, batch 64) and left OFF (DN_DW_LDS=1 opts in; bit-identity with dw_kernel is tested either way): 120 channels at 40 x 40
-// 40 -> 36 us, but 72 channels 80 x 80 -> 40 x 40 stride 2 36.6 -> 53 us, 480 channels at 10 x 10 13.5 -> 22 us, 672 channels stride 2 18.8 -> 42 us;
-// step 1.025 -> 1.052 ms one at a time, 0.768 -> 0.798 ms in flight. tools/valu_dw.hip shows why the instruction mix is not the lever: the
-// row step costs 687 SIMD-cycles as 160 v_fma_mix_f32, 782 - 904 as conversions + fp32 FMAs, and only v_dot2_f32_f16 on tap pairs is cheaper
-// (405); at 8.4 us of multiply-add issue for the 40 x 40 layer both kernels are bound by their dependent phases (stage -> barrier -> compute ->
-// barrier -> reduce, all workgroups of a launch in step), not by VALU throughput.
-template <int K, int S, int OTH, int OTW, int TW, int POOL>
-__global__ __launch_bounds__(256) void dwl_kernel(DwArgs a, int tiles_x, int tiles, int cgw, int chunks, FastDiv fd_chunks) {
-    constexpr int IH = (OTH - 1) * S + K, IW = (OTW - 1) * S + K, NPIX = IH * IW;
-    constexpr int STRIPS = OTW / TW, NIN = (TW - 1) * S + K;
-    static_assert(OTW % TW == 0, "strips must tile the tile row");
-    extern __shared__ __attribute__((aligned(16))) unsigned char dwl_lds[];
-    int n, bx;
-    if (!xcd_image_of2(a.xq, a.n, n, bx)) return;
-    const int tile = (int)fd_div((unsigned)bx, fd_chunks), chunk = bx - tile * chunks;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int C8 = a.c >> 3;
-    const int g0 = chunk * cgw, gn = min(cgw, C8 - g0);         // this chunk's channel groups [g0, g0 + gn)
-    const int pitch = gn * 8;                                    // halfs per staged pixel
-    half_t* Xs = reinterpret_cast<half_t*>(dwl_lds);             // [NPIX][gn * 8]
-    half_t* Ws = Xs + NPIX * cgw * 8;                            // [K*K][gn * 8]
-    float* red = reinterpret_cast<float*>(dwl_lds);              // [items][8], over the dead input tile (phase 3)
-    const int tid = threadIdx.x;
-    const int oy0 = ty * OTH, ox0 = tx * OTW;
-    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
-    const FastDiv fd_gn = FastDiv{(unsigned)gn, gn > 1 ? (unsigned)((0x100000000ull + gn - 1) / gn) : 0u};
-    // ---- 1. stage
-    {
-        typedef const __attribute__((address_space(1))) half8* gp16;     // explicit global pointers: the selected pointer must not degrade to a flat load
-        const gp16 zero = (gp16)(&g_dw_zero16);
-        const half_t* xin = a.x + (size_t)n * a.h * a.w_ * a.c + g0 * 8;
-        const int total = NPIX * gn;
-        // every 16-byte piece of the tile is requested before the first one is parked in LDS: ONE memory round trip per workgroup
-        // (batches of four cost three dependent round trips on the 12 x 12 x 15-group tile)
-        constexpr int NLD = (NPIX * 16 + 255) / 256;             // pieces per thread at the widest chunk (cgw <= 16)
-        half8 v[NLD];
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int idx = min(tid + 256 * u, total - 1);
-            const int pix = (int)fd_div((unsigned)idx, fd_gn), g = idx - pix * gn;
-            const int py = pix / IW, px = pix - py * IW;
-            const int gy = iy0 + py, gx = ix0 + px;
-            const bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_;
-            v[u] = *(ok ? (gp16)(xin + ((size_t)gy * a.w_ + gx) * a.c + g * 8) : zero);
-        }
-#pragma unroll
-        for (int u = 0; u < NLD; ++u)
-            if (tid + 256 * u < total) *reinterpret_cast<half8*>(Xs + (size_t)(tid + 256 * u) * 8) = v[u];
-        for (int idx = tid; idx < K * K * gn; idx += 256) {
-            const int tap = (int)fd_div((unsigned)idx, fd_gn), g = idx - tap * gn;
-            *reinterpret_cast<uint4*>(Ws + (size_t)idx * 8) = *reinterpret_cast<const uint4*>(a.w + (size_t)tap * a.c + (g0 + g) * 8);
-        }
-    }
-    __syncthreads();
-    // ---- 2. items
-    const int nitems = OTH * STRIPS * gn;
-    float psum[2][8];                                            // (at most two items per thread: the launcher keeps nitems <= 512)
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) psum[r][e] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int item = tid + 256 * r;
-        if (item >= nitems) break;
-        const int rest = (int)fd_div((unsigned)item, fd_gn), g = item - rest * gn;
-        const int oy = rest / STRIPS, st = rest - oy * STRIPS;
-        float acc[TW][8];
-        {
-            // (the bias comes straight from global memory: its 480 bytes are what keeps the 15-group tile of the 40 x 40 layers from fitting four times per CU)
-            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + (g0 + g) * 8), b1 = *reinterpret_cast<const float4*>(a.bias + (g0 + g) * 8 + 4);
-#pragma unroll
-            for (int t = 0; t < TW; ++t) {
-                acc[t][0] = b0.x; acc[t][1] = b0.y; acc[t][2] = b0.z; acc[t][3] = b0.w;
-                acc[t][4] = b1.x; acc[t][5] = b1.y; acc[t][6] = b1.z; acc[t][7] = b1.w;
-            }
-        }
-        const half_t* xb = Xs + ((oy * S) * IW + st * TW * S) * pitch + g * 8;
-        const half_t* wb = Ws + g * 8;
-#pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
-            uint4 xv[NIN], wv[K];
-#pragma unroll
-            for (int i = 0; i < NIN; ++i) xv[i] = *reinterpret_cast<const uint4*>(xb + (ky * IW + i) * pitch);
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) wv[kx] = *reinterpret_cast<const uint4*>(wb + (ky * K + kx) * pitch);
-#pragma unroll
-            for (int t = 0; t < TW; ++t)
-#pragma unroll
-                for (int kx = 0; kx < K; ++kx) fma_mix_h8(acc[t], xv[t * S + kx], wv[kx]);
-        }
-        const int gy = oy0 + oy;
-        half_t* orow = a.out + (((size_t)n * a.ho + gy) * a.wo) * a.c + (g0 + g) * 8;
-#pragma unroll
-        for (int t = 0; t < TW; ++t) {
-            const int gx = ox0 + st * TW + t;
-            if (gy >= a.ho || gx >= a.wo) continue;
-            dn_act_n<float[8], 8>(acc[t], a.act);
-            half8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if constexpr (POOL != 0) psum[r][e] += acc[t][e];
-                o[e] = (half_t)acc[t][e];
-            }
-            *reinterpret_cast<half8*>(orow + (size_t)gx * a.c) = o;
-        }
-    }
-    if constexpr (POOL != 0) {
-        // ---- 3. pooled sums per tile, fixed order: items of one group sit gn apart
-        __syncthreads();                                         // every read of the input tile is done: its LDS becomes `red`
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int item = tid + 256 * r;
-            if (item < nitems) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) red[item * 8 + e] = psum[r][e];
-            }
-        }
-        __syncthreads();
-        if (tid < gn) {
-            float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int u = tid; u < nitems; u += gn)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t8[e] += red[u * 8 + e];
-            float* dst = a.pool + ((size_t)n * tiles + tile) * a.c + (g0 + tid) * 8;
-            if constexpr (POOL == 2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) __hip_atomic_store(&dst[e], t8[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // acknowledged before the ticket barrier (see dw_body)
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dst[e] = t8[e];
-            }
-        }
-        if constexpr (POOL == 2) {
-            __shared__ int s_last;
-            __syncthreads();
-            if (tid == 0)
-                s_last = __hip_atomic_fetch_add(&a.se_counter[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(tiles * chunks - 1);
-            __syncthreads();
-            if (s_last) {
-                if (dw_se_tail_is_small(a.c, a.se_sq, tiles)) dw_se_tail_small(a, n, tiles, reinterpret_cast<float*>(dwl_lds));
-                else dw_se_tail(a, n, tiles, reinterpret_cast<float*>(dwl_lds));
-                if (tid == 0) a.se_counter[n] = 0u;
-            }
-        }
-    }
-}
-
-// geometry of the LDS-tiled launch for one problem; false: not supported (the register-window kernel takes it)
-struct DwlGeom { int oth, otw, tw, tiles_x, tiles_y, cgw, chunks; size_t lds; };
-static bool dwl_geom(const DwArgs& a, DwlGeom& g) {
-    if (a.k != 5 || (a.stride != 1 && a.stride != 2) || a.c % 8 != 0 || a.pad != 2) return false;
-    g.oth = 8; g.otw = 8; g.tw = 4;
-    const int ih = (g.oth - 1) * a.stride + a.k, iw = (g.otw - 1) * a.stride + a.k, npix = ih * iw;
-    const int c8 = a.c / 8;
-    const int cap = std::min(16, (int)(52 * 1024 / ((size_t)npix * 16)));          // groups per chunk the input tile allows
-    if (cap < 4) return false;
-    int best = std::min(c8, cap), waste = dn_cdiv(c8, best) * best - c8;
-    for (int cg = std::min(c8, cap); cg >= std::max(4, cap / 2); --cg) {
-        const int w = dn_cdiv(c8, cg) * cg - c8;
-        if (w < waste) { waste = w; best = cg; }
-    }
-    g.cgw = best;
-    g.chunks = dn_cdiv(c8, best);
-    g.tiles_x = dn_cdiv(a.wo, g.otw); g.tiles_y = dn_cdiv(a.ho, g.oth);
-    const int items = g.oth * (g.otw / g.tw) * g.cgw;
-    if (items > 512) return false;
-    const size_t stage = ((size_t)npix * g.cgw * 8 + (size_t)a.k * a.k * g.cgw * 8) * sizeof(half_t);
-    const size_t tail = a.se_scale ? (size_t)(a.c + a.se_sq + 2048) * sizeof(float) : 0;
-    g.lds = std::max(std::max(stage, (size_t)items * 8 * sizeof(float)), tail);
-    return g.lds <= 96 * 1024 && fd_ok((unsigned long long)npix * g.cgw + 1024, (unsigned)g.cgw);
-}
-
-template <int S>
-static int launch_dwl(const DwArgs& a, const DwlGeom& g, hipStream_t s) {
-    const int tiles = g.tiles_x * g.tiles_y, per_image = tiles * g.chunks;
-    const dim3 grid = xcd_grid2(per_image, a.xq, a.n);
-    const FastDiv fdc = fastdiv((unsigned)g.chunks);
-    DN_REQUIRE(fd_ok((unsigned long long)per_image + 8, (unsigned)g.chunks), "depthwise (LDS tiles): %d workgroups per image outside the index range", per_image);
-    if (a.se_scale) DN_REQUIRE(a.pool && a.se_counter && depthwise_se_tail_supported(a.c, a.se_sq), "depthwise: squeeze-excitation tail needs the pooled output and c <= 1024, squeeze <= 256, both multiples of 8");
-    dn_note_kernel("dwl_kernel<5,%d,8,8,4>", S);
-#define DWL_LAUNCH(P)                                                                                                          \
-    do {                                                                                                                       \
-        if (g.lds > 48 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(dwl_kernel<5, S, 8, 8, 4, P>), 96 * 1024)); \
-        hipLaunchKernelGGL((dwl_kernel<5, S, 8, 8, 4, P>), grid, dim3(256), g.lds, s, a, g.tiles_x, tiles, g.cgw, g.chunks, fdc);   \
-    } while (0)
-    if (a.pool && a.se_scale) DWL_LAUNCH(2);
-    else if (a.pool) DWL_LAUNCH(1);
-    else DWL_LAUNCH(0);
-#undef DWL_LAUNCH
-    return DN_OK;
-}
-
 // Grouped launch: up to 12 independent depthwise problems of the same (k, stride) and batch in ONE launch (the head
 // depthwise convs of all pyramid levels, both heads). blockIdx.x is flat over the problems' per-image block counts (x 8 with the
 // XCD grouping: every problem's range starts at a multiple of 8), blockIdx.y is the image slot.
 struct DwGroup {
-    unsigned* zero_u32; int zero_count;      // optional: words this launch clears (the score histogram of the head launch behind it)
     int count;
     int start[13];
     int nblocks[12];        // workgroups per image
@@ -573,10 +340,6 @@ struct DwGroup {
 
 template <int K, int S, int TW, int MODE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 4) && K == 3 ? 4 : 1))) void dw_group_kernel(DwGroup g) {
-    if (g.zero_u32 && blockIdx.y == 0) {
-        const int i = blockIdx.x * 256 + threadIdx.x;
-        if (i < g.zero_count) g.zero_u32[i] = 0u;
-    }
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 12; ++i)
@@ -606,10 +369,9 @@ bool dw_fill(DwArgs& a) {
 }
 
 template <int K, int S, int TW>
-int launch_dw_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_u32, int zero_count) {
+int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
     DwGroup g{};
     g.count = count;
-    g.zero_u32 = zero_u32; g.zero_count = zero_count;
     int acc = 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
@@ -620,7 +382,6 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_
         acc += g.nblocks[i] * (arr[i].xq > 0 ? 8 : 1);
     }
     g.start[count] = acc;
-    DN_REQUIRE(!zero_u32 || (long)acc * 256 >= zero_count, "depthwise group: %d workgroups cannot clear %d words", acc, zero_count);
     dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
     if (dn_knob("DN_DW_PIPE3", 1)) hipLaunchKernelGGL((dw_group_kernel<K, S, TW, 4>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
     else hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
@@ -637,44 +398,21 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
     if (a.se_scale) DN_REQUIRE(a.pool && a.se_counter && depthwise_se_tail_supported(a.c, a.se_sq), "depthwise: squeeze-excitation tail needs the pooled output and c <= 1024, squeeze <= 256, both multiples of 8");
     const size_t pool_lds = a.se_scale ? (size_t)(a.c + a.se_sq + 2048) * 4 : (size_t)256 * 8 * 4;
     const dim3 grid = xcd_grid2(nblocks, a.xq, a.n);
-    // DN_DW_ROWS: bit mask of the launch classes that take the one-row form (1 = no pooling, 2 = pooled sums, 4 = pooled sums + SE tail),
-    // DN_DW_K restricts it to one kernel size. Default 0: the batched rows. The one-row form is 1.8 % faster on the step (70 - 116
-    // registers instead of 126 - 172), but with it a forward's result depends on what else runs on the chip: NOT adopted, kept behind
-    // the knob as the reproducer (tests/test_gpu_pipeline.py::test_stress... with DN_DW_ROWS=6 fails within a few hundred forwards;
-    // DESIGN section 4 lists what was ruled out in round 3).
-    const int cls = a.pool ? (a.se_scale ? 4 : 2) : 1;
-    const int kf = dn_knob("DN_DW_K", 0);
-    const bool rows1 = (dn_knob("DN_DW_ROWS", 0) & cls) != 0 && (kf == 0 || kf == K);
-    const bool pipe = !rows1 && (K == 5 ? (dn_knob("DN_DW_PIPE", 7) & cls) != 0 : (dn_knob("DN_DW_PIPE3", 7) & cls) != 0);      // software-pipelined rows, default on, stress-tested. 5x5 (DN_DW_PIPE): one exposed round trip instead of three, 29 -> 25.7 us per 40 x 40 launch. 3x3 (DN_DW_PIPE3): the batched form already takes its three rows in one round trip, but two row sets instead of three are 127 registers instead of 140 -- 4 waves per SIMD: the head group 36.4 -> 33.8 us
+    const int cls = a.pool ? (a.se_scale ? 4 : 2) : 1;      // launch class: 1 = no pooling, 2 = pooled sums, 4 = pooled sums + SE tail
+    // software-pipelined rows, default on, stress-tested. 5x5 (DN_DW_PIPE): one exposed round trip instead of three, 29 -> 25.7 us per 40 x 40 launch. 3x3 (DN_DW_PIPE3): the batched form already takes its three rows in one round trip, but two row sets instead of three are 127 registers instead of 140 -- 4 waves per SIMD: the head group 36.4 -> 33.8 us.
+    // (Round 2 - 3 also carried a ONE-row-at-a-time form, 70 - 116 registers: with it a forward's result depended on what else ran on the chip; cause not found in
+    //  two rounds of hunting (profiles/r03_dw_rows_hunt.txt), deleted in round 4 -- the poison test of tests/test_gpu_pipeline.py and the in-flight stress test guard what is left.)
+    const bool pipe = K == 5 ? (dn_knob("DN_DW_PIPE", 7) & cls) != 0 : (dn_knob("DN_DW_PIPE3", 7) & cls) != 0;
     const size_t lds = a.pool ? pool_lds : 0;
-    if (a.pool && g_dw_dbg_count > 0) {
-        for (int i = 0; i < g_dw_dbg_count; ++i)
-            if (g_dw_dbg_pool[i] == (const void*)a.pool) a.dbg = reinterpret_cast<float*>(g_dw_dbg_buf + (size_t)i * g_dw_dbg_stride);
-        if (a.se_scale) {
-            if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 3>), grid, dim3(256), lds, s, a, nblocks);
-            else hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 2>), grid, dim3(256), lds, s, a, nblocks);
-        } else {
-            if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 3>), grid, dim3(256), lds, s, a, nblocks);
-            else hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 2>), grid, dim3(256), lds, s, a, nblocks);
-        }
-        return DN_OK;
-    }
     if (pipe) {
         if (a.pool && a.se_scale) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 4>), grid, dim3(256), lds, s, a, nblocks);
         else if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 4>), grid, dim3(256), lds, s, a, nblocks);
         else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 4>), grid, dim3(256), lds, s, a, nblocks);
         return DN_OK;
     }
-    if (a.pool && a.se_scale) {
-        if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 1>), grid, dim3(256), lds, s, a, nblocks);
-        else hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 0>), grid, dim3(256), lds, s, a, nblocks);
-    } else if (a.pool) {
-        if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 1>), grid, dim3(256), lds, s, a, nblocks);
-        else hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 0>), grid, dim3(256), lds, s, a, nblocks);
-    } else {
-        if (rows1) hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 1>), grid, dim3(256), lds, s, a, nblocks);
-        else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 0>), grid, dim3(256), lds, s, a, nblocks);
-    }
+    if (a.pool && a.se_scale) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 0>), grid, dim3(256), lds, s, a, nblocks);
+    else if (a.pool) hipLaunchKernelGGL((dw_kernel<K, S, TW, 1, 0>), grid, dim3(256), lds, s, a, nblocks);
+    else hipLaunchKernelGGL((dw_kernel<K, S, TW, 0, 0>), grid, dim3(256), lds, s, a, nblocks);
     return DN_OK;
 }
 
@@ -1237,19 +975,9 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Which kernel a problem takes. A pooling launch must produce the row count the plan sized the partial-sum tensor for (DwArgs::pool_rows,
-// from depthwise_pool_blocks at plan time); without that hint (stand-alone calls) the knob decides: DN_DW_LDS=0 keeps the register-window kernel.
-static bool dwl_wanted(const DwArgs& a, DwlGeom& g) {
-    if (!dwl_geom(a, g)) return false;
-    if (a.pool && a.pool_rows > 0) return a.pool_rows == g.tiles_x * g.tiles_y;
-    return dn_knob("DN_DW_LDS", 0) != 0;
-}
-
 int launch_depthwise(const DwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.c % 8 == 0, "depthwise: c=%d must be a multiple of 8", a.c);
     DN_REQUIRE(!a.pool || a.c / 8 <= 256, "depthwise: pooled channel groups %d > 256", a.c / 8);
-    DwlGeom g;
-    if (dwl_wanted(a, g)) return a.stride == 1 ? launch_dwl<1>(a, g, s) : launch_dwl<2>(a, g, s);
     if (a.k == 3 && a.stride == 1) return launch_dw<3, 1, 4>(a, s);
     if (a.k == 3 && a.stride == 2) return launch_dw<3, 2, 2>(a, s);
     if (a.k == 5 && a.stride == 1) return launch_dw<5, 1, 4>(a, s);
@@ -1258,21 +986,19 @@ int launch_depthwise(const DwArgs& a, hipStream_t s) {
     return DN_E_UNSUPPORTED;
 }
 
-int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s, unsigned* zero_u32, int zero_count) {
+int launch_depthwise_group(const DwArgs* arr, int count, hipStream_t s) {
     DN_REQUIRE(count >= 1 && count <= 12, "depthwise group: %d problems", count);
     for (int i = 0; i < count; ++i) {
         DN_REQUIRE(arr[i].c % 8 == 0 && !arr[i].pool && arr[i].k == arr[0].k && arr[i].stride == arr[0].stride && arr[i].n == arr[0].n,
                    "depthwise group: problem %d is not compatible", i);
     }
-    if (arr[0].k == 3 && arr[0].stride == 1) return launch_dw_group<3, 1, 4>(arr, count, s, zero_u32, zero_count);
-    if (arr[0].k == 3 && arr[0].stride == 2) return launch_dw_group<3, 2, 2>(arr, count, s, zero_u32, zero_count);
-    if (arr[0].k == 5 && arr[0].stride == 1) return launch_dw_group<5, 1, 4>(arr, count, s, zero_u32, zero_count);
-    return launch_dw_group<5, 2, 2>(arr, count, s, zero_u32, zero_count);
+    if (arr[0].k == 3 && arr[0].stride == 1) return launch_dw_group<3, 1, 4>(arr, count, s);
+    if (arr[0].k == 3 && arr[0].stride == 2) return launch_dw_group<3, 2, 2>(arr, count, s);
+    if (arr[0].k == 5 && arr[0].stride == 1) return launch_dw_group<5, 1, 4>(arr, count, s);
+    return launch_dw_group<5, 2, 2>(arr, count, s);
 }
 
 int depthwise_pool_blocks(const DwArgs& a) {
-    DwlGeom g;
-    if (dwl_geom(a, g) && dn_knob("DN_DW_LDS", 0) != 0) return g.tiles_x * g.tiles_y;
     if (a.k == 3 && a.stride == 1) return dw_blocks<3, 1, 4>(a);
     if (a.k == 3 && a.stride == 2) return dw_blocks<3, 2, 2>(a);
     if (a.k == 5 && a.stride == 1) return dw_blocks<5, 1, 4>(a);

@@ -74,7 +74,6 @@ struct Layout {
     // (chain_n images), chain k adds k * arena. arena == 0: one contiguous [n]-image block per tensor.
     size_t arena = 0;
     int chain_n = 0;
-    size_t trunk_off = 0;       // [n][trunk_scratch_halfs] fp16
     size_t secnt_off = 0;       // [n_se_in_dw][n] unsigned: last-workgroup counters of the squeeze-excitation tails
 };
 
@@ -101,26 +100,13 @@ struct dn_plan {
     bool graph_mode = true;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t capture_stream = nullptr;   // capture never happens on the caller's stream (may be the null stream)
-    // head chains (dw -> 1x1 per level, class and box) are independent of the rest of the backbone: they run on two side
-    // streams forked at the event of their feature map and joined before the post-process (parallel graph branches)
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev_feat[8] = {}, ev_join[2] = {};
-    std::vector<int> op_stream;             // 0 main, 1 class-head chain, 2 box-head chain
+    std::vector<int> op_stream;             // 0 backbone, 1 class-head chain, 2 box-head chain (head ops and the depthwise ops feeding them)
     std::vector<int> op_wait_level;         // head-chain op reading a feature map: its level, else -1
-    std::vector<int> op_feat_level;         // main op producing a feature map: its level, else -1
-    bool multi_stream = false;
     int split = 2;                          // sub-batch branches per forward (see batch_split)
     bool ws_reuse = true;                   // DN_WS_REUSE=0: one private block per tensor (every intermediate stays readable after the forward)
     int chain_graphs = -1;                  // DN_CHAIN_GRAPHS: 1 = one single-chain graph per sub-batch on its own stream, 0 = branches of ONE graph, -1 = by batch size
     bool xcd = true;                        // XCD grouping of every kernel's workgroups by image (common.h; DN_XCD, read in dn_create)
     hipStream_t branch_stream[3] = {nullptr, nullptr, nullptr};
-    // early heads: the head launches of the first `head_early` pyramid levels leave the chain as soon as their feature map exists
-    // and run on a side stream of the chain (a parallel branch of the graph) while the backbone goes on; joined before the post-process
-    int head_early = 0;
-    int head_inline = 0;                    // DN_HEAD_STAGGER: the early levels' head launches stay ON the chain's stream, right after their feature map (1: odd chains only, 2: all)
-    int head_fork_op = -1;                  // op whose output is the last early level's feature map
-    hipStream_t head_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_head_fork[4] = {}, ev_head_join[4] = {};
     hipEvent_t ev_fork = nullptr, ev_branch[3] = {nullptr, nullptr, nullptr};
     std::map<std::pair<int, int>, Layout> sub_layouts;
     int chains_override = 0;                // dn_set_chains: > 0 = that many sub-batch chains per forward whatever the batch size
@@ -131,14 +117,10 @@ struct dn_plan {
     std::vector<int> head_dw, head_cls, head_reg;
     // run of tiny backbone layers [tail_first, tail_end) executed by one per-image workgroup (tail.hip); -1: none
     int tail_first = -1, tail_end = -1;
-    // run of inverted-residual blocks on the small maps executed by one per-image workgroup (trunk.hip): ops [trunk_first, trunk_end)
     std::vector<int> se_in_dw;              // per op: DW op -> index of the SE op whose FCs run in its tail (depthwise.hip dw_se_tail), SE op -> -2, else -1
     int n_se_in_dw = 0;                     // such pairs; slot q of the counter block belongs to the q-th
     std::vector<int> se_slot;               // per op (DW op of a pair): q
     std::vector<int> se_fold;               // per op: PW op -> index of the SE op whose FCs run in its prologue (pointwise.hip SEF), SE op -> -2, else -1
-    int trunk_first = -1, trunk_end = -1;
-    std::vector<int> trunk_block_op;        // first op of every block of the run
-    long trunk_scratch_halfs = 0;           // per image: parked depthwise outputs of the run's SE blocks
     std::vector<char> tail_materialise;     // per op of the run: its output is read outside the run (pyramid feature) -> also to HBM            // optional extra output of the merge kernel (dn_set_packed_output)
     // inverted-residual stages that run as one launch (expdw.hip): at the first op of a group, fused_len = number of ops and
     // fused_kind bit0 = has expand (1x1), bit1 = has project (1x1 [+ residual]); the depthwise op is always part of it
@@ -169,7 +151,6 @@ static void drop_graphs(dn_plan* p) {
 // two branches; more branches lose again, and below 32 images there is nothing to gain). Every workspace tensor is
 // image-major, so a sub-batch simply addresses rows [n0, n0 + ns) of the same layout.
 static int batch_split(const dn_plan* p, int n) {
-    if (p->multi_stream) return 1;
     if (p->chains_override > 0) return std::min(p->chains_override, n);
     if (p->split <= 1 || n < 32) return 1;
     return p->split;
@@ -220,7 +201,6 @@ static const Layout& get_layout(dn_plan* p, int n) {
                     break;
                 }
                 if (i == p->tail_first) len = p->tail_end - p->tail_first;
-                else if (i == p->trunk_first) len = p->trunk_end - p->trunk_first;
                 else if (p->fused_len[i] > 0) len = p->fused_len[i];
                 for (int q = 0; q < len; ++q) when[i + q] = tstep;
                 if (len > 1) {
@@ -255,13 +235,6 @@ static const Layout& get_layout(dn_plan* p, int n) {
             if (p->se_in_dw[i] >= 0) {      // the scale vector is written by the depthwise launch itself (dw_se_tail)
                 const int t = p->ops[p->se_in_dw[i]].out;
                 if (born[t] >= 0) born[t] = std::min(born[t], when[i]);
-            }
-        if (p->head_early > 0 && p->head_fork_op >= 0)
-            // early head launches run beside the backbone from the fork on: what they write must not alias anything alive there
-            for (int i = p->head_first; i < NO; ++i) {
-                const dn_op_desc& o = p->ops[i];
-                const int lv = o.head ? o.level : p->op_wait_level[i];
-                if (lv >= 0 && lv < p->head_early && born[o.out] >= 0) born[o.out] = std::min(born[o.out], when[p->head_fork_op]);
             }
         const int t_end = NO + 2;
         if (const int slack = dn_knob("DN_WS_SLACK", 0))        // diagnostics: every block stays reserved `slack` launches beyond its last reader
@@ -299,8 +272,6 @@ static const Layout& get_layout(dn_plan* p, int n) {
     off += align256((size_t)n * p->d.num_anchors * 4 * 4);
     L.scale_off = off;
     off += align256((size_t)n * 2 * 4);
-    L.trunk_off = off;
-    off += align256((size_t)n * p->trunk_scratch_halfs * 2);
     L.secnt_off = off;
     off += align256((size_t)n * p->n_se_in_dw * 4 + 4);
     L.post_off = off;
@@ -428,75 +399,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             }
         }
     }
-    // ---- trunk run: consecutive inverted-residual blocks [expand 1x1][depthwise][SE][project 1x1 (+residual)] on maps of at most
-    //      20 x 20 pixels whose input is the previous block's output (trunk.hip). The expanded map may be a pyramid feature.
-    //      MEASURED (tools/probe_trunk.py, profiles/r02_trunk_stamps.txt): correct (head outputs within 2.3e-2 of the launch-per-layer
-    //      path, bit-identical without SE), but 1.68 ms per image-workgroup against ~0.43 ms for the 31 launches it replaces at 32
-    //      images per chain: a whole image on ONE CU makes every phase a latency chain (21-26 us per 64-channel chunk, 50-110 us
-    //      per SE FC pair at 2 waves per SIMD) and leaves 3/4 of the chip idle. Kept as an opt-in experiment (DN_TRUNK=1).
-    if (dn_knob("DN_TRUNK", 0) != 0) {
-        std::vector<int> uses(desc->n_tensors, 0);
-        for (int i = 0; i < desc->n_ops; ++i) {
-            const dn_op_desc& o = p->ops[i];
-            uses[o.in]++;
-            if (o.residual >= 0) uses[o.residual]++;
-            if (o.se >= 0) uses[o.se]++;
-        }
-        auto is_level = [&](int t) { for (int l = 0; l < desc->n_levels; ++l) if (desc->level_tensor[l] == t) return true; return false; };
-        auto block_at = [&](int i, int* len) -> bool {
-            if (i + 2 >= desc->n_ops) return false;
-            const dn_op_desc& e = p->ops[i];
-            const dn_op_desc& d = p->ops[i + 1];
-            if (e.type != DN_OP_PW || e.head || e.se >= 0 || e.residual >= 0 || e.w2_off < 0 || p->tensors[e.in].kind != DN_T_ACT) return false;
-            if (d.type != DN_OP_DW || d.head || d.in != e.out || d.dil != 1) return false;
-            if (uses[e.out] != 1 + 0 && !(is_level(e.out) && uses[e.out] >= 1)) return false;      // read by the depthwise (and by head ops if a feature)
-            int j = i + 2, se_vec = -1, sq = 0;
-            if (p->ops[j].type == DN_OP_SE) {
-                if (d.pool < 0 || p->ops[j].in != d.pool) return false;
-                se_vec = p->ops[j].out; sq = p->ops[j].squeeze;
-                ++j;
-                if (j >= desc->n_ops) return false;
-            } else if (d.pool >= 0) return false;
-            const dn_op_desc& pj = p->ops[j];
-            if (pj.type != DN_OP_PW || pj.head || pj.in != d.out || pj.se != se_vec || pj.act != DN_ACT_NONE || pj.w2_off < 0 || uses[d.out] != 1) return false;
-            if (pj.residual >= 0 && (pj.residual != e.in || d.stride != 1 || pj.cout != e.cin)) return false;
-            const dn_tensor_desc& ti = p->tensors[e.in];
-            const dn_tensor_desc& to = p->tensors[pj.out];
-            if (ti.h != ti.w || to.h != to.w || is_level(d.out) || is_level(pj.out)) return false;
-            if (!trunk_block_supported(e.cin, e.cout, pj.cout, d.k, d.stride, ti.h, to.h, sq)) return false;
-            for (int q = i; q <= j; ++q) if (p->fused_len[q] > 0) return false;
-            for (int q = 1; q <= 2 && i - q >= 0; ++q) if (p->fused_len[i - q] > q) return false;
-            *len = j - i + 1;
-            return true;
-        };
-        int best_first = -1, best_end = -1;
-        for (int i = 0; i < desc->n_ops; ++i) {
-            int len = 0, first = i, end = i, blocks = 0;
-            std::vector<int> starts;
-            while (blocks < TRUNK_MAX_BLOCKS && block_at(end, &len) && (blocks == 0 || p->ops[end].in == p->ops[end - 1].out)) {
-                starts.push_back(end);
-                end += len;
-                ++blocks;
-            }
-            if (blocks >= 2 && end - first > best_end - best_first) {
-                best_first = first; best_end = end;
-                p->trunk_block_op = starts;
-            }
-            if (blocks > 0) i = end - 1;
-        }
-        if (best_first >= 0) {
-            p->trunk_first = best_first;
-            p->trunk_end = best_end;
-            long halfs = 0;
-            for (int b : p->trunk_block_op) {
-                if (p->ops[b + 2].type == DN_OP_SE) {
-                    const dn_tensor_desc& to = p->tensors[p->ops[b + 1].out];
-                    halfs += (long)to.h * to.w * to.c;
-                }
-            }
-            p->trunk_scratch_halfs = halfs;
-        }
-    }
     // ---- small squeeze-excitations (c <= 128, squeeze <= 32: the 40 x 40 blocks of MobileNetV3) are computed in the prologue of the
     //      projection that consumes them: one dependent launch (~10 us of pure latency) less per block
     p->se_fold.assign(desc->n_ops, -1);
@@ -504,7 +406,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         const dn_op_desc& so = p->ops[i];
         const dn_op_desc& pj = p->ops[i + 1];
         if (so.type != DN_OP_SE || pj.type != DN_OP_PW || pj.se != so.out || pj.head) continue;
-        if (p->trunk_first >= 0 && i >= p->trunk_first && i < p->trunk_end) continue;
         const dn_tensor_desc& ti = p->tensors[pj.in];
         int users = 0;
         for (int q = 0; q < desc->n_ops; ++q) users += p->ops[q].se == so.out;
@@ -518,7 +419,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     }
     // ---- the other squeeze-excitations (opt-in, DN_SE_IN_DW=1): their FCs run in the tail of the depthwise launch that pools for
     //      them (the last workgroup of an image to finish; depthwise.hip dw_se_tail) instead of a 32-workgroup launch of their own.
-    //      Needs the plain depthwise launch (not the fused expand+depthwise, tail or trunk runs) and the stem launch, which clears
+    //      Needs the plain depthwise launch (not the fused expand+depthwise or tail runs) and the stem launch, which clears
     //      the counters. MEASURED and left off. With a device-scope fence per workgroup the 20 x 20 depthwise launches went from
     //      10 to 50 us (a release at agent scope writes back the XCD's L2: batch 64 1.12 -> 1.32 ms). With the fence-free publish
     //      (device-scope atomic stores / loads of the partial sums, relaxed ticket) the launch overhead is gone, but the FCs of the
@@ -540,7 +441,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             if (j < 1 || !depthwise_se_tail_supported(so.cin, so.squeeze)) continue;
             bool plain = p->fused_len[j] == 0 && !(p->fused_len[j - 1] >= 2);
             if (j >= 2 && p->fused_len[j - 2] >= 3) plain = false;
-            if (p->trunk_first >= 0 && j >= p->trunk_first && j < p->trunk_end) plain = false;
             if (!plain) continue;
             p->se_in_dw[j] = i;
             p->se_in_dw[i] = -2;
@@ -568,7 +468,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     // stream assignment
     p->op_stream.assign(desc->n_ops, 0);
     p->op_wait_level.assign(desc->n_ops, -1);
-    p->op_feat_level.assign(desc->n_ops, -1);
     auto level_of = [&](int tensor) { for (int l = 0; l < desc->n_levels; ++l) if (desc->level_tensor[l] == tensor) return l; return -1; };
     for (int i = 0; i < desc->n_ops; ++i) {
         const dn_op_desc& o = p->ops[i];
@@ -580,7 +479,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     for (int i = 0; i < desc->n_ops; ++i) {
         const dn_op_desc& o = p->ops[i];
         if (p->op_stream[i]) p->op_wait_level[i] = level_of(o.in);
-        else p->op_feat_level[i] = level_of(o.out);
     }
     {
         const bool enabled = getenv("DN_HEAD_GROUPS") ? atoi(getenv("DN_HEAD_GROUPS")) != 0 : true;
@@ -639,38 +537,10 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         }
     }
     p->graph_mode = dn_knob("DN_GRAPH", 1) != 0;      // DN_GRAPH=0: plain launches (diagnostics)
-    p->multi_stream = getenv("DN_MULTI_STREAM") ? atoi(getenv("DN_MULTI_STREAM")) != 0 : false;
     p->xcd = getenv("DN_XCD") ? atoi(getenv("DN_XCD")) != 0 : true;
     p->chain_graphs = dn_knob("DN_CHAIN_GRAPHS", -1);      // -1: auto (forward_impl)
-    p->ws_reuse = dn_knob("DN_WS_REUSE", 1) != 0 && !p->multi_stream;      // (head chains on side streams overlap the backbone: no reuse)
+    p->ws_reuse = dn_knob("DN_WS_REUSE", 1) != 0;
     p->split = getenv("DN_SPLIT") ? atoi(getenv("DN_SPLIT")) : 2;
-    {
-        // early heads (DN_HEAD_EARLY = number of leading levels, default 0 = off): level 0 carries ~85 % of the head work of the SSDLite
-        // models and its feature map exists two thirds into the backbone; its two launches could overlap the rest of the chain
-        // instead of extending it. MEASURED and left off: a fork inside a chain's graph costs far more than the ~80 us of head
-        // launches it hides -- batch 64: 1.13 -> 1.44 ms (level 0), 1.33 ms (levels 0-1); batch 32: 0.78 -> 1.13 ms. (A fork inside
-        // a forked branch of one graph also crashes hipStreamEndCapture on ROCm 7.2, hence per-chain graphs in this mode.)
-        // DN_HEAD_STAGGER (default 0): the same early launches but ON the chain's own stream (no fork), for odd chains only (1) or all (2),
-        // so that the two chains do not run their head GEMMs at the same moment. MEASURED and left off: batch 64 1.060 -> 1.065 (1) /
-        // 1.078 ms (2), batch 32 0.739 -> 0.747 / 0.762 ms -- the early-born head buffers cost more workspace reuse than the staggering gains.
-        p->head_inline = dn_knob("DN_HEAD_STAGGER", 0);
-        const int want = dn_knob("DN_HEAD_EARLY", p->head_inline > 0 ? 1 : 0);
-        p->head_early = 0;
-        p->head_fork_op = -1;
-        if (want > 0 && want < desc->n_levels && p->head_first >= 0 && !p->multi_stream) {
-            int fo = -1;
-            bool ok = true;
-            for (int l = 0; l < want && ok; ++l) {
-                int prod = -1;
-                for (int i = 0; i < p->head_first; ++i) if (p->ops[i].out == desc->level_tensor[l]) prod = i;
-                ok = prod >= 0;
-                fo = std::max(fo, prod);
-            }
-            if (ok && p->tail_first >= 0 && fo >= p->tail_first) ok = false;        // produced inside the tail launch: nothing left to overlap
-            if (ok && fo + 1 >= p->head_first) ok = false;
-            if (ok) { p->head_early = want; p->head_fork_op = fo; }
-        }
-    }
     if (p->split < 1) p->split = 1;
     if (p->split > 4) p->split = 4;
     // anchor offsets per level
@@ -697,15 +567,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         if (p->anchors_dev) (void)hipFree(p->anchors_dev);
         return fail(DN_E_HIP);
     }
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking);
-    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_feat[i], hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming);
     for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->branch_stream[i], hipStreamNonBlocking);
     for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_branch[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&p->head_stream[i], hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_head_fork[i], hipEventDisableTiming);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ev_head_join[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         dn_set_error("dn_create: stream/event creation failed: %s", hipGetErrorString(e));
         return fail(DN_E_HIP);
@@ -721,15 +585,9 @@ extern "C" void dn_destroy(dn_plan* p) {
     (void)hipDeviceSynchronize();       // forwards of this plan may still be in flight on the caller's streams: the weights go away below
     drop_graphs(p);
     if (p->capture_stream) (void)hipStreamDestroy(p->capture_stream);
-    for (int i = 0; i < 2; ++i) if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
-    for (int i = 0; i < 8; ++i) if (p->ev_feat[i]) (void)hipEventDestroy(p->ev_feat[i]);
-    for (int i = 0; i < 2; ++i) if (p->ev_join[i]) (void)hipEventDestroy(p->ev_join[i]);
     for (int i = 0; i < 3; ++i) if (p->branch_stream[i]) (void)hipStreamDestroy(p->branch_stream[i]);
     for (int i = 0; i < 3; ++i) if (p->ev_branch[i]) (void)hipEventDestroy(p->ev_branch[i]);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-    for (int i = 0; i < 4; ++i) if (p->head_stream[i]) (void)hipStreamDestroy(p->head_stream[i]);
-    for (int i = 0; i < 4; ++i) if (p->ev_head_fork[i]) (void)hipEventDestroy(p->ev_head_fork[i]);
-    for (int i = 0; i < 4; ++i) if (p->ev_head_join[i]) (void)hipEventDestroy(p->ev_head_join[i]);
     for (auto ev : p->events) (void)hipEventDestroy(ev);
     if (p->weights_dev) (void)hipFree(p->weights_dev);
     if (p->anchors_dev) (void)hipFree(p->anchors_dev);
@@ -793,7 +651,6 @@ static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
     V.logits_off = L.logits_off + (size_t)n0 * p->d.num_anchors * p->d.num_classes * 4;
     V.reg_off = L.reg_off + (size_t)n0 * p->d.num_anchors * 16;
     V.scale_off = L.scale_off + (size_t)n0 * 8;
-    V.trunk_off = L.trunk_off + (size_t)n0 * p->trunk_scratch_halfs * 2;
     V.secnt_off = L.secnt_off + (size_t)n0 * p->n_se_in_dw * 4;
     const size_t slice = L.post_bytes / (size_t)S;
     V.post_off = L.post_off + (size_t)k * slice;
@@ -920,33 +777,6 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     };
     int ev = ev0;
     hipStream_t const main_stream = s;
-    // Softmax in the epilogue of the grouped class-head launch (DN_HEAD_SOFTMAX=1, opt-in; pointwise.hip): the 1x1 class heads write the
-    // class scores and their histogram straight into the post-process workspace -- the logits (n x A x K fp32: 75 MB per 64 images) are
-    // neither written nor read back. Only for whole forwards whose heads run as ONE grouped 1x1 launch behind the grouped depthwise
-    // launch (the SSDLite models); forward_heads keeps the unfused path, which is what the parity tests of the logits read.
-    // MEASURED (round 3, batch 64) and left OFF: bit-identical detections (tests/test_gpu_model.py::test_softmax_in_the_head_epilogue...),
-    // but the head launch goes from 92 to 161 us while the softmax launch it replaces costs 46 (the box decode that remains: 7): the
-    // softmax is ~2 600 vector instructions per thread of exp / divide / histogram work, and in the epilogue of a 51 KB-LDS GEMM
-    // workgroup (3 per CU) it runs at a third of the occupancy of the stand-alone kernel (6 per CU, 24 waves) with nothing to overlap it;
-    // 0.741 -> 0.760 ms in flight, 0.985 -> 0.990 one at a time. The 150 MB of logits traffic it saves were not what bounds the step.
-    bool fuse_sm = false;
-    float* sm_scores = nullptr; unsigned* sm_hist = nullptr;
-    int sm_hb0 = 0, sm_nb = 0;
-    if (!heads_only && p->head_first >= 0 && !p->head_dw.empty() && !p->head_cls.empty() && p->head_early == 0 && !p->multi_stream &&
-        dn_knob("DN_HEAD_SOFTMAX", 0) != 0 && dn_knob("DN_HEAD_MERGE", 1) != 0 && d.num_classes <= 96 && d.score_thresh >= 0.f) {
-        fuse_sm = true;
-        for (int q : p->head_cls) fuse_sm &= p->ops[q].type == DN_OP_PW && p->ops[q].act == DN_ACT_NONE && p->ops[q].cout == d.anchors_per_loc[p->ops[q].level] * d.num_classes;
-        for (int q : p->head_reg) fuse_sm &= p->ops[q].type == DN_OP_PW;
-        fuse_sm &= p->head_reg.size() + p->head_cls.size() <= 12;
-        if (fuse_sm) {
-            int clamped;
-            postprocess_fused_targets(ws + L.post_off, n, d.num_anchors, d.num_classes, d.topk_candidates, &sm_scores, &sm_hist);
-            post_hist_range(d.score_thresh, &sm_hb0, &sm_nb, &clamped);
-        }
-    }
-    const bool inl = p->head_inline == 2 || (p->head_inline == 1 && (chain & 1));
-    const bool branch = !record && p->head_early > 0 && p->head_fork_op >= 0 && chain >= 0 && chain < 4 && (p->head_inline == 0 || inl);
-    bool forked = false;
     // head launches of the pyramid levels [lv0, lv1): the depthwise group, then the 1x1 / dense group(s), on stream hs
     auto launch_heads = [&](int lv0, int lv1, hipStream_t hs, bool rec, size_t& seg) -> int {
         int rc = DN_OK;
@@ -962,7 +792,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         // SSDLite heads (depthwise 3x3 -> 1x1, class and box head per level): ONE launch with the depthwise computed inside the 1x1 GEMM's
         // operand staging (headfuse.hip) -- no depthwise output in HBM, no second launch. DN_HEAD_FUSE=0 keeps the two grouped launches
         // (the reference path of the bit-identity test).
-        if (!fuse_sm && dn_knob("DN_HEAD_FUSE", 1) != 0 && !h_dw.empty() && !h_cls.empty() && !h_reg.empty()) {
+        if (dn_knob("DN_HEAD_FUSE", 1) != 0 && !h_dw.empty() && !h_cls.empty() && !h_reg.empty()) {
             HeadFuseLevel fl[8];
             int nl = 0;
             std::vector<int> members;
@@ -1021,8 +851,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         if (!h_dw.empty()) {
             DwArgs arr[12];
             for (size_t q = 0; q < h_dw.size(); ++q) arr[q] = make_dw(p->ops[h_dw[q]]);
-            // softmax in the class heads' epilogue: the depthwise group in front of them clears the per-image score histogram
-            rc = launch_depthwise_group(arr, (int)h_dw.size(), hs, fuse_sm ? sm_hist : nullptr, fuse_sm ? n * DN_PP_HBINS : 0);
+            rc = launch_depthwise_group(arr, (int)h_dw.size(), hs);
             if (rc != DN_OK) return rc;
             for (int q : h_dw) hnote(q, seg);
             ++seg;
@@ -1052,12 +881,6 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             std::stable_sort(lst.begin(), lst.end(), [&](int x, int y) { return p->ops[x].cout > p->ops[y].cout; });
             for (size_t q = 0; q < lst.size(); ++q) {
                 PwArgs pa = conv ? conv_to_pw(make_conv(p->ops[lst[q]])) : make_pw(p->ops[lst[q]]);
-                if (fuse_sm && !conv && p->ops[lst[q]].head == 1) {
-                    const dn_op_desc& ho = p->ops[lst[q]];
-                    pa.sm_scores = sm_scores; pa.sm_hist = sm_hist;
-                    pa.sm_K = d.num_classes; pa.sm_A = d.num_anchors; pa.sm_off = p->level_off[ho.level]; pa.sm_aloc = d.anchors_per_loc[ho.level];
-                    pa.sm_thr = d.score_thresh; pa.sm_hb0 = sm_hb0; pa.sm_nb = sm_nb;
-                }
                 if (conv && taken.count(lst[q])) continue;          // rides in another head's launch
                 if (conv && conv_head_big_supported(pa)) {
                     // the wide dense heads of the large levels: MFMA-bound, each on the run-staged 256x256 tile. The box head of the
@@ -1083,30 +906,6 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                     ++seg;
                     if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
                     continue;
-                }
-                if (!conv) {
-                    // the 1x1 class head of a large level (SSDLite level 0: 672 -> 546 on 20 x 20, a quarter of the network's MACs): its own
-                    // launch on the 256 x 256 MFMA tile instead of the 128 x 128 tile of the grouped launch
-                    PwArgs pb = pa;
-                    const dn_tensor_desc& th = p->tensors[p->ops[lst[q]].in];
-                    pb.cv_k = 1; pb.cv_stride = 1; pb.cv_pad = 0; pb.cv_dil = 1; pb.cv_h = pb.cv_ho = th.h; pb.cv_w = pb.cv_wo = th.w; pb.cv_cin = pb.cin;
-                    pb.zeros = reinterpret_cast<const half_t*>(Wb + p->zeros_off);
-                    if (head_xs_supported(pa)) {
-                        rc = launch_head_xs(pa, hs);
-                        if (rc != DN_OK) return rc;
-                        hnote(lst[q], seg);
-                        ++seg;
-                        if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
-                        continue;
-                    }
-                    if (!pa.sm_scores && pw_head_big_supported(pb)) {
-                        rc = launch_pw_head_big(pb, hs);
-                        if (rc != DN_OK) return rc;
-                        hnote(lst[q], seg);
-                        ++seg;
-                        if (rec && seg < p->ops.size()) (void)hipEventRecord(p->events[ev++], hs);
-                        continue;
-                    }
                 }
                 arr[cnt++] = pa;
                 grouped.push_back(lst[q]);
@@ -1136,19 +935,15 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         }
         return DN_OK;
     };
-    const bool ms = p->multi_stream && !record;
-    bool side_used[2] = {false, false};
+    // DN_POISON=1 (correctness tooling): a launch that fills every LDS byte and vector register with NaN patterns in front of every launch of
+    // the forward -- results must not change (no kernel may read LDS or registers it has not written)
+    const bool poison = !record && dn_knob("DN_POISON", 0) != 0;
     for (size_t i = 0; i < p->ops.size(); ++i) {
+        if (poison) { int prc = launch_poison(main_stream); if (prc != DN_OK) return prc; }
         const dn_op_desc& o = p->ops[i];
         const dn_tensor_desc& ti = p->tensors[o.in];
         const dn_tensor_desc& to = p->tensors[o.out];
         s = main_stream;
-        if (ms && p->op_stream[i]) {
-            const int sid = p->op_stream[i] - 1;
-            s = p->side[sid];
-            side_used[sid] = true;
-            if (p->op_wait_level[i] >= 0) DN_HIP_CHECK(hipStreamWaitEvent(s, p->ev_feat[p->op_wait_level[i]], 0));
-        }
         if (record) (void)hipEventRecord(p->events[ev++], s);
         int rc = DN_OK;
         const unsigned char* W = p->weights_dev;
@@ -1157,78 +952,15 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             p->prof_kernel[op] = dn_last_kernel();
             p->prof_owner[op] = (int)owner;
         };
-        if (branch && !forked && (int)i > p->head_fork_op && (int)i < p->head_first) {
-            // the early levels' feature maps exist: their head launches leave the chain here
-            if (!inl) {
-                DN_HIP_CHECK(hipEventRecord(p->ev_head_fork[chain], main_stream));
-                DN_HIP_CHECK(hipStreamWaitEvent(p->head_stream[chain], p->ev_head_fork[chain], 0));
-            }
-            size_t seg_side = 0;
-            int hrc = launch_heads(0, p->head_early, inl ? main_stream : p->head_stream[chain], false, seg_side);
-            if (hrc != DN_OK) return hrc;
-            forked = true;
-        }
         if ((int)i == p->head_first) {
             // all remaining ops are head ops of the pyramid levels: three grouped launches instead of up to 28.
             // Profiling: the three launches take the event segments of ops i, i+1, i+2 (prof_owner maps members to them).
             size_t seg = i;
-            rc = launch_heads(forked ? p->head_early : 0, 1 << 20, s, record, seg);
+            rc = launch_heads(0, 1 << 20, s, record, seg);
             if (rc != DN_OK) return rc;
-            if (forked && !inl) {
-                DN_HIP_CHECK(hipEventRecord(p->ev_head_join[chain], p->head_stream[chain]));
-                DN_HIP_CHECK(hipStreamWaitEvent(main_stream, p->ev_head_join[chain], 0));
-            }
             for (size_t q = seg + 1; q < p->ops.size(); ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             break;
-        }
-        if ((int)i == p->trunk_first) {
-            TrunkArgs ta{};
-            ta.count = (int)p->trunk_block_op.size();
-            ta.xq = xq;
-            ta.weights = reinterpret_cast<const half_t*>(W);
-            const dn_op_desc& o0 = p->ops[i];
-            const dn_op_desc& ol = p->ops[p->trunk_end - 1];
-            ta.in0 = reinterpret_cast<const half_t*>(tptr(o0.in));
-            ta.in0_stride = (long)(L.tbytes[o0.in] / (size_t)L.n / 2);
-            ta.cin0 = o0.cin; ta.px0 = ti.h * ti.w;
-            ta.out = reinterpret_cast<half_t*>(tptr(ol.out));
-            ta.out_stride = (long)(L.tbytes[ol.out] / (size_t)L.n / 2);
-            ta.cout_last = ol.cout; ta.px_last = p->tensors[ol.out].h * p->tensors[ol.out].w;
-            ta.dscratch = reinterpret_cast<half_t*>(ws + L.trunk_off);
-            ta.dscratch_stride = p->trunk_scratch_halfs;
-            long dsc = 0;
-            for (int b = 0; b < ta.count; ++b) {
-                const int q = p->trunk_block_op[b];
-                const dn_op_desc& e = p->ops[q];
-                const dn_op_desc& dwo = p->ops[q + 1];
-                const bool has_se = p->ops[q + 2].type == DN_OP_SE;
-                const dn_op_desc& pj = p->ops[q + (has_se ? 3 : 2)];
-                TrunkBlock& t = ta.blk[b];
-                t.cin = e.cin; t.cexp = e.cout; t.cout = pj.cout; t.k = dwo.k; t.stride = dwo.stride; t.pad = dwo.pad;
-                t.act1 = e.act; t.act2 = dwo.act; t.hin = p->tensors[e.in].h; t.hout = p->tensors[pj.out].h;
-                t.has_se = has_se ? 1 : 0; t.sq = has_se ? p->ops[q + 2].squeeze : 0; t.has_res = pj.residual >= 0 ? 1 : 0;
-                t.w1f_off = (int)e.w2_off; t.b1_off = (int)e.b_off; t.wd_off = (int)dwo.w_off; t.bd_off = (int)dwo.b_off;
-                t.w3f_off = (int)pj.w2_off; t.b3_off = (int)pj.b_off;
-                if (has_se) {
-                    const dn_op_desc& so = p->ops[q + 2];
-                    t.se_w1t_off = (int)so.w_off; t.se_b1_off = (int)so.b_off; t.se_w2t_off = (int)so.w2_off; t.se_b2_off = (int)so.b2_off;
-                    t.dsc_off = (int)dsc;
-                    dsc += (long)t.hout * t.hout * t.cexp;
-                }
-                bool outside = false;       // the expanded map is read outside the run (pyramid feature): materialise it
-                for (int l = 0; l < d.n_levels; ++l) outside |= d.level_tensor[l] == e.out;
-                t.feat_out = outside ? reinterpret_cast<half_t*>(tptr(e.out)) : nullptr;
-                t.feat_stride = outside ? (long)(L.tbytes[e.out] / (size_t)L.n / 2) : 0;
-            }
-            rc = launch_trunk(ta, n, s);
-            if (rc != DN_OK) return rc;
-            const int cnt = p->trunk_end - p->trunk_first;
-            for (int q = 0; q < cnt; ++q) note(i + q, i);
-            for (int q = 1; q < cnt; ++q)
-                if (record) (void)hipEventRecord(p->events[ev++], s);
-            i += cnt - 1;
-            continue;
         }
         if ((int)i == p->tail_first) {
             TailArgs ta{};
@@ -1351,14 +1083,8 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         }
         if (rc != DN_OK) return rc;
         note(i, i);
-        if (ms && p->op_feat_level[i] >= 0) DN_HIP_CHECK(hipEventRecord(p->ev_feat[p->op_feat_level[i]], main_stream));
     }
     s = main_stream;
-    for (int k = 0; k < 2; ++k)
-        if (side_used[k]) {
-            DN_HIP_CHECK(hipEventRecord(p->ev_join[k], p->side[k]));
-            DN_HIP_CHECK(hipStreamWaitEvent(main_stream, p->ev_join[k], 0));
-        }
     if (!heads_only) {
         PostArgs a;
         a.logits = logits; a.reg = reg; a.anchors = p->anchors_dev;
@@ -1370,19 +1096,8 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.score_thresh = d.score_thresh; a.nms_thresh = d.nms_thresh; a.topk = d.topk_candidates; a.dets = d.detections_per_img;
         a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts; a.kept_anchor = nullptr;
         a.packed = packed;
-        a.fused = fuse_sm ? 1 : 0;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         a.xq = xq;
-        // with the softmax in the head epilogue the class-major scores are stored anchor-major within a level (common.h PostLevels);
-        // the stand-alone softmax launch keeps the canonical order (default level table: its writes stay coalesced)
-        a.lv.n = fuse_sm ? d.n_levels : 1;
-        for (int l = 0; fuse_sm && l < d.n_levels; ++l) {
-            const dn_tensor_desc& tl = p->tensors[d.level_tensor[l]];
-            a.lv.off[l] = p->level_off[l];
-            a.lv.hw[l] = tl.h * tl.w;
-            a.lv.aloc[l] = d.anchors_per_loc[l];
-        }
-        if (fuse_sm) a.lv.off[d.n_levels] = d.num_anchors;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
         if (rc) return rc;
@@ -1497,12 +1212,11 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     // another; on the real chain the two forms measure the same at two chains (1.25 vs 1.24 ms) and per-chain graphs lose
     // badly at three or four (1.9 ms): kept as an opt-in for that measurement only.
     const int S = batch_split(p, n);
-    // (early heads: a fork inside a forked branch crashes hipStreamEndCapture on ROCm 7.2 -- with them every chain is a graph of its own)
     // Measured (batch 32 = 2 x 16, 12 runs each): per-chain graphs 0.78 ms every time, one graph with two branches 0.785 ms in
     // two runs of three and 0.82 - 0.85 ms in the third (the placement of the branches differs from process to process); at batch
     // 64 one graph is 0.7 % faster (1.127 vs 1.135 ms). Default: per-chain graphs below 64 images.
     const bool want_chains = p->chain_graphs < 0 ? n < 64 : p->chain_graphs != 0;
-    const bool per_chain = S > 1 && (want_chains || (p->head_early > 0 && p->head_fork_op >= 0 && p->head_inline == 0));
+    const bool per_chain = S > 1 && want_chains;
     const int flags = (heads_only ? 1 : 0) | (p->input_u8 ? 2 : 0);
     auto capture = [&](const GraphKey& key, hipGraphExec_t* out) -> int {
         hipGraph_t g = nullptr;

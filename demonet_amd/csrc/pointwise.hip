@@ -50,9 +50,7 @@ __device__ __forceinline__ bool pw_tile_rows(const PwArgs& a, int flat, int tile
     return true;
 }
 
-// SM: softmax epilogue for the fp32 class-head problems that ask for it (PwArgs::sm_scores; grouped launch only). A template
-// parameter because its code costs the plain kernel two registers -- exactly the two that take it from 3 to 2 waves per SIMD.
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false, bool SM = false, bool FK = false>
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SEF = false, bool FK = false>
 __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, const int by) {
     static_assert(WP * WC == 4, "4 waves per workgroup");
     constexpr int LDS_ROW = BK + 8;     // halfs per LDS row: BK data + 8 pad -> odd number of 16-B slots (conflict-free b128)
@@ -77,8 +75,7 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
     const int wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC;
     const int r = lane & 31, hh = lane >> 5;
-    // (softmax epilogue: a channel tile starts at an anchor boundary and covers sm_apt whole anchors -- its last BC - sm_apt * K columns are the next tile's)
-    const int n0 = (SM && a.sm_scores) ? by * a.sm_apt * a.sm_K : by * BC;
+    const int n0 = by * BC;
     const int M = mend, K = a.cin, NC = a.cout;      // rows beyond the group's end belong to another workgroup
     const int dbg = a.act >> 8;            // probe-only knobs: 1 = skip stores, 2 = skip global loads of x
     a.act &= 0xff;
@@ -542,72 +539,6 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             }
         }
         __syncthreads();
-        if (SM && a.sm_scores) {
-            // ---- softmax over the classes of every (pixel, anchor) of the tile, scores and histogram written where the post-process reads
-            // them (generalized_ssd.py:354 F.softmax; postprocess.hip softmax_decode_kernel does the same arithmetic in the same order on the
-            // logits this tile would have written: four lanes per row, strided maximum and sum, (s0 + s1) + (s2 + s3), true division).
-            const int KC = a.sm_K, Km1 = KC - 1;
-            const int ja = min(a.sm_apt, a.sm_aloc - by * a.sm_apt);        // anchors of this tile
-            int* rimg = reinterpret_cast<int*>(ot + BP * FROW);               // [BP] image of the row (-1: beyond the problem)
-            int* rpix = rimg + BP;                                            // [BP] pixel within the image
-            unsigned* lhist = reinterpret_cast<unsigned*>(rpix + BP);         // [4][256] histogram of the tile's first four images
-            const int img_first = m0 / a.hw;
-            for (int row = tid; row < BP; row += 256) {
-                const int m = m0 + row, img = m / a.hw;
-                rimg[row] = m < M ? img : -1;
-                rpix[row] = m - img * a.hw;
-            }
-            for (int i = tid; i < 4 * 256; i += 256) lhist[i] = 0u;
-            __syncthreads();
-            {
-                const int sub = tid & 3;
-                for (int pr = tid >> 2; pr < BP * ja; pr += 64) {
-                    const int row = pr % BP, j = pr / BP;
-                    float* base = &ot[row * FROW + j * KC];
-                    const bool live = rimg[row] >= 0;
-                    float mx = -INFINITY;
-                    if (live)
-                        for (int k = sub; k < KC; k += 4) mx = fmaxf(mx, base[k]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 1));
-                    mx = fmaxf(mx, __shfl_xor(mx, 2));
-                    float sm = 0.f;
-                    if (live)
-                        for (int k = sub; k < KC; k += 4) {
-                            const float e = expf(base[k] - mx);
-                            base[k] = e;
-                            sm += e;
-                        }
-                    sm += __shfl_xor(sm, 1);
-                    sm += __shfl_xor(sm, 2);
-                    if (sub == 0 && live) base[0] = sm;                      // the background column carries the row sum from here on
-                }
-            }
-            __syncthreads();
-            const int total = Km1 * ja * BP;
-            for (int idx = tid; idx < total; idx += 256) {
-                const int row = idx % BP, t = idx / BP;
-                const int j = t % ja, k = 1 + t / ja;
-                const int img = rimg[row];
-                if (img < 0) continue;
-                const float* base = &ot[row * FROW + j * KC];
-                const float sc = base[k] / base[0];
-                const int ap = a.sm_off + (by * a.sm_apt + j) * a.hw + rpix[row];        // stored order: anchor-major within the level (PostLevels)
-                a.sm_scores[((size_t)img * Km1 + (k - 1)) * a.sm_A + ap] = sc;
-                if (sc > a.sm_thr) {
-                    const int bin = min(max((int)(__float_as_uint(sc) >> DN_PP_HSHIFT) - a.sm_hb0, 0), a.sm_nb - 1);
-                    const int slot = img - img_first;
-                    if (slot < 4) atomicAdd(&lhist[slot * 256 + bin], 1u);
-                    else atomicAdd(&a.sm_hist[(size_t)img * 256 + bin], 1u);          // (a tile of a small level spans more images)
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < 4 * 256; i += 256) {
-                const unsigned v = lhist[i];
-                if (v) atomicAdd(&a.sm_hist[(size_t)(img_first + (i >> 8)) * 256 + (i & 255)], v);
-            }
-            PW_STAMP(3);
-            return;
-        }
         float* outp = reinterpret_cast<float*>(a.out);
         const bool pair_ok = ((NC | (int)(a.out_base & 1) | (int)(a.out_img_stride & 1)) & 1) == 0 &&
                              (reinterpret_cast<size_t>(outp) & 7) == 0;       // every row start 8-byte aligned
@@ -734,7 +665,7 @@ template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bo
 __global__ __launch_bounds__(256) void pw_kernel(PwArgs a, int tiles) {
     int m0, mend, by;
     if (!pw_tile_rows<BP>(a, blockIdx.x, tiles, m0, mend, by)) return;
-    pw_body<BP, BC, WP, WC, CONV, BK, PF, SEF, false, FK>(a, m0, mend, by);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF, SEF, FK>(a, m0, mend, by);
 }
 
 // Grouped launch: up to 12 independent GEMMs (e.g. the class-head 1x1 convs of all pyramid levels) in ONE launch.
@@ -747,15 +678,15 @@ struct PwGroup {
     PwArgs a[12];
 };
 
-template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool SM = false, bool FK = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((SM || FK) && BP == 128 && BC == 96) ? 3 : 1))) void pw_group_kernel(PwGroup g) {
+template <int BP, int BC, int WP, int WC, bool CONV, int BK = 32, int PF = 1, bool FK = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FK && BP == 128 && BC == 96) ? 3 : 1))) void pw_group_kernel(PwGroup g) {
     int p = 0;
 #pragma unroll
     for (int i = 1; i < 12; ++i)
         if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
     int m0, mend, by;       // (start[] are multiples of 8 when the XCD grouping is on: local % 8 == blockIdx.x % 8)
     if (!pw_tile_rows<BP>(g.a[p], blockIdx.x - g.start[p], g.gx[p], m0, mend, by)) return;
-    pw_body<BP, BC, WP, WC, CONV, BK, PF, false, SM, FK>(g.a[p], m0, mend, by);
+    pw_body<BP, BC, WP, WC, CONV, BK, PF, false, FK>(g.a[p], m0, mend, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -996,224 +927,6 @@ int launch_cfg(const PwArgs& a, hipStream_t s) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// X-stationary 1x1 class head of a LARGE pyramid level (round 3): SSDLite level 0 is 672 -> 546 on 20 x 20 pixels, a quarter of the
-// network's multiply-adds, and the tiled kernel above spends ~1.4 us per 32-deep K stage on it (global -> LDS -> barrier -> 6 MFMAs per
-// wave, three workgroups per CU; each 128 x 96 tile re-reads its pixel rows for every one of the 6 channel tiles: 620 MB through L2
-// for a 34 MB input). Here a 512-thread workgroup owns `bp` consecutive pixels (bp divides h*w: the strip lies in one image and its
-// [bp][cout] fp32 output block is ONE contiguous run of the logits array):
-//   1. the strip's rows x[bp][K] go to LDS once (row stride K + 8 halfs = an odd number of 16-byte slots), every load in flight together;
-//   2. wave w = channel-tile pair w (64 output columns) x all row tiles: per 16-deep K step two A fragments come straight from L2 out of the
-//      fragment-major weight copy (1 KB contiguous per wave load, chunks of KC steps double-buffered in registers) and four B fragments
-//      from LDS feed eight MFMAs -- 64 B/clk of LDS reads and 32 B/clk of L1 per CU at full MFMA rate; a pair beyond the eighth is split
-//      by row tile over the waves so that every SIMD runs the same number of matrix instructions;
-//   3. the finished columns leave through LDS (over the dead strip) in two passes as row-contiguous 8-byte runs.
-// One accumulator per output, K walked in order, bias added in fp32 afterwards: the same arithmetic as pw_body, logits equal bit for bit
-// (test_head_xs_logits_bit_identical).
-// MEASURED (round 3, batch 64) and left OFF (DN_HEAD_XS=1 opts in): 45 us for the level-0 class head + 42 us for the rest of the grouped launch against
-// 88 - 90 us for the grouped launch with it: one forward at a time 0.938 -> 0.934 ms, in flight level (0.712 / 0.711). tools/probe_head_xs.py, per
-// workgroup: strip 5.5 us (34 MB at the HBM rate: it is the depthwise group's output), the split units 7.7 us (four dependent L2 round trips of ~2 us with
-// every CU walking the same weight rows), the pairs 11 us (two waves per SIMD x 4.5 us of matrix instructions), output 7.6 us (56 MB at the HBM rate) --
-// with 136 KB of LDS there is ONE workgroup per CU and nothing overlaps its four phases, where the tiled kernel overlaps three workgroups per CU. What it
-// would take: the phases of two half-size strips pipelined inside one workgroup (the output staging then has no room in LDS), or 128 registers per wave.
-template <int NR, int KC>
-__device__ __forceinline__ void head_xs_task(const PwArgs& a, const half_t* xs, int KP, int NCH, int rows, int nt0, int NT, int j0,
-                                             int lane, floatx16 (&acc)[2][NR]) {
-    const int r = lane & 31, hh = lane >> 5;
-    const int KS = NCH * KC;
-    const half_t* w0 = a.wfrag + (size_t)nt0 * KS * 512 + lane * 8;
-    const half_t* w1 = a.wfrag + (size_t)min(nt0 + 1, NT - 1) * KS * 512 + lane * 8;
-    const half_t* xr[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) xr[j] = xs + min((j0 + j) * 32 + r, rows - 1) * KP + hh * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    half8 wa[2][KC], wb[2][KC], wc[2][KC];
-    auto load_w = [&](half8 (&wf)[2][KC], int ch) {        // unconditional, clamped chunk index (a load behind a branch costs a full wait at the join)
-#pragma unroll
-        for (int u = 0; u < KC; ++u) {
-            wf[0][u] = *reinterpret_cast<const half8*>(w0 + (size_t)(ch * KC + u) * 512);
-            wf[1][u] = *reinterpret_cast<const half8*>(w1 + (size_t)(ch * KC + u) * 512);
-        }
-    };
-    auto compute = [&](const half8 (&wf)[2][KC], int ch) {
-#pragma unroll
-        for (int u = 0; u < KC; ++u) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const half8 xf = *reinterpret_cast<const half8*>(xr[j] + (ch * KC + u) * 16);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][u], xf, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][u], xf, acc[1][j], 0, 0, 0);
-            }
-        }
-    };
-    // three register sets: two chunks (2 * KC K steps) of weight requests are in flight behind the chunk being multiplied
-    load_w(wa, 0);
-    load_w(wb, min(1, NCH - 1));
-    for (int ch = 0; ch < NCH; ch += 3) {
-        load_w(wc, min(ch + 2, NCH - 1));
-        __builtin_amdgcn_sched_barrier(0);          // requests stay in front of the matrix instructions
-        compute(wa, ch);
-        load_w(wa, min(ch + 3, NCH - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        if (ch + 1 < NCH) compute(wb, ch + 1);
-        load_w(wb, min(ch + 4, NCH - 1));
-        __builtin_amdgcn_sched_barrier(0);
-        if (ch + 2 < NCH) compute(wc, ch + 2);
-    }
-}
-
-// one (channel tile, row tile) unit with the WHOLE reduction requested up front in two halves (few matrix instructions, pure latency otherwise):
-// the channel tiles beyond the eight pairs -- for 546 columns: tile 16 and the two columns of tile 17 -- one unit per wave
-template <int KH>
-__device__ __forceinline__ void head_xs_unit(const PwArgs& a, const half_t* xs, int KP, int KS, int rows, int nt, int j0, int lane, floatx16& acc) {
-    const int r = lane & 31, hh = lane >> 5;
-    const half_t* w0 = a.wfrag + (size_t)nt * KS * 512 + lane * 8;
-    const half_t* xr = xs + min(j0 * 32 + r, rows - 1) * KP + hh * 8;
-    half8 wa[KH], wb[KH];
-#pragma unroll
-    for (int u = 0; u < KH; ++u) wa[u] = *reinterpret_cast<const half8*>(w0 + (size_t)min(u, KS - 1) * 512);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int k0 = 0; k0 < KS; k0 += 2 * KH) {       // (uniform) chunks of KH steps, the next one requested before this one is multiplied
-#pragma unroll
-        for (int u = 0; u < KH; ++u) wb[u] = *reinterpret_cast<const half8*>(w0 + (size_t)min(k0 + KH + u, KS - 1) * 512);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < KH; ++u)
-            if (k0 + u < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[u], *reinterpret_cast<const half8*>(xr + (k0 + u) * 16), acc, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < KH; ++u) wa[u] = *reinterpret_cast<const half8*>(w0 + (size_t)min(k0 + 2 * KH + u, KS - 1) * 512);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < KH; ++u)
-            if (k0 + KH + u < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[u], *reinterpret_cast<const half8*>(xr + (k0 + KH + u) * 16), acc, 0, 0, 0);
-    }
-}
-
-template <int KC>
-__global__ __launch_bounds__(512) void head_xs_kernel(PwArgs a, int bp, int tiles) {
-    constexpr int RT = 4;                           // row tiles of 32 pixels (bp <= 128)
-    constexpr int KH = 11;                          // head_xs_unit: chunks of 11 K steps, two register sets
-    extern __shared__ __attribute__((aligned(16))) half_t xs[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int K = a.cin, NC = a.cout, KP = K + 8, KS = K >> 4, NCH = KS / KC;
-    int m0, mend;
-    if (a.xq > 0) {
-        const int g = blockIdx.x & 7, t = blockIdx.x >> 3;
-        const int r0 = g * a.xq * a.hw;
-        mend = min(a.m, r0 + a.xq * a.hw);
-        m0 = r0 + t * bp;
-    } else {
-        m0 = blockIdx.x * bp;
-        mend = a.m;
-    }
-    if (m0 >= mend) return;
-    const int rows = min(bp, mend - m0);
-    PW_STAMP(0);
-    // ---- 1. the strip: every 16-byte piece of it in flight at once (17 per thread for 100 x 672), one round trip
-    {
-        constexpr int NL = 17;
-        const int CPR = K >> 3, total = rows * CPR;
-        const half_t* xg = a.x + (size_t)m0 * K;
-        for (int c0 = 0; c0 < total; c0 += 512 * NL) {
-            uint4 v[NL];
-#pragma unroll
-            for (int u = 0; u < NL; ++u) v[u] = *reinterpret_cast<const uint4*>(xg + (size_t)min(c0 + u * 512 + tid, total - 1) * 8);
-#pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                const int c = c0 + u * 512 + tid;
-                if (c < total) {
-                    const int row = c / CPR, q = c - row * CPR;
-                    *reinterpret_cast<uint4*>(&xs[row * KP + q * 8]) = v[u];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    PW_STAMP(1);
-    const int NT = (NC + 31) >> 5;
-    const int img = m0 / a.hw;
-    float* obase = reinterpret_cast<float*>(a.out) + (size_t)a.out_base + (size_t)img * a.out_img_stride + (size_t)(m0 - img * a.hw) * NC;   // [rows][NC]
-    // ---- 2a. channel tiles beyond the eight pairs: one (tile, row tile) unit per wave, straight to memory (34 columns of 546)
-    for (int q = wave; q < (NT - 16) * RT; q += 8) {
-        const int nt = 16 + q / RT, j0 = q - (q / RT) * RT;
-        if (j0 * 32 >= rows) continue;
-        floatx16 acc1;
-        head_xs_unit<KH>(a, xs, KP, KS, rows, nt, j0, lane, acc1);
-        const int row = j0 * 32 + r;
-        if (row < rows) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = nt * 32 + 8 * g + 4 * hh;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c0 + e < NC) obase[(size_t)row * NC + c0 + e] = acc1[4 * g + e] + a.bias[c0 + e];
-            }
-        }
-    }
-    PW_STAMP(2);
-    // ---- 2b. this wave's pair, all row tiles
-    floatx16 acc[2][RT];
-    const bool mine = 2 * wave < min(NT, 16);
-    if (mine) head_xs_task<RT, KC>(a, xs, KP, NCH, rows, 2 * wave, NT, 0, lane, acc);
-    PW_STAMP(3);
-    // ---- 3. out through LDS (over the dead strip): pairs 0..4 (columns 0..319), then 5..7. The copy keeps a fixed column pair per thread and
-    //         walks the rows (no division per element), LDS reads of four rows ahead of their stores
-    float* ot = reinterpret_cast<float*>(xs);
-    for (int pass = 0; pass < 2; ++pass) {
-        const int p_lo = pass ? 5 : 0, p_hi = pass ? 8 : 5;
-        const int col0 = p_lo * 64, ncol = min(NC, p_hi * 64) - col0;
-        if (ncol <= 0) break;
-        const int OW = (p_hi - p_lo) * 64 + 4;
-        __syncthreads();                            // the strip (pass 0) / the first half (pass 1) is no longer read
-        if (mine && wave >= p_lo && wave < p_hi) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = (2 * wave + i) * 32 + 8 * g + 4 * hh;
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c0 + 3 < NC) bv = *reinterpret_cast<const float4*>(a.bias + c0);
-                    else {
-                        if (c0 < NC) bv.x = a.bias[c0];
-                        if (c0 + 1 < NC) bv.y = a.bias[c0 + 1];
-                        if (c0 + 2 < NC) bv.z = a.bias[c0 + 2];
-                    }
-#pragma unroll
-                    for (int j = 0; j < RT; ++j) {
-                        const int row = j * 32 + r;
-                        if (row < rows)
-                            *reinterpret_cast<float4*>(&ot[row * OW + (c0 - col0)]) =
-                                make_float4(acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
-                    }
-                }
-        }
-        __syncthreads();
-        const int c2 = ncol >> 1;                   // (cout and the pass boundaries are even: whole float2 runs, 8-byte aligned)
-        const int rpi = 512 / c2;                   // rows per iteration of the workgroup
-        const int rsub = tid / c2, q = tid - rsub * c2;
-        if (rsub < rpi) {
-            const float* src = ot + 2 * q;
-            float* dst = obase + col0 + 2 * q;
-            for (int row0 = rsub; row0 < rows; row0 += 4 * rpi) {
-                float2 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(src + min(row0 + u * rpi, rows - 1) * OW);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (row0 + u * rpi < rows) *reinterpret_cast<float2*>(dst + (size_t)(row0 + u * rpi) * NC) = v[u];
-            }
-        }
-        PW_STAMP(4 + pass);
-    }
-}
-
 }  // namespace
 
 // Tile choice: these GEMMs are latency/HBM-bound, not MFMA-bound, so what matters is (a) enough workgroups to fill
@@ -1301,23 +1014,14 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     g.count = count;
     int acc = 0;
     bool all_xq = true;         // XCD grouping needs every problem's first workgroup at a multiple of 8: all problems or none
-    bool any_sm = false;
     for (int i = 0; i < count; ++i) all_xq &= arr[i].xq > 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = arr[i];
         if (!all_xq) g.a[i].xq = 0;
-        g.a[i].stamps = dn_knob("DN_PW_GROUP_STAMPS", 1) ? g_pw_stamps : nullptr;        // dev hook (null unless tools/probe_head_stamps.py set it)
+        g.a[i].stamps = g_pw_stamps;        // dev hook (null unless a probe set it)
         g.start[i] = acc;
         g.gx[i] = pw_row_tiles(g.a[i], BP);
-        int ctiles = dn_cdiv(arr[i].cout, BC);
-        if (arr[i].sm_scores) {
-            // softmax epilogue: whole anchors per channel tile
-            DN_REQUIRE(!CONV && arr[i].out_fp32 && arr[i].sm_K >= 2 && arr[i].sm_K <= BC && arr[i].sm_aloc >= 1 && arr[i].cout == arr[i].sm_aloc * arr[i].sm_K &&
-                       arr[i].sm_hist && arr[i].act == DN_ACT_NONE, "pointwise group: problem %d cannot take the softmax epilogue (K=%d, tile %d)", i, arr[i].sm_K, BC);
-            g.a[i].sm_apt = BC / arr[i].sm_K;
-            ctiles = dn_cdiv(arr[i].sm_aloc, g.a[i].sm_apt);
-            any_sm = true;
-        }
+        const int ctiles = dn_cdiv(arr[i].cout, BC);
         acc += (g.a[i].xq > 0 ? 8 * g.gx[i] : g.gx[i]) * ctiles;
     }
     g.start[count] = acc;
@@ -1325,25 +1029,17 @@ int launch_group_cfg(const PwArgs* arr, int count, hipStream_t s) {
     bool any_fp32 = false;
     for (int i = 0; i < count; ++i) any_fp32 |= arr[i].out_fp32 != 0 || arr[i].residual != nullptr;
     size_t otile = any_fp32 ? (size_t)2 * BP * (BC + 4) : (size_t)BP * (BC + 8);
-    if (any_sm) otile += (size_t)2 * (2 * BP + 4 * 256);        // softmax epilogue: image / pixel of every tile row, a four-image histogram (ints behind the fp32 tile)
     if (otile > halfs) halfs = otile;
     const size_t lds = halfs * sizeof(half_t) + BC * sizeof(float);
     dn_note_kernel(GPF > 1 ? "pw_group_kernel<%d,%d,%d,%d,%s,%d,%d>" : "pw_group_kernel<%d,%d,%d,%d,%s,%d>", BP, BC, WP, WC, CONV ? "true" : "false", BK, GPF);
-    if constexpr (!CONV) {
-        if (any_sm) {
-            if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>)));
-            hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>), dim3(acc), dim3(256), lds, s, g);
-            return DN_OK;
-        }
-    }
     if constexpr (!CONV && GPF == 3) {
         // every problem on the bound-test-free K loop (whole 32-deep stages, no SE-scaled staging, 32-bit byte offsets): the instantiation that holds nothing else
         bool fk = dn_knob("DN_PW_FASTK", 1) != 0;
         for (int i = 0; i < count; ++i)
             fk &= arr[i].cin % BK == 0 && !arr[i].se && !(arr[i].act >> 8) && (size_t)arr[i].m * arr[i].cin < (1u << 30) && (size_t)arr[i].cout * arr[i].cin < (1u << 30);
         if (fk) {
-            if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, false, true>)));
-            hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, false, true>), dim3(acc), dim3(256), lds, s, g);
+            if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>)));
+            hipLaunchKernelGGL((pw_group_kernel<BP, BC, WP, WC, CONV, BK, GPF, true>), dim3(acc), dim3(256), lds, s, g);
             return DN_OK;
         }
     }
@@ -1364,13 +1060,6 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         if (arr[i].cout > maxc) maxc = arr[i].cout;
         wg128 += (long)dn_cdiv(arr[i].m, 128) * dn_cdiv(arr[i].cout, 128);
     }
-    const int gt = dn_knob("DN_PW_GROUP_TILE", 0);   // dev knob
-    if (!conv && maxc > 64 && gt == 4) return launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
-    if (!conv && maxc > 64 && gt == 5) return launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
-    if (!conv && maxc > 64 && gt == 6) return launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
-    if (!conv && maxc > 64 && gt == 7) return launch_group_cfg<128, 96, 4, 1, false>(arr, count, s);
-    if (!conv && maxc > 64 && gt == 8) return launch_group_cfg<64, 128, 2, 2, false, 64>(arr, count, s);
-    if (!conv && maxc > 64 && gt == 9) return launch_group_cfg<128, 128, 2, 2, false, 64>(arr, count, s);
     if (maxc <= 32 && conv && wg128 < 256 && dn_knob("DN_CONV_SMALL_PF", 1)) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
@@ -1466,32 +1155,4 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     return launch_select<true>(a, s);
 }
 
-// the X-stationary class-head kernel: fp32 head output with a fragment-major weight copy, a strip length that divides the map, K in whole
-// chunks, at most 9 channel-tile pairs (8 waves + one split pair) and enough strips to give every CU one
-static int head_xs_strip(const PwArgs& a) {
-    for (int bp : {100, 128, 96, 80, 64})
-        if (a.hw % bp == 0 && (size_t)bp * (a.cin + 8) * 2 <= 150 * 1024 && (size_t)bp * (5 * 64 + 4) * 4 <= (size_t)bp * (a.cin + 8) * 2) return bp;
-    return 0;
-}
-bool head_xs_supported(const PwArgs& a) {
-    if (!dn_knob("DN_HEAD_XS", 0)) return false;       // opt-in: measured level with the tiled kernel (below)
-    if (!a.out_fp32 || !a.wfrag || a.residual || a.se || a.act != DN_ACT_NONE || a.sm_scores) return false;
-    if (a.cin % 48 != 0 || a.cout % 2 != 0 || a.cout <= 256 || a.cout > 9 * 64) return false;
-    const int bp = head_xs_strip(a);
-    return bp > 0 && a.m / bp >= dn_knob("DN_HEAD_XS_MIN", 128);
-}
-static int g_head_xs_launches = 0;
-extern "C" __attribute__((visibility("default"))) int dn_debug_head_xs_launches() { return g_head_xs_launches; }      // tests: the path was taken
-int launch_head_xs(const PwArgs& a, hipStream_t s) {
-    ++g_head_xs_launches;
-    const int bp = head_xs_strip(a);
-    DN_REQUIRE(bp > 0, "head_xs: no strip length for %d pixels x %d channels", a.hw, a.cin);
-    const int tiles = a.xq > 0 ? a.xq * a.hw / bp : a.m / bp;
-    const size_t lds = (size_t)bp * (a.cin + 8) * sizeof(half_t);
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(head_xs_kernel<3>)));
-    dn_note_kernel("head_xs_kernel<3>");
-    const_cast<PwArgs&>(a).stamps = g_pw_stamps;
-    hipLaunchKernelGGL(head_xs_kernel<3>, dim3(a.xq > 0 ? 8 * tiles : tiles), dim3(512), lds, s, a, bp, tiles);
-    return DN_OK;
-}
 

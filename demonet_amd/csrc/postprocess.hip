@@ -946,14 +946,6 @@ size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
            align256((size_t)n * Km1 * 4) + align256((size_t)n * dn_cdiv(A, 64) * HBINS * 4 + (size_t)n * (8 + 4 * Km1));
 }
 
-void postprocess_fused_targets(void* ws, int n, int A, int K, int topk, float** scores, unsigned** hist) {
-    const size_t Km1 = K - 1;
-    unsigned char* p = reinterpret_cast<unsigned char*>(ws);
-    *scores = reinterpret_cast<float*>(p);
-    p += align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) + align256((size_t)n * Km1 * 4);
-    *hist = reinterpret_cast<unsigned*>(p);        // (the first n * 256 words of the per-tile histogram rows of the unfused path)
-}
-
 void post_hist_range(float score_thresh, int* hb0_out, int* nb_out, int* clamped_out) {
     // histogram bins that scores in (score_thresh, 1] can reach (float bits >> HSHIFT is monotone for positive floats)
     unsigned thr_bits, one_bits;
@@ -1022,13 +1014,8 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     post_hist_range(a.score_thresh, &hb0, &nb, &clamped);
     const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)HBINS * sizeof(unsigned);
     const int slots = xcd_image_slots(a.xq, a.n);
-    int hist_rows = tiles;          // per-image rows of the histogram table tau_kernel adds up
-    if (a.fused) {
-        // the class scores and the per-image histogram are there already (head launch epilogue): only the boxes are left to decode
-        const int btiles = dn_cdiv(a.A, 256);
-        hipLaunchKernelGGL(decode_boxes_kernel, dim3(btiles * slots), dim3(256), 0, s, a.reg, a.anchors, boxes, a.A, a.img_w, a.img_h, a.n, btiles, a.xq);
-        hist_rows = 1;
-    } else {
+    const int hist_rows = tiles;    // per-image rows of the histogram table tau_kernel adds up
+    {
         if (!(a.lv.n == 1 && a.lv.aloc[0] == 1))
             hipLaunchKernelGGL(softmax_decode_kernel<true>, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
                                scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,

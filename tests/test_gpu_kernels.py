@@ -192,29 +192,6 @@ def test_depthwise_conv(n, h, w, c, k, s, act):
     torch.testing.assert_close(got, ref.half().float(), rtol=4e-3, atol=4e-3)
 
 
-@pytest.mark.parametrize("n,h,w,c,k,s,act", [c for c in DW_CASES if c[4] == 5])
-def test_depthwise_lds_tiles_bit_identical_to_register_window(n, h, w, c, k, s, act, monkeypatch):
-    """dwl_kernel (LDS-staged input tile, round 3) runs the multiply-adds of dw_kernel in the same order (bias first, taps in (ky, kx)
-    order, fp32 accumulate, one rounding): the two kernels' outputs are equal bit for bit on the same inputs."""
-    L, lib = _lib()
-    g = torch.Generator().manual_seed(h * 17 + c)
-    x = torch.randn(n, h, w, c, generator=g).half().cuda()
-    wd = (torch.randn(k * k, c, generator=g) / k).half().cuda()
-    b = torch.randn(c, generator=g).cuda()
-    pad = (k - 1) // 2
-    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
-    outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DN_DW_LDS", flag)
-        out = torch.zeros(n, ho, wo, c, dtype=torch.half, device="cuda")
-        L.check(lib.dn_depthwise_conv(_ptr(x), _ptr(wd), _ptr(b), _ptr(out), n, h, w, c, k, s, pad, act,
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dn_depthwise_conv")
-        torch.cuda.synchronize()
-        outs.append(out)
-    assert torch.equal(outs[0], outs[1])
-    assert float(outs[0].float().abs().max()) > 0
-
-
 DENSE_CASES = [
     # n, h, w, cin, cout, k, s, pad, dil, act, zeros
     (2, 19, 19, 64, 256, 3, 1, 1, 1, 1, True),       # 256x256-tile kernel: M = 722 (3 tiles, ragged last), borders on every side

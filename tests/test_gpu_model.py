@@ -442,37 +442,6 @@ def test_xcd_grouping_is_placement_only(n):
     assert int(res["1"][5].sum()) > 0
 
 
-@pytest.mark.parametrize("name,kw,n", [
-    ("ssdlite320_mobilenet_v3_large", dict(num_classes=91), 3),
-    ("ssdlite320_mobilenet_v3_large", dict(num_classes=91), 37),
-    ("ssd_lite_mobilenet_v2", dict(num_classes=21, score_thresh=0.02), 2),
-    ("ssd_lite_mobilenet_v2", dict(num_classes=21, image_size=300, score_thresh=0.02), 9),
-])
-def test_trunk_kernel_matches_launch_per_layer_path(name, kw, n):
-    """The inverted-residual blocks of the 20 x 20 / 10 x 10 maps run as one launch per layer (default) or in one per-image launch
-    (trunk.hip, DN_TRUNK=1: a measured-and-parked experiment). Same rounding points (fp16 expanded map, fp16 depthwise output, fp16 SE-scaled operand, fp32
-    accumulation in the same K order); only the SE pooled sums are added in a different order -> the head outputs agree far inside
-    the fp16 tolerance of the path, and the pyramid feature that the run materialises (the C4 expansion) agrees likewise."""
-    size = kw.get("image_size", 320)
-    imgs = torch.from_numpy(synth.images(55, n, size, size)).cuda()
-    res = {}
-    for flag in ("0", "1"):
-        os.environ["DN_TRUNK"] = flag
-        try:
-            m = models.load_synthetic(getattr(models, name)(**kw), 0).cuda()
-            logits, reg = m.forward_heads(imgs)
-            f0 = m.tensor(imgs.shape, m.graph.features[0]).float() if n < 32 else None
-            res[flag] = (logits.clone(), reg.clone(), f0)
-        finally:
-            del os.environ["DN_TRUNK"]
-    d = (res["0"][0] - res["1"][0]).abs()
-    print(f"{name} n={n}: trunk vs per-layer logits max|d| {d.max().item():.4g} mean {d.mean().item():.3g}")
-    assert d.max().item() < 3e-2 and d.mean().item() < 2e-3
-    assert (res["0"][1] - res["1"][1]).abs().max().item() < 3e-2
-    if res["0"][2] is not None:
-        assert (res["0"][2] - res["1"][2]).abs().max().item() < 2e-2
-
-
 @pytest.mark.parametrize("n", [2, 19, 40])
 def test_se_fold_matches_separate_se_kernel(n):
     """The small squeeze-excitations (c <= 128, squeeze <= 32) run in the prologue of the projection that consumes them
@@ -531,33 +500,11 @@ def test_head_group_fast_k_loop_bit_identical(n, monkeypatch):
     whole model equal bit for bit with the general K loop."""
     imgs = torch.from_numpy(synth.images(29, n, 320, 320)).cuda()
     res = {}
+    monkeypatch.setenv("DN_HEAD_FUSE", "0")              # the grouped 1x1 head launch (since round 4 the fallback of the fused head launch)
     for flag in ("0", "1"):
         monkeypatch.setenv("DN_PW_FASTK", flag)
         m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
         res[flag] = [t.clone() for t in m.forward_heads(imgs)]
-    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
-
-
-@pytest.mark.parametrize("n", [64, 37])
-def test_head_xs_logits_bit_identical(n, monkeypatch):
-    """DN_HEAD_XS=1 (round 3; opt-in, measured level -- pointwise.hip head_xs_kernel): the 1x1 class head of pyramid level 0 runs X-stationary (the
-    pixel strip resident in LDS, the weights streamed from the fragment-major copy into MFMA fragments, output staged through LDS) instead of as
-    128 x 96 tiles of the grouped launch. One accumulator per output, K walked in the same order: logits and box regressions equal bit for bit
-    (n = 64: 256 strips; n = 37: two sub-batch chains, the plain and the XCD-grouped mapping)."""
-    import ctypes
-    from demonet_amd import _lib
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    imgs = torch.from_numpy(synth.images(23, n, 320, 320)).cuda()
-    res, launches = {}, {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DN_HEAD_XS", flag)
-        monkeypatch.setenv("DN_HEAD_XS_MIN", "64")
-        monkeypatch.setenv("DN_HEAD_FUSE", "0")          # (an alternative of the two-launch head path)
-        m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
-        before = raw.dn_debug_head_xs_launches()
-        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
-        launches[flag] = raw.dn_debug_head_xs_launches() - before
-    assert launches["0"] == 0 and launches["1"] >= 1, launches
     assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
 
 
@@ -589,51 +536,6 @@ def test_fused_head_launch_is_bit_identical(name, ncls, kw, n, monkeypatch):
     assert torch.isfinite(res["1"][0]).all() and torch.isfinite(res["1"][1]).all()
     assert torch.equal(res["0"][0], res["1"][0]), (res["0"][0] - res["1"][0]).abs().max().item()
     assert torch.equal(res["0"][1], res["1"][1]), (res["0"][1] - res["1"][1]).abs().max().item()
-
-
-@pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
-                                           ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 9)])
-def test_softmax_in_the_head_epilogue_is_bit_identical(name, ncls, kw, n, monkeypatch, pp_fast):
-    """DN_HEAD_SOFTMAX=1 (round 3; opt-in, measured slower -- plan.hip): the grouped 1x1 class-head launch computes the softmax of every (pixel, anchor) in its epilogue
-    and writes the class scores + their histogram straight into the post-process workspace (stored anchor-major within a level); the
-    logits never reach memory. Same arithmetic in the same order as softmax_decode_kernel on the logits the launch would have written:
-    detections (boxes, scores, labels, counts) equal bit for bit, with the cut-off path and with the full per-class path, for a batch
-    that runs as two sub-batch chains (37), and for K = 21 (four anchors per 96-column tile, 19 x 19 / 10 x 10 ... maps: tiles span images)."""
-    size = kw.get("image_size", 320)
-    imgs = torch.from_numpy(synth.images(91, n, size, size)).cuda()
-    res = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DN_HEAD_SOFTMAX", flag)
-        m = _model(name, num_classes=ncls, **kw)
-        res[flag] = [t.clone() for t in m.forward_batch(imgs)]
-        again = m.forward_batch(imgs)                       # graph replay
-        for a, b in zip(res[flag], again):
-            assert torch.equal(a, b)
-    for a, b in zip(res["0"], res["1"]):
-        assert torch.equal(a, b)
-    assert int(res["1"][3].sum()) > 0
-
-
-def test_class_head_on_the_256_tile_matches_grouped_launch():
-    """DN_PW_HEAD_BIG=1 (opt-in, measured slower -- convbig.hip): the 1x1 class head of level 0 (672 -> 546) leaves the grouped head
-    launch for the 256 x 256 MFMA tile with the fp32 epilogue; its reduction length 672 is not a multiple of the 64-deep stage (the
-    tail chunks come from the zero block). Same products, 64- instead of 32-deep partial sums: logits agree to fp32 rounding. 50
-    images = 20 000 rows of that head: 79 x 3 workgroups, the last pixel tile partial."""
-    imgs = torch.from_numpy(synth.images(77, 50, 320, 320)).cuda()
-    res = {}
-    for flag in ("0", "1"):
-        os.environ["DN_PW_HEAD_BIG"] = flag
-        os.environ["DN_SPLIT"] = "1"
-        try:
-            m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
-            res[flag] = [t.clone() for t in m.forward_heads(imgs)]
-        finally:
-            del os.environ["DN_PW_HEAD_BIG"]
-            del os.environ["DN_SPLIT"]
-    d = (res["0"][0] - res["1"][0]).abs().max().item()
-    print(f"class head on the 256 tile vs grouped launch: max|d| {d:.3g} (max|logit| {res['0'][0].abs().max().item():.3g})")
-    assert 0 < d < 2e-4 or d == 0
-    assert torch.equal(res["0"][1], res["1"][1])          # the box heads stay in the grouped launch
 
 
 @pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
@@ -963,3 +865,20 @@ def test_v2_at_300_matches_oracle():
     assert bool(((reg - raw["bbox_regression"]).abs() <= 8e-2 + 1.5e-2 * raw["bbox_regression"].abs()).all())
     boxes, scores, labels, counts = m.forward_batch(imgs)
     assert bool(torch.isfinite(scores).all()) and int(counts.max()) <= g.post["detections_per_img"]
+
+
+def test_hub_model_legacy_two_argument_call():
+    """The hub entry's call form (reference hubconf.py / box_head.py:323-381 PostProcess.forward): `model(x[N, 3, S, S], image_shapes)` with a stacked
+    4-d batch instead of a list of images; every result dict then lists its keys in the order of box_head.py:379 -- scores, labels, boxes.
+    Same detections as the list form on the same images."""
+    m = _model("ssd_lite_mobilenet_v2", num_classes=21)
+    W, H = m.graph.size
+    x = torch.from_numpy(synth.images(31, 3, H, W)).cuda()
+    legacy = m(x, [(H, W)] * 3)
+    listed = m(list(x.unbind(0)))
+    assert len(legacy) == 3
+    for a, b in zip(legacy, listed):
+        assert list(a.keys()) == ["scores", "labels", "boxes"] and list(b.keys()) == ["boxes", "scores", "labels"]
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(a[k], b[k])
+        assert a["boxes"].shape[0] > 0 and a["boxes"].shape[1] == 4

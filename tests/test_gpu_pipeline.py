@@ -252,3 +252,28 @@ def test_stress_forwards_in_flight_are_bit_identical_to_serial(se_small, monkeyp
             assert not bad, f"batch {n}, {depth} in flight, DN_SE_SMALL={se_small}: forwards {bad[:10]} of {count} differ from their serial forward"
             total += count
     assert total >= (500 if se_small == "1" else 100)
+
+
+@pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
+                                           ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 9), ("ssd300_vgg16", 21, {}, 2)])
+def test_results_do_not_depend_on_stale_lds_or_registers(name, ncls, kw, n, monkeypatch):
+    """DN_POISON=1 (round 4, correctness tooling -- dense.hip poison_kernel, plan.hip): a launch that leaves NaN patterns in every LDS byte and every
+    vector register (VGPR and AGPR) of the chip runs in front of every launch of the forward (plain launches, no graph). A kernel that reads LDS or a
+    register it has not written itself would now see different (NaN) bits than in an undisturbed run: the detections must be equal bit for bit.
+    (The round-2 / round-3 one-row depthwise form, whose results depended on what else ran on the chip, was deleted in round 4; this test and the
+    in-flight stress test guard the forms that are left.)"""
+    size = kw.get("image_size", None)
+    m0 = getattr(models, name)(num_classes=ncls, **kw)
+    W, H = m0.graph.size
+    imgs = torch.from_numpy(synth.images(13, n, H, W)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_POISON", flag)
+        monkeypatch.setenv("DN_GRAPH", "0")
+        m = models.load_synthetic(getattr(models, name)(num_classes=ncls, **kw), 0).cuda()
+        res[flag] = [t.clone() for t in m.forward_batch(imgs)]
+        heads = [t.clone() for t in m.forward_heads(imgs)]
+        res[flag] += heads
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)
+    assert int(res["1"][3].sum()) > 0 and torch.isfinite(res["1"][4]).all()
