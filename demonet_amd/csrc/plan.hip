@@ -1161,7 +1161,7 @@ static int enqueue_chain(dn_plan* p, const float* images, int n, int h, int w, f
 }
 
 static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, float* boxes, float* scores, int64_t* labels,
-                        int32_t* counts, void* workspace, size_t ws_bytes, void* stream, bool heads_only) {
+                        int32_t* counts, void* workspace, size_t ws_bytes, void* stream, bool heads_only, bool u8 = false) {
     DN_REQUIRE(p && images && workspace, "dn_forward: null argument");
     DN_REQUIRE(n > 0 && h > 0 && w > 0, "dn_forward: bad shape n=%d h=%d w=%d", n, h, w);
     struct Busy {
@@ -1170,6 +1170,8 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
         ~Busy() { if (ok) f.store(0); }
     } busy(p->in_call);
     DN_REQUIRE(busy.ok, "dn_forward: the plan is in use by another host thread (one plan serves one thread at a time; use one plan per thread)");
+    // per-call state of the plan: set and cleared INSIDE the guard (a second thread that the guard rejects must not have touched it)
+    struct U8 { dn_plan* p; U8(dn_plan* q, bool v) : p(q) { p->input_u8 = v; } ~U8() { p->input_u8 = false; } } u8_state(p, u8);
     DN_REQUIRE(heads_only || (boxes && scores && labels && counts), "dn_forward: null output buffer");
     const Layout& L = get_layout(p, n);
     if (ws_bytes < L.total) {
@@ -1281,11 +1283,8 @@ extern "C" int dn_forward(dn_plan* plan, const float* images_dev, int n, int h, 
 extern "C" int dn_forward_u8(dn_plan* plan, const uint8_t* images_dev, int n, int h, int w, float* boxes_dev, float* scores_dev,
                              int64_t* labels_dev, int32_t* counts_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
     DN_REQUIRE(plan, "dn_forward_u8: null plan");
-    plan->input_u8 = true;
-    const int rc = forward_impl(plan, reinterpret_cast<const float*>(images_dev), n, h, w, boxes_dev, scores_dev, labels_dev, counts_dev,
-                                workspace_dev, workspace_bytes, stream, false);
-    plan->input_u8 = false;
-    return rc;
+    return forward_impl(plan, reinterpret_cast<const float*>(images_dev), n, h, w, boxes_dev, scores_dev, labels_dev, counts_dev,
+                        workspace_dev, workspace_bytes, stream, false, true);
 }
 
 extern "C" int dn_forward_heads(dn_plan* plan, const float* images_dev, int n, int h, int w, void* workspace_dev,
@@ -1321,6 +1320,7 @@ extern "C" int dn_batch_split(const dn_plan* p, int n) {
 
 extern "C" int dn_set_packed_output(dn_plan* p, float* packed_dev) {
     DN_REQUIRE(p, "null plan");
+    DN_REQUIRE(p->in_call.load() == 0, "dn_set_packed_output: the plan is inside a forward of another host thread");
     p->packed_out = packed_dev;
     return DN_OK;
 }

@@ -101,9 +101,9 @@ class ForwardPipeline:
             raise RuntimeError("the pipeline is closed")
         if self.model._handle != self._handle or self.model._plan_gen != self._gen:
             raise RuntimeError("the model's plan was rebuilt (weights changed / invalidate()): build a new ForwardPipeline")
-        if self.n % 64 == 0 and (self.model._weights_signature(), str(self.device)) != self.model._sig:
-            # in-place weight updates do not rebuild the plan by themselves (only the model's own forward re-checks the signature):
-            # looked at every 64th submit (~0.1 ms), so a pipeline never replays stale folded weights for long
+        if not self.model._weights_unchanged(self.device) and (self.model._weights_signature(), str(self.device)) != self.model._sig:
+            # in-place weight updates do not rebuild the plan by themselves (only the model's own forward does): checked on EVERY submit
+            # (the flat-list test of SSD._weights_unchanged, tens of microseconds), so a pipeline never replays stale folded weights
             raise RuntimeError("the model's weights changed since the plan was lowered: close this pipeline and build a new one")
         s = self.slots[self.n % self.depth]
         if tuple(images.shape) != tuple(s.images.shape):
@@ -124,6 +124,7 @@ class ForwardPipeline:
             images.record_stream(s.stream)
         args = self._args(s, images.data_ptr() if direct else s.images.data_ptr())
         _lib.check(self._L.dn_set_packed_output(args[0], C.c_void_p(s.packed.data_ptr()) if s.packed is not None else None))
+        self.model._packed_set = -1                 # (the model's own forward re-sets it)
         with torch.cuda.device(self.device):
             _lib.check(self._fwd(*args), self._name)
         s.done.record(s.stream)
