@@ -391,9 +391,313 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
     XD_STAMP(4);
 }
 
+// ---- persistent single-chunk form (round 4) --------------------------------------------------------------------------------------
+// The blocks of the large maps whose expanded width is ONE chunk (16 -> 64 -> 24 at 160 x 160 stride 2, 24 -> 72 -> 24 at 80 x 80) are the
+// largest launches of the family: 6 400 / 3 200 workgroups that live 4.6 us each, two per CU -- 1.2 us of it the input region's memory
+// round trip, every workgroup re-requesting the same weights. Here 512 workgroups (two per CU, as many as are resident) WALK the tiles:
+//   * weights, biases and the depthwise weights' LDS copy are set up once per workgroup;
+//   * the input region of the NEXT tile is copied by LDS-DMA (per-lane source: a pixel outside the image reads a zero block, the bias
+//     column a block of ones -- the staging of expdw_kernel without its registers) as soon as the current tile's expand stage has read
+//     X (the residual pixels are taken into registers during that stage), and lands under the depthwise / project / store stages;
+//   * four barriers per tile instead of five plus a launch ramp.
+// Same arithmetic at the same rounding points as expdw_kernel<..., ONE>: outputs are bit-identical (test_expdw_persistent_bit_identical).
+__device__ const uint4 g_xd_const[2] = {{0u, 0u, 0u, 0u}, {0x3c003c00u, 0u, 0u, 0u}};      // what a chunk outside the image / the bias column of a pixel inside it reads
+
+template <int K, int S, int OH, int OW, int KSM, int XW8, bool WD>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void expdw_one_kernel(ExpDwArgs a, int tiles_x, int tiles_y, int wpg, int dty, int dtx) {
+    using G = ExpDwGeom<K, S, OH, OW>;
+    constexpr int IW = G::IW, NPIX = G::NPIX, RT = G::RT, ROWS = G::ROWS;
+    constexpr bool WIDE = WD;
+    constexpr int XW = XW8 * 8, XC8 = XW8;
+    static_assert(XW8 > 0 && KSM <= 2, "block shapes with a compile-time X row and at most two full K steps");
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    half_t* Xs = lds;                                       // [ROWS][XW] + 8 zero halfs
+    half_t* Es = Xs + ROWS * XW + 8;                        // [ROWS][EW]
+    half_t* Wd = Es + ROWS * EW;                            // [K*K][72]
+    float* Bd = reinterpret_cast<float*>(Wd + K * K * EW);  // [72]
+    half_t* Ds = reinterpret_cast<half_t*>(Bd + EW + NT / 64 * 64);   // [DROWS][EW]   (same offsets as expdw_kernel: one LDS size for both)
+    constexpr int DROWS = (OH * OW + 31) / 32 * 32;
+    float* B3s = reinterpret_cast<float*>(Ds + DROWS * EW); // [256]
+    half_t* Os = reinterpret_cast<half_t*>(B3s + 256);      // [OH * OW][cout]: the finished tile, stored to memory during the NEXT tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int cin = a.cin, cexp = a.cexp;
+    const int KSF = cin >> 4;
+    const int tiles = tiles_x * tiles_y;
+    // ---- this workgroup's tiles: XCD group g walks the tiles of its images, workgroup j of the group takes tiles j, j + wpg, ...
+    int grp = 0, j = blockIdx.x, img0 = 0, nimg = a.n;
+    if (a.xq > 0) { grp = blockIdx.x & 7; j = blockIdx.x >> 3; img0 = grp * a.xq; nimg = min(a.xq, a.n - img0); }
+    if (nimg <= 0) return;
+    int img = j / tiles, tl = j - img * tiles;
+    int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+    if (img >= nimg) return;
+
+    // ---- once per workgroup: weights (registers), depthwise weights / biases (LDS)
+    const int t = wave & 1;
+    half8 wf[KSM], wl, wf2[WIDE ? KSM : 1], wl2;
+    float b1v, b1v2 = 0.f;
+    const int kb = KSF * 16 + hh * 8;
+    const int kcl = min(kb, cin - 8);
+    {
+        const int ch = min(t * 32 + r, cexp - 1);
+        const half_t* wrow = a.w1 + (size_t)ch * cin;
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks)
+            if (ks < KSF) wf[ks] = *reinterpret_cast<const half8*>(wrow + ks * 16 + hh * 8);
+        wl = *reinterpret_cast<const half8*>(wrow + kcl);
+        b1v = a.b1[ch];
+        if constexpr (WIDE) {
+            const int ch2 = min(64 + r, cexp - 1);
+            const half_t* wrow2 = a.w1 + (size_t)ch2 * cin;
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks)
+                if (ks < KSF) wf2[ks] = *reinterpret_cast<const half8*>(wrow2 + ks * 16 + hh * 8);
+            wl2 = *reinterpret_cast<const half8*>(wrow2 + kcl);
+            b1v2 = a.b1[ch2];
+        }
+    }
+    auto last_frag = [&](const half8& w, float b) {
+        const half_t hi = (half_t)b;
+        const half_t lo = (half_t)(b - (float)hi);
+        const half8 bw = {hi, lo, 0, 0, 0, 0, 0, 0};
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        return kb < cin ? w : (kb == cin ? bw : zero8);
+    };
+    const half8 wlast = last_frag(wl, b1v);
+    half8 wlast2 = wlast;
+    if constexpr (WIDE) wlast2 = last_frag(wl2, b1v2);
+    const int cw = WIDE ? EW : 64, ng = cw >> 3;
+    {
+        const int wrow_i = tid / 9, wc8 = tid - wrow_i * 9;
+        const bool wok = tid < K * K * 9 && wc8 < ng && wc8 * 8 < cexp;
+        if (tid < K * K * 9) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.wd + (size_t)min(wrow_i, K * K - 1) * cexp + min(wc8 * 8, cexp - 8));
+            *reinterpret_cast<uint4*>(&Wd[wrow_i * EW + wc8 * 8]) = wok ? v : make_uint4(0, 0, 0, 0);
+        }
+        if (tid < EW) Bd[tid] = (tid < cw && tid < cexp) ? a.bd[min(tid, cexp - 1)] : 0.f;
+        if (tid < 256) B3s[tid] = tid < a.cout ? a.b3[tid] : 0.f;
+        if (tid == 0) *reinterpret_cast<uint4*>(&Xs[ROWS * XW]) = make_uint4(0, 0, 0, 0);
+        // channel groups beyond cexp are never written by the depthwise stage and must read as zero in the projection
+        if (cw > cexp)
+            for (int item = tid; item < DROWS * ng; item += NT)
+                if ((item % ng) * 8 >= cexp) *reinterpret_cast<uint4*>(&Ds[(item / ng) * EW + (item % ng) * 8]) = make_uint4(0, 0, 0, 0);
+    }
+    constexpr int PRT = DROWS / 32;
+    const int pct = (a.cout + 31) >> 5;
+    const int prt = wave % PRT, pc = wave / PRT;
+    const bool punit = pc < pct;
+    half8 w3f[WIDE ? 5 : 4];
+    {
+        const int co = min(pc * 32 + r, a.cout - 1);
+#pragma unroll
+        for (int ks = 0; ks < (WIDE ? 5 : 4); ++ks)
+            w3f[ks] = *reinterpret_cast<const half8*>(a.w3 + (size_t)co * cexp + min(ks * 16 + hh * 8, cexp - 8));
+    }
+
+    // ---- LDS-DMA of a tile's input region: chunk idx = (pixel of the halo region, 16-byte piece of its X row), two instructions per wave
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    constexpr int NCHK = ROWS * XC8;                       // 16-byte chunks of the region (a multiple of 32)
+    constexpr int DPW = (NCHK + NT - 1) / NT;               // DMA instructions per wave
+    int cpy[DPW], cpx[DPW], cq[DPW];
+#pragma unroll
+    for (int u = 0; u < DPW; ++u) {
+        const int idx = (wave * DPW + u) * 64 + lane;
+        const int pix = idx / XC8;
+        cq[u] = idx - pix * XC8;
+        cpy[u] = pix / IW; cpx[u] = pix - cpy[u] * IW;
+        if (idx >= NCHK || pix >= NPIX) cpy[u] = -100000;   // rows of the padding: always "outside"
+    }
+    const int c8 = cin >> 3;
+    auto stage_x = [&](int im, int ty_, int tx_) {
+        const half_t* xin = a.x + (size_t)(img0 + im) * a.H * a.W * cin;
+        const int iy0 = ty_ * OH * S - a.pad, ix0 = tx_ * OW * S - a.pad;
+#pragma unroll
+        for (int u = 0; u < DPW; ++u) {
+            if ((wave * DPW + u) * 64 >= NCHK) break;       // (uniform: the last wave's second instruction may be beyond the region)
+            const int gy = iy0 + cpy[u], gx = ix0 + cpx[u];
+            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const void* src = (inside && cq[u] < c8) ? (const void*)(xin + ((size_t)gy * a.W + gx) * cin + cq[u] * 8)
+                                                      : (const void*)&g_xd_const[(inside && cq[u] == c8) ? 1 : 0];
+            const unsigned dst = lds0 + (unsigned)((wave * DPW + u) * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    stage_x(img, ty, tx);
+
+    const int oc8 = a.cout >> 3;
+    // the finished tile of the PREVIOUS iteration leaves Os here (row-contiguous 16-byte chunks): issued in front of the next region's DMA, so
+    // that the wait for that DMA at the top of the loop has nothing younger behind it
+    int pn = -1, poy0 = 0, pox0 = 0;
+    auto store_prev = [&]() {
+        if (pn < 0) return;
+        for (int i = tid; i < OH * OW * oc8; i += NT) {
+            const int px = (int)fd_div((unsigned)i, a.fd_oc8), c8o = i - px * oc8;
+            const int py = px / OW, pxx = px - py * OW;
+            const int y = poy0 + py, x = pox0 + pxx;
+            if (y < a.Ho && x < a.Wo)
+                *reinterpret_cast<uint4*>(a.out + (((size_t)pn * a.Ho + y) * a.Wo + x) * a.cout + c8o * 8) =
+                    *reinterpret_cast<const uint4*>(Os + px * a.cout + c8o * 8);
+        }
+    };
+    while (true) {
+        const int n = img0 + img;
+        const int oy0 = ty * OH, ox0 = tx * OW;
+        // this tile's region has landed (every wave waits for its own DMA instructions; the only memory operations behind them in the queue
+        // would be the previous tile's stores, and those were issued in front of the DMA)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- expand on the matrix cores (expdw_kernel, stage 2)
+        for (int rt = wave >> 1; rt < RT && t * 32 < cexp; rt += NT / 128) {
+            floatx16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const half_t* xrow = &Xs[(rt * 32 + r) * XW + hh * 8];
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks)
+                if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
+            act_n<floatx16, 16>(acc, a.act1);
+            half_t* erow = &Es[(rt * 32 + r) * EW + t * 32 + 4 * hh];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[4 * g + e];
+                *reinterpret_cast<half4*>(erow + 8 * g) = hv;
+            }
+        }
+        if constexpr (WIDE) {
+            for (int rt = wave; rt < RT; rt += NT / 64) {
+                floatx16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                const half_t* xrow = &Xs[(rt * 32 + r) * XW + hh * 8];
+#pragma unroll
+                for (int ks = 0; ks < KSM; ++ks)
+                    if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf2[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast2, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
+                float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+                act_n<float[4], 4>(v4, a.act1);
+                half4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)v4[e];
+                *reinterpret_cast<half4*>(&Es[(rt * 32 + r) * EW + 64 + 4 * hh]) = hv;
+            }
+        }
+        // the residual pixels of this wave's output unit leave X now: the region is overwritten under the stages below
+        const int opix = prt * 32 + r;
+        const int poy = opix / OW, pox = opix - poy * OW;
+        half4 res[4];
+        if (a.has_res && punit) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = pc * 32 + 8 * g + 4 * hh;
+                res[g] = *reinterpret_cast<const half4*>(&Xs[((min(poy, OH - 1) * S + a.pad) * IW + pox * S + a.pad) * XW + min(c, a.cout - 4)]);
+            }
+        }
+        __syncthreads();
+        // ---- the previous tile's output, then the next tile's region
+        store_prev();
+        int nimg_i = img, nty = ty + dty, ntx = tx + dtx;
+        if (ntx >= tiles_x) { ntx -= tiles_x; ++nty; }
+        while (nty >= tiles_y) { nty -= tiles_y; ++nimg_i; }
+        const bool more = nimg_i < nimg;
+        if (more) stage_x(nimg_i, nty, ntx);
+        // ---- depthwise over the LDS tile (expdw_kernel, stage 3)
+        for (int item = tid; item < OH * OW * ng; item += NT) {
+            const int op = WIDE ? item / 9 : item >> 3;
+            const int cg = item - op * ng;
+            if (cg * 8 >= cexp) continue;
+            const int oy = op / OW, ox = op - oy * OW;
+            float acc[8];
+            {
+                const float4 b0 = *reinterpret_cast<const float4*>(&Bd[cg * 8]), b1 = *reinterpret_cast<const float4*>(&Bd[cg * 8 + 4]);
+                acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+            }
+            const half_t* ebase = Es + ((oy * S) * IW + ox * S) * EW + cg * 8;
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const uint4 ev = *reinterpret_cast<const uint4*>(ebase + (ky * IW + kx) * EW);
+                    const uint4 wv = *reinterpret_cast<const uint4*>(&Wd[(ky * K + kx) * EW + cg * 8]);
+                    fma_mix_h8(acc, ev, wv);
+                }
+            act_n<float[8], 8>(acc, a.act2);
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)acc[e];
+            *reinterpret_cast<half8*>(&Ds[op * EW + cg * 8]) = hv;
+        }
+        __syncthreads();            // (also: every thread's reads of Os for the previous tile's stores are complete)
+        // ---- project (expdw_kernel, PROJ); the tile goes to Os and leaves during the next iteration
+        floatx16 pacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pacc[e] = 0.f;
+        if (punit) {
+            const bool cok = pc * 32 + r < a.cout;
+            const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < (WIDE ? 5 : 4); ++ks) {
+                const bool ok = cok && ks * 16 + hh * 8 < cexp && ks * 16 + hh * 8 < cw;
+                const half8 w = ok ? w3f[ks] : zero8;
+                half8 df = *reinterpret_cast<const half8*>(&Ds[(prt * 32 + r) * EW + ks * 16 + hh * 8]);
+                if (ks == 4) df = hh ? zero8 : df;
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, df, pacc, 0, 0, 0);
+            }
+            if (opix < OH * OW) {
+                half_t* orow = Os + opix * a.cout;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = pc * 32 + 8 * g + 4 * hh;
+                    if (c < a.cout) {
+                        const float4 b = *reinterpret_cast<const float4*>(&B3s[c]);
+                        float v[4] = {pacc[4 * g + 0] + b.x, pacc[4 * g + 1] + b.y, pacc[4 * g + 2] + b.z, pacc[4 * g + 3] + b.w};
+                        if (a.has_res) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)res[g][e];
+                        }
+                        half4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)v[e];
+                        *reinterpret_cast<half4*>(orow + c) = hv;
+                    }
+                }
+            }
+        }
+        pn = n; poy0 = oy0; pox0 = ox0;
+        if (!more) break;
+        img = nimg_i; ty = nty; tx = ntx;
+    }
+    __syncthreads();
+    store_prev();
+}
+
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD>
 int launch_kw(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
     const dim3 grid(a.xq > 0 ? 8 * tiles_x : tiles_x, tiles_y * zsplit, a.xq > 0 ? a.xq : a.n);
+    if constexpr (PROJ && EXP && KSM <= 2 && XW8 > 0) {
+        // persistent single-chunk form: the workgroups that are resident (two per CU) walk the tiles. Needs the staged output tile inside the dead E
+        // buffer (no barrier between the project stage and its write) and a stride of whole tiles per step.
+        const size_t lds_p = lds + (size_t)OH * OW * a.cout * sizeof(half_t);        // + the tile's own output buffer
+        if ((WD ? a.cexp == EW : a.cexp <= 64) && !a.pool && !a.stamps && a.cout % 8 == 0 && a.cout <= 256 && lds_p <= 80 * 1024 &&
+            fd_ok((unsigned long long)OH * OW * (a.cout >> 3), (unsigned)(a.cout >> 3)) && dn_knob("DN_EXPDW_PERSIST", 1)) {
+            const int tiles = tiles_x * tiles_y;
+            const int groups = a.xq > 0 ? 8 : 1;
+            const long per_group = (long)(a.xq > 0 ? a.xq : a.n) * tiles;
+            const int wpg = (int)std::min<long>(per_group, 512 / groups);       // two resident workgroups per CU
+            DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_one_kernel<K, S, OH, OW, KSM, XW8, WD>)));
+            dn_note_kernel("expdw_one_kernel<%d,%d,%d,%d,%d>", K, S, OH, OW, KSM);
+            ExpDwArgs b = a;
+            b.fd_oc8 = fastdiv((unsigned)(a.cout >> 3));
+            hipLaunchKernelGGL((expdw_one_kernel<K, S, OH, OW, KSM, XW8, WD>), dim3(groups * wpg), dim3(NT), lds_p, s, b, tiles_x, tiles_y, wpg, wpg / tiles_x, wpg % tiles_x);
+            return DN_OK;
+        }
+    }
     if constexpr (PROJ && EXP && KSM <= 2) {
         if ((WD ? a.cexp == EW : a.cexp <= 64) && dn_knob("DN_EXPDW_ONE", 1)) {          // the whole expanded width is one chunk (72 channels: the wide variant)
             DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD, true>)));

@@ -304,6 +304,43 @@ def test_expand_depthwise(n, h, w, cin, cexp, cout, k, s, expand, project, pool,
         torch.testing.assert_close(pp.cpu().sum(1), pooled_ref, rtol=2e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cexp,cout,k,s,res,act", [
+    (12, 36, 44, 16, 64, 24, 3, 2, False, 1),       # b2-like, XCD-grouped (12 images: ragged last group), ragged tile edges
+    (3, 160, 160, 16, 64, 24, 3, 2, False, 1),      # the 160 x 160 block itself, plain mapping: 300 tiles on 300 workgroups ... and
+    (40, 160, 160, 16, 64, 24, 3, 2, False, 1),     # ... 4 000 tiles on 512: every workgroup walks 7 - 8 tiles
+    (19, 80, 80, 24, 72, 24, 3, 1, True, 1),        # b3-like: 72 channels taken whole, residual from the staged region, 50 tiles per image
+    (2, 40, 40, 24, 72, 24, 3, 1, True, 3),         # few tiles: fewer workgroups than resident slots, hardswish
+    (9, 38, 38, 32, 64, 32, 3, 1, True, 2),         # another X row width (cin 32), relu6
+])
+def test_expdw_persistent_bit_identical(n, h, w, cin, cexp, cout, k, s, res, act, monkeypatch):
+    """expdw_one_kernel (round 4, default for the single-chunk full blocks): 512 resident workgroups walk the tiles, the next tile's input
+    region copied by LDS-DMA under the current tile's depthwise / project stages, the finished tile stored during the next one. Same
+    arithmetic at the same rounding points as one workgroup per tile (expdw_kernel, DN_EXPDW_PERSIST=0): outputs equal bit for bit."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(h * 3 + cexp + n)
+    x = torch.randn(n, h, w, cin, generator=g).half().cuda()
+    w1 = (torch.randn(cexp, cin, generator=g) / cin ** 0.5).half().cuda()
+    b1 = (torch.randn(cexp, generator=g) * 0.1).cuda()
+    wd = (torch.randn(k * k, cexp, generator=g) / k).half().cuda()
+    bd = (torch.randn(cexp, generator=g) * 0.1).cuda()
+    w3 = (torch.randn(cout, cexp, generator=g) / cexp ** 0.5).half().cuda()
+    b3 = (torch.randn(cout, generator=g) * 0.1).cuda()
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_EXPDW_PERSIST", flag)
+        out = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.half, device="cuda")
+        for _ in range(2):          # (twice: the second run starts from a used LDS / L2 state)
+            L.check(lib.dn_expand_depthwise(_ptr(x), _ptr(w1), _ptr(b1), _ptr(wd), _ptr(bd), _ptr(w3), _ptr(b3), _ptr(out), None,
+                                            n, h, w, cin, cexp, cout, k, s, act, act, int(res),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dn_expand_depthwise")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_expand_depthwise_rejects_unsupported_shapes():
     L, lib = _lib()
     x = torch.zeros(4096, dtype=torch.half, device="cuda")
