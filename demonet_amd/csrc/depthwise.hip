@@ -146,7 +146,16 @@ __device__ __forceinline__ void dw_se_tail_small(const DwArgs& a, const int n, c
     fc(w1, act1, i0, i1, mean, ogp1, KS1, sq, b1v, z, false);
     fc(w2, act2, j0, j1, z, ogp2, KS2, c, b2v, a.se_scale + (size_t)n * c, true);
 }
-__device__ __forceinline__ bool dw_se_tail_is_small(int c, int sq, int nblk) { return c <= 128 && sq <= 32 && nblk <= 32; }
+// (dw_se_tail_small keeps TWO weight rows per thread and FC: the K slices of its thread map must be at most two rows long. c <= 128 and
+//  sq <= 32 imply that -- 256 / pow2(ceil(sq / 8)) >= 64 slices for fc1, >= 16 for fc2 -- and the condition is spelled out rather than implied.)
+__device__ __forceinline__ bool dw_se_tail_is_small(int c, int sq, int nblk) {
+    if (!(c <= 128 && sq <= 32 && nblk <= 32)) return false;
+    int ogp1 = 1, ogp2 = 1;
+    while (ogp1 < ((sq + 7) >> 3)) ogp1 <<= 1;
+    while (ogp2 < ((c + 7) >> 3)) ogp2 <<= 1;
+    const int ks1 = 256 / ogp1, ks2 = 256 / ogp2;
+    return (c + ks1 - 1) / ks1 <= 2 && (sq + ks2 - 1) / ks2 <= 2;
+}
 
 // POOL: 0 = none, 1 = per-workgroup channel sums for the squeeze-excitation, 2 = sums + the FCs in the image's last workgroup
 //   (dw_se_tail: its 16-row load batches need 114 registers, which capped EVERY pooling launch while the code was compiled into all of them).

@@ -680,7 +680,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8, bool WD>
 int launch_kw(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
     const dim3 grid(a.xq > 0 ? 8 * tiles_x : tiles_x, tiles_y * zsplit, a.xq > 0 ? a.xq : a.n);
-    if constexpr (PROJ && EXP && KSM <= 2 && XW8 > 0) {
+    // (instantiated for the block shapes that take it: 3x3 on the 8 x 8 stride-2 / 8 x 16 stride-1 tiles of the large maps, cin 16 / 24 / 32)
+    if constexpr (PROJ && EXP && KSM <= 2 && (XW8 == 3 || XW8 == 5) && K == 3 && OH == 8 && OW == (S == 1 ? 16 : 8)) {
         // persistent single-chunk form: the workgroups that are resident (two per CU) walk the tiles. Needs the staged output tile inside the dead E
         // buffer (no barrier between the project stage and its write) and a stride of whole tiles per step.
         const size_t lds_p = lds + (size_t)OH * OW * a.cout * sizeof(half_t);        // + the tile's own output buffer

@@ -1,0 +1,150 @@
+"""CPU-side checks of the compiled gfx950 code (no GPU: hipcc cross-compiles).
+
+1. Hand-scheduled loads. depthwise.hip (se_fc8_kernel, the squeeze-excitation FC launch) and headfuse.hip issue `global_load_*` from
+   `asm volatile` statements and wait for them with hand-written `s_waitcnt vmcnt(N)` statements. LLVM believes an asm statement's output
+   register is defined when the statement ends; the data arrives later. Nothing in the language stops the compiler from scheduling a copy,
+   a spill or a use of such a register between the load and the wait that covers it -- so this test reads the assembly hipcc produces and
+   checks, per kernel and in text order (conservative across branches): between an asm-issued VGPR load and the first hand-written wait that
+   retires it (loads return in order: `vmcnt(N)` retires all but the N youngest outstanding vector-memory operations) NO instruction reads or
+   writes its destination registers, and no compiler-issued vector-memory operation sits between them (it would shift the hand-made count).
+2. No scratch (register spills) in the kernels whose schedules depend on counted waits or that are meant to run at a fixed occupancy.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "demonet_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _asm(src, tmp_path, extra=()):
+    out = os.path.join(str(tmp_path), src.replace(".hip", ".s"))
+    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-gpu-rdc", "--cuda-device-only", "-S", *extra,
+           os.path.join(CSRC, src), "-o", out]
+    subprocess.check_call(cmd)
+    return open(out).read()
+
+
+def _kernels(text):
+    """name -> (body lines, metadata dict) for every kernel of a device .s file"""
+    res = {}
+    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+        res[m.group(1)] = m.group(2).split("\n")
+    meta = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+        meta[m.group(1)] = m.group(2)
+    return res, meta
+
+
+def _regs(tok):
+    """VGPR numbers named by one operand token: v12, v[12:15]"""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def _operands(line):
+    line = line.split(";")[0].strip()
+    if not line or line.endswith(":") or line.startswith("."):
+        return None, []
+    parts = line.split(None, 1)
+    ops = [t.strip() for t in re.split(r",\s*(?![^\[]*\])", parts[1])] if len(parts) > 1 else []
+    return parts[0], ops
+
+
+VMEM = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "scratch_", "flat_")
+
+
+def _lint_asm_loads(lines, name):
+    """text-order scan; returns the number of asm-issued loads checked"""
+    in_asm = False
+    pending = []            # outstanding asm-issued VGPR loads, oldest first: [line number, dest registers, crossed a label]
+    checked = 0
+    for ln, raw in enumerate(lines):
+        if "#ASMSTART" in raw:
+            in_asm = True
+            continue
+        if "#ASMEND" in raw:
+            in_asm = False
+            continue
+        op, ops = _operands(raw)
+        if op is None:
+            if raw.strip().endswith(":"):
+                for q in pending:       # (labels: the scan follows the TEXT order -- a load stays 'in flight' across branch targets until a hand-written wait retires it)
+                    q[2] = True
+            continue
+        touched = set()
+        for t in ops:
+            touched |= _regs(t)
+        if op in ("v_mad_u64_u32", "v_mad_i64_i32") and len(ops) == 5:
+            # hipcc uses the 64-bit multiply-add for 32-bit index arithmetic (only the low result half is used): the HIGH register of its addend
+            # pair is then an undefined input and may be any register -- including one with a load in flight, whose value cannot reach the low
+            # half. Seen in se_fc8_kernel<15,4> (v[70:71] with v71 = the bias load's destination). Not a use of the loaded value.
+            hi = _regs(ops[4])
+            if len(hi) == 2:
+                touched -= {max(hi)} - (_regs(ops[0]) | _regs(ops[2]) | _regs(ops[3]))
+        if in_asm and op.startswith(("global_load_dword", "buffer_load_dword")) and "lds" not in raw:
+            pending.append([ln, _regs(ops[0]), False])
+            checked += 1
+            continue
+        if in_asm and op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", raw)
+            if m:
+                keep = int(m.group(1))
+                pending = pending[len(pending) - keep:] if keep < len(pending) else pending
+            continue
+        if pending:
+            hot = set().union(*(q[1] for q in pending))
+            assert not (touched & hot), f"{name}: `{raw.strip()}` (line {ln}) touches v{sorted(touched & hot)} while its asm-issued load is in flight"
+            # a compiler-issued vector-memory operation inside a straight-line run of asm loads and their wait shifts the hand-made count
+            if not in_asm and op.startswith(VMEM) and not all(q[2] for q in pending):
+                raise AssertionError(f"{name}: compiler-issued `{op}` (line {ln}) between asm-issued loads and their hand-counted wait")
+    left = [q for q in pending if not q[2]]
+    assert not left, f"{name}: {len(left)} asm-issued loads never waited for"
+    return checked
+
+
+def test_hand_scheduled_loads_of_se_fc8_are_not_touched_before_their_wait(tmp_path):
+    text = _asm("depthwise.hip", tmp_path)
+    kernels, meta = _kernels(text)
+    se = {k: v for k, v in kernels.items() if "se_fc8_kernel" in k}
+    assert len(se) >= 2, list(kernels)[:5]
+    for name, lines in se.items():
+        n = _lint_asm_loads(lines, name)
+        assert n >= 20, (name, n)                  # partial rows + two FC weight batches + biases
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[name]), f"{name}: scratch in a kernel with hand-counted waits"
+    # the depthwise launches that carry the SE tail (POOL = 2) run their small-tail loads the same way
+    tails = {k: v for k, v in kernels.items() if "dw_kernel" in k}
+    for name, lines in tails.items():
+        _lint_asm_loads(lines, name)
+
+
+def test_fused_head_kernel_has_no_scratch_and_its_dma_is_counted(tmp_path):
+    """head_fused_kernel: every spill reload is a vector-memory operation that waits IN ORDER behind the A-fragment requests and shifts the
+    counted wait that publishes the LDS-DMA -- the kernel must compile without scratch at its 256-register budget, and every chunk iteration
+    must carry the counted wait in front of its barrier."""
+    text = _asm("headfuse.hip", tmp_path)
+    kernels, meta = _kernels(text)
+    hf = {k: v for k, v in kernels.items() if "head_fused_kernel" in k}
+    assert len(hf) == 5
+    for name, lines in hf.items():
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[name]), f"{name}: scratch"
+        body = "\n".join(lines)
+        assert "global_load_lds_dwordx4" in body
+        tcw = int(re.search(r"head_fused_kernelILi(\d)E", name).group(1))
+        assert re.search(rf"s_waitcnt vmcnt\({tcw}\)", body), f"{name}: the counted wait vmcnt({tcw}) is missing"
+        assert "scratch_" not in body
+
+
+def test_persistent_expdw_has_no_scratch(tmp_path):
+    text = _asm("expdw.hip", tmp_path)
+    kernels, meta = _kernels(text)
+    one = [k for k in kernels if "expdw_one_kernel" in k]
+    assert one
+    for name in one:
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[name]), f"{name}: scratch"
