@@ -43,7 +43,7 @@ def _family(name):
     return name if cut < 0 else name[:cut]
 
 
-POINTWISE_FAMILIES = ("pw_direct_kernel", "pw_kernel", "pw_xs_kernel", "pw_group_kernel")     # stand-alone 1x1 launches (north_star's ">= 90 % of roofline" path)
+POINTWISE_FAMILIES = ("pw_direct_kernel", "pw_stream_kernel", "pw_kernel", "pw_xs_kernel", "pw_group_kernel")     # stand-alone 1x1 launches (north_star's ">= 90 % of roofline" path; the fused head launch, whose GEMM is a 1x1 behind a depthwise, is reported as its own family)
 
 
 def op_costs(graph, n):

@@ -222,7 +222,11 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwArgs a, int tiles, int
 // workgroup walk the same weight tiles at the same time (three of the four reads hit L1). Per-tile arithmetic, bias-in-the-reduction and
 // the permlane epilogue are pw_direct_kernel's: the outputs are bit-identical to it. No squeeze-excitation scale, no residual (the
 // expansions have neither).
-template <int KSF>
+// PX (round 4): 32-pixel tiles per wave. The four waves of a workgroup walk the same weight tiles, and every wave pulls them through the CU's
+// L1 by itself: 13 M cache accesses (850 MB) for a 40 MB layer, and with the weight requests taken out the 112 -> 672 launch drops from 20.8 to
+// 15.3 us (tools/time_pw.py on an ablated build) -- the L1's 64 B per clock, not L2 or HBM, is what the stream costs. With two pixel tiles per
+// wave a weight fragment feeds two matrix instructions: half the L1 traffic per output.
+template <int KSF, int PX>
 __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, int tiles, int tiles_per_run) {
     constexpr int KSM = KSF > 0 ? KSF : 1;
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
@@ -237,20 +241,17 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, int tiles, int
             const int t = w - by * tiles;
             const int r0 = g * a.xq * a.hw;
             mend = min(a.m, r0 + a.xq * a.hw);
-            m0 = r0 + t * 128;
+            m0 = r0 + t * (128 * PX);
         } else {
             by = flat / tiles;
-            m0 = (flat - by * tiles) * 128;
+            m0 = (flat - by * tiles) * (128 * PX);
             mend = a.m;
         }
     }
-    const int mrow0 = m0 + wave * 32;
+    const int mrow0 = m0 + wave * (32 * PX);
     const int ctiles = (NC + 31) >> 5;
     const int ct0 = by * tiles_per_run, ct1 = min(ctiles, ct0 + tiles_per_run);
     if (mrow0 >= mend || ct0 >= ct1) return;               // wave-uniform
-    const int row = mrow0 + r;
-    const int rowc = min(row, mend - 1);
-    const half_t* xp = a.x + (size_t)rowc * K + hh * 8;
     const int kb = KSF * 16 + hh * 8;
     const int kcl = min(kb, K - 8) - hh * 8;
     const bool data = kb < K, bcol = kb == K;
@@ -265,16 +266,22 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, int tiles, int
         wl[buf] = *reinterpret_cast<const half8*>(wp + kcl);
         bl[buf] = a.bias[nrow];
     };
-    half8 xf[KSM];
+    half8 xf[PX][KSM], xl[PX];
+    int row[PX];
 #pragma unroll
-    for (int ks = 0; ks < KSF; ++ks) xf[ks] = *reinterpret_cast<const half8*>(xp + ks * 16);
-    half8 xl = *reinterpret_cast<const half8*>(xp + kcl);
+    for (int j = 0; j < PX; ++j) {
+        row[j] = mrow0 + 32 * j + r;
+        const half_t* xp = a.x + (size_t)min(row[j], mend - 1) * K + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSF; ++ks) xf[j][ks] = *reinterpret_cast<const half8*>(xp + ks * 16);
+        xl[j] = *reinterpret_cast<const half8*>(xp + kcl);
+    }
     request(ct0, 0);
     {
         const half8 ones = {(half_t)1.f, (half_t)1.f, 0, 0, 0, 0, 0, 0};
-        xl = data ? xl : (bcol ? ones : zero8);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) xl[j] = data ? xl[j] : (bcol ? ones : zero8);
     }
-    half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row * NC + hh * 8;
     auto tile = [&](const int ct, const int buf) {
         half8 wlast;
         {
@@ -283,30 +290,34 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, int tiles, int
             const half8 bw = {hi, lo, 0, 0, 0, 0, 0, 0};
             wlast = data ? wl[buf] : (bcol ? bw : zero8);
         }
-        floatx16 acc;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int j = 0; j < PX; ++j) {
+            floatx16 acc;
 #pragma unroll
-        for (int ks = 0; ks < KSF; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][ks], xf[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast, xl, acc, 0, 0, 0);
-        act16(acc, a.act);
-        uint2v p[4];
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            half4 hv;
+            for (int ks = 0; ks < KSF; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[buf][ks], xf[j][ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast, xl[j], acc, 0, 0, 0);
+            act16(acc, a.act);
+            uint2v p[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[4 * g + e];
-            p[g] = __builtin_bit_cast(uint2v, hv);
-        }
-        const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[1][0], false, false);
-        const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[1][1], false, false);
-        const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[2][0], p[3][0], false, false);
-        const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[2][1], p[3][1], false, false);
-        const uint4 lo4 = make_uint4(s0[0], s1[0], s0[1], s1[1]), hi4 = make_uint4(s2[0], s3[0], s2[1], s3[1]);
-        const int nt = ct * 32, c0 = nt + hh * 8;
-        if (row < mend) {
-            if (c0 < NC) *reinterpret_cast<uint4*>(orow + nt) = lo4;
-            if (c0 + 16 < NC) *reinterpret_cast<uint4*>(orow + nt + 16) = hi4;
+            for (int g = 0; g < 4; ++g) {
+                half4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[4 * g + e];
+                p[g] = __builtin_bit_cast(uint2v, hv);
+            }
+            const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[1][0], false, false);
+            const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[1][1], false, false);
+            const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[2][0], p[3][0], false, false);
+            const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[2][1], p[3][1], false, false);
+            const uint4 lo4 = make_uint4(s0[0], s1[0], s0[1], s1[1]), hi4 = make_uint4(s2[0], s3[0], s2[1], s3[1]);
+            const int nt = ct * 32, c0 = nt + hh * 8;
+            half_t* orow = reinterpret_cast<half_t*>(a.out) + (size_t)row[j] * NC + hh * 8;
+            if (row[j] < mend) {
+                if (c0 < NC) *reinterpret_cast<uint4*>(orow + nt) = lo4;
+                if (c0 + 16 < NC) *reinterpret_cast<uint4*>(orow + nt + 16) = hi4;
+            }
         }
     };
     // (the requests are UNCONDITIONAL, with a clamped tile index: behind a branch the compiler cannot count which loads are outstanding at
@@ -325,12 +336,12 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(PwArgs a, int tiles, int
     }
 }
 
-template <int KSF>
+template <int KSF, int PX>
 int launch_stream_t(const PwArgs& a, int runs, int tiles_per_run, hipStream_t s) {
-    const int tiles = a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, 128) : dn_cdiv(a.m, 128);
+    const int tiles = a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, 128 * PX) : dn_cdiv(a.m, 128 * PX);
     const dim3 grid((unsigned)(a.xq > 0 ? 8 * tiles : tiles) * runs);
-    dn_note_kernel("pw_stream_kernel<%d>", KSF);
-    hipLaunchKernelGGL((pw_stream_kernel<KSF>), grid, dim3(256), 0, s, a, tiles, tiles_per_run);
+    dn_note_kernel("pw_stream_kernel<%d,%d>", KSF, PX);
+    hipLaunchKernelGGL((pw_stream_kernel<KSF, PX>), grid, dim3(256), 0, s, a, tiles, tiles_per_run);
     return DN_OK;
 }
 
@@ -540,16 +551,22 @@ int launch_pw_direct(const PwArgs& a, hipStream_t s) {
     const int ksf = a.cin >> 4;
     // wide expansions with enough rows: the streaming variant (pw_stream_kernel) -- channel runs sized so that all waves are resident at once
     if (dn_knob("DN_PW_STREAM", 1) && !a.se && !a.residual && ksf >= 4 && ksf <= 8 && ctiles >= 12 && a.m >= dn_knob("DN_PW_STREAM_MINM", 12800)) {
-        const long ptiles = dn_cdiv(a.m, 32);
+        const int px = dn_knob("DN_PW_STREAM_PX", 2) == 2 ? 2 : 1;      // 32-pixel tiles per wave
+        const long ptiles = dn_cdiv(a.m, 32 * px);
         int runs = (int)std::max(1L, std::min((long)ctiles, (long)dn_knob("DN_PW_STREAM_WAVES", 2800) / ptiles));
         const int per = dn_cdiv(ctiles, runs);
         runs = dn_cdiv(ctiles, per);
-        switch (ksf) {
-            case 4: return launch_stream_t<4>(a, runs, per, s);
-            case 5: return launch_stream_t<5>(a, runs, per, s);
-            case 6: return launch_stream_t<6>(a, runs, per, s);
-            case 7: return launch_stream_t<7>(a, runs, per, s);
-            case 8: return launch_stream_t<8>(a, runs, per, s);
+        switch (ksf * 10 + px) {
+            case 41: return launch_stream_t<4, 1>(a, runs, per, s);
+            case 51: return launch_stream_t<5, 1>(a, runs, per, s);
+            case 61: return launch_stream_t<6, 1>(a, runs, per, s);
+            case 71: return launch_stream_t<7, 1>(a, runs, per, s);
+            case 81: return launch_stream_t<8, 1>(a, runs, per, s);
+            case 42: return launch_stream_t<4, 2>(a, runs, per, s);
+            case 52: return launch_stream_t<5, 2>(a, runs, per, s);
+            case 62: return launch_stream_t<6, 2>(a, runs, per, s);
+            case 72: return launch_stream_t<7, 2>(a, runs, per, s);
+            case 82: return launch_stream_t<8, 2>(a, runs, per, s);
         }
     }
     if (ksf <= 8 && a.cout >= dn_knob("DN_PW_DIRECT_TC2", 400)) {
