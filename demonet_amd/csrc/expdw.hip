@@ -707,15 +707,22 @@ int launch_kw(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t l
             return DN_OK;
         }
     }
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>)));
-    dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
-    hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
-    return DN_OK;
+    if constexpr (WD) {
+        return DN_E_UNSUPPORTED;        // (launch_k only picks the wide variant together with the single-chunk form)
+    } else {
+        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>)));
+        dn_note_kernel("expdw_kernel<%d,%d,%d,%d,%d,%s,%s>", K, S, OH, OW, KSM, EXP ? "true" : "false", PROJ ? "true" : "false");
+        hipLaunchKernelGGL((expdw_kernel<K, S, OH, OW, KSM, EXP, PROJ, XW8, WD>), grid, dim3(NT), lds, s, a, tiles_x, tiles_y, zsplit);
+        return DN_OK;
+    }
 }
 template <int K, int S, int OH, int OW, int KSM, bool EXP, bool PROJ, int XW8>
 int launch_k(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t lds, hipStream_t s) {
     if constexpr (PROJ && EXP && KSM <= 2) {
-        if (a.cexp % 64 == 8 && dn_knob("DN_EXPDW_WIDE", 1)) return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, true>(a, tiles_x, tiles_y, zsplit, lds, s);
+        // the wide variant (a last chunk of 72 channels taken whole) exists for the one shape that uses it: the whole expanded width IS that chunk
+        // (24 -> 72 -> 24). As a tail of a longer chunk run (cexp = 136, 200 ... with cin <= 40) it was never dispatched by the model zoo and every
+        // such instantiation spilled 36 - 76 B per lane at the 128-register cap: not instantiated any more.
+        if (a.cexp == EW && dn_knob("DN_EXPDW_WIDE", 1) && dn_knob("DN_EXPDW_ONE", 1)) return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, true>(a, tiles_x, tiles_y, zsplit, lds, s);
     }
     return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, false>(a, tiles_x, tiles_y, zsplit, lds, s);
 }
@@ -793,7 +800,7 @@ void expdw_tile(int Ho, int Wo, int stride, int* oh, int* ow, int proj_cout = 0)
     if (Wo <= 5 && Ho <= 5) { *oh = 5; *ow = 5; }
     else if (Wo <= 10) { *oh = 5; *ow = 10; }
     else if (Wo < 32 && Wo % 16 != 0) {                     // 19x19 / 20x20 maps: 10-wide tiles waste nothing
-        if (stride == 1) { *oh = 10; *ow = 10; } else { *oh = 5; *ow = 10; }
+        if (stride == 1) { *oh = 10; *ow = 10; } else { *oh = 5; *ow = 10; }       // (measured again in round 4 on the V2 model at 300 x 300: 5 x 10 tiles there are 2.4 % slower, although the 10 x 10 variants with cin >= 64 spill 36 - 44 B per lane)
         // with a project stage the (pixel tile x channel tile) units must fit the 8 waves: 100 pixels x 80 channels = 12 units, 50 x 80 = 6
         if (proj_cout > 0 && ((*oh * *ow + 31) / 32) * ((proj_cout + 31) / 32) > NT / 64) { *oh = 5; *ow = 10; }
     }
