@@ -40,7 +40,9 @@ def _family(name):
     The dominant family is the one with the largest share of the step's kernel time."""
     name = name.replace(" ", "")
     cut = name.find("<")
-    return name if cut < 0 else name[:cut]
+    fam = name if cut < 0 else name[:cut]
+    # expdw_one_kernel is the persistent form of expdw_kernel for the single-chunk blocks (round 4): the same stage of the network, one family
+    return "expdw_kernel" if fam == "expdw_one_kernel" else fam
 
 
 POINTWISE_FAMILIES = ("pw_direct_kernel", "pw_stream_kernel", "pw_kernel", "pw_xs_kernel", "pw_group_kernel")     # stand-alone 1x1 launches (north_star's ">= 90 % of roofline" path; the fused head launch, whose GEMM is a 1x1 behind a depthwise, is reported as its own family)
@@ -505,11 +507,16 @@ def main(argv=None):
         # fused inverted-residual launches: the intermediate activations never reach HBM -> external bytes only
         fused = {}
         for i, c in enumerate(costs):
-            if c["kernel"].startswith(("expdw_kernel", "pw_dw_direct_kernel")):
+            if c["kernel"].startswith(("expdw_kernel", "expdw_one_kernel", "pw_dw_direct_kernel", "head_fused_kernel")):
                 fused.setdefault(c["owner"], []).append(i)
         for mem in fused.values():
-            first, last = costs[mem[0]], costs[mem[-1]]
-            ext = first["b_in"] + last["b_out"] + sum(costs[i]["b_w"] for i in mem)
+            if costs[mem[0]]["kernel"].startswith("head_fused_kernel"):
+                # every level's two depthwise ops read the SAME feature map (once), their outputs never exist; the two 1x1 heads write the fp32 rows
+                ext = (sum(costs[i]["b_in"] for i in mem if g.nodes[i].op == "dw") / 2 + sum(costs[i]["b_out"] for i in mem if g.nodes[i].op == "pw") +
+                       sum(costs[i]["b_w"] for i in mem))
+            else:
+                first, last = costs[mem[0]], costs[mem[-1]]
+                ext = first["b_in"] + last["b_out"] + sum(costs[i]["b_w"] for i in mem)
             for i in mem:
                 costs[i]["bytes"] = ext / len(mem)
         owners = {}
