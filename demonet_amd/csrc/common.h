@@ -136,6 +136,7 @@ struct PwArgs {
     int cv_k = 1, cv_stride = 1, cv_pad = 0, cv_dil = 1, cv_h = 0, cv_w = 0, cv_ho = 0, cv_wo = 0, cv_cin = 0;
     FastDiv fd_cin32{1, 0}, fd_k{1, 0};     // conv_to_pw: (k0 / 32) / (cv_cin / 32) and tap / cv_k without a hardware division per K stage
     const half_t* zeros = nullptr;   // optional: >= 16 zero bytes on the device (dense convs)
+    int cv_plain_order = 0;          // dev knob DN_CONV_PLAIN_ORDER: conv_halo_kernel tiles in plain (x, y) order instead of XCD-grouped
     // optional second head on the same input (convbig.hip, head kernel): output channels [cout, cout + cout2) use these
     const half_t* w_b = nullptr; const float* bias_b = nullptr; void* out_b = nullptr;
     int cout_b = 0; long out_b_img_stride = 0, out_b_base = 0;

@@ -351,19 +351,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int A_BUF = A_ROWS * HK;      // halfs
     constexpr int B_HALF = BCt * HK;
     constexpr int B_STAGE = 2 * B_HALF;
-    constexpr int APW = (A_ROWS / 16 + 3) / 4;      // DMA pieces of a run per wave, APS per stage over a 4-stage window
-    constexpr int APS = (APW + 3) / 4;
+    constexpr int APW = (A_ROWS / 16 + 3) / 4;      // DMA pieces of a run per wave, APS per stage over a 3-stage window
+    constexpr int APS = (APW + 2) / 3;
+    constexpr int NM = TP * TC;             // MFMAs of a phase
     extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];
     float* bsh = reinterpret_cast<float*>(lds_raw);
     half_t* lds = lds_raw + 2 * BCt;
     half_t* Abuf = lds;                     // [2][A_BUF]
-    half_t* Bbuf = lds + 2 * A_BUF;         // [2][B_STAGE]
-    half_t* dummy = Bbuf + 2 * B_STAGE;     // 1 KB nobody reads: destination of the DMA slots a short run does not need
+    half_t* Bbuf = lds + 2 * A_BUF;         // [2][B_STAGE]; behind it 1 KB nobody reads: destination of the DMA slots a short run does not need
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave >> 1, wc = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * BPt, n0 = blockIdx.y * BCt;
+    // Tile of this workgroup. Workgroups are dispatched in linear order, workgroup b to XCD b % 8. An XCD walks a CONTIGUOUS range of
+    // pixel tiles, the channel tiles of one pixel tile next to each other: neighbouring pixel tiles share their halo rows (W + 1 rows
+    // on each side of 256: a third to a half of a run) and the channel tiles share the whole run in that XCD's L2. In the plain (x, y)
+    // order neighbouring pixel tiles sit on different XCDs and the second channel tile of a pixel tile runs a full round later: every
+    // XCD fetched its halos, and every channel tile its rows, from HBM again (PMC: 2.7 x the input bytes).
+    int bx, by;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, id = blockIdx.x + gx * blockIdx.y, G = gx & ~7;
+        if (a.cv_plain_order) {
+            bx = blockIdx.x;
+            by = blockIdx.y;
+        } else if (id < G * gy) {
+            const int k = id >> 3;
+            by = k % gy;
+            bx = (id & 7) * (G >> 3) + k / gy;
+        } else {
+            const int rem = id - G * gy, wd = gx - G;
+            bx = G + rem % wd;
+            by = rem / wd;
+        }
+    }
+    const int m0 = bx * BPt, n0 = by * BCt;
     const int M = a.m, K = a.cin, CIN = a.cv_cin;
     const int NC = HEAD ? a.cout + a.cout_b : a.cout;       // head kernel: the channels of a second head on the same input follow
     const int W = a.cv_w, pad = a.cv_pad, dil = a.cv_dil;
@@ -379,34 +401,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ---- loader geometry: a DMA piece = 16 rows of 64 B; lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 2) & 3)
+    // ---- loader. A DMA piece = 16 rows of 64 B; lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 2) & 3).
+    // The DMA goes out from inline asm, behind the compiler's back: as a builtin, hipcc drains EVERY outstanding piece (s_waitcnt vmcnt(0))
+    // in front of the stage barrier, and the youngest piece had been issued a few dozen cycles before it -- every stage waited one full L2
+    // round trip with the matrix pipe idle (one wave per SIMD: nothing else runs). Here the wait in front of a stage's barrier is COUNTED:
+    // it retires the weight pieces of the next stage (issued three and four phases earlier) and leaves the run pieces of this stage in
+    // flight until the next stage's wait. Addresses are raw-buffer offsets (one VGPR per lane, the tap / slice part in an SGPR): rows of
+    // the run outside the tensor are out of range, return 0 and need no clamp (the fragment masks zero them anyway).
     const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
-    const char* xbase = reinterpret_cast<const char*>(a.x);
-    const int arow0 = m0 - HALO + lrow;      // input pixel of run row lrow
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+    const unsigned dummy_dst = lds0 + (2 * A_BUF + 2 * B_STAGE) * 2;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(a.x)), 0,
+                                                                            (int)((unsigned)M * (unsigned)CIN * 2u), 0x00020000);
+    const unsigned xvo = ((unsigned)(m0 - HALO + wave * 16 + lrow) * (unsigned)CIN + (unsigned)lchunk * 8u) * 2u;     // piece 0 of this wave
+    const unsigned xstep = 128u * (unsigned)CIN;                                                                     // 64 rows on
     // weight rows beyond the last channel (last channel tile of a head): the last row again, its outputs are never stored
-    const char* wbase = reinterpret_cast<const char*>(a.w);
-    const long wdelta = HEAD && a.w_b ? reinterpret_cast<const char*>(a.w_b) - wbase : 0;
-    long wro[TC];
+    const char* wlo = reinterpret_cast<const char*>(a.w);
+    if (HEAD && a.w_b && reinterpret_cast<const char*>(a.w_b) < wlo) wlo = reinterpret_cast<const char*>(a.w_b);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wlo), 0, -1, 0x00020000);
+    unsigned wvo[TC];
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
         const int row = min(n0 + wave * (BCt / 4) + j * 16 + lrow, NC - 1);
-        wro[j] = (row < a.cout ? (long)row * K : wdelta / 2 + (long)(row - a.cout) * K) * 2 + lchunk * 16;
+        const bool first = row < a.cout;
+        const unsigned base = (unsigned)((first ? reinterpret_cast<const char*>(a.w) : reinterpret_cast<const char*>(a.w_b)) - wlo);
+        wvo[j] = base + (unsigned)(first ? row : row - a.cout) * (unsigned)K * 2u + (unsigned)lchunk * 16u;
     }
-
-    const char* zeros = reinterpret_cast<const char*>(a.zeros);
+    auto dma16 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned soff, unsigned dst) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" : : "v"(voff), "s"(rs), "s"(dst), "s"(soff) : "memory");
+    };
     auto issue_a = [&](int ab, int slice, int i, bool live) {    // piece i of this wave, 32-channel slice `slice` -> run buffer ab
-        // The DMA schedule is static (APW slots per wave and slice); a slot beyond the run, or a slice that does not exist, moves
-        // 16 cached zero bytes into the dummy block instead of branching around the instruction.
+        // The DMA schedule is static (APW slots per wave and slice); a slot beyond the run, or a slice that does not exist, lands in the
+        // dummy block instead of branching around the instruction.
         const int pc = wave + 4 * i;
         const bool real = live && pc < NPIECE;                   // wave-uniform
-        const int pix = min(max(arow0 + pc * 16, 0), M - 1);    // rows outside the tensor are masked in the fragments: any valid address
-        const char* p = real ? xbase + (long)((pix * CIN + lchunk * 8) * 2 + slice * 64) : zeros;
-        half_t* dst = real ? Abuf + ab * A_BUF + pc * 16 * HK : dummy;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)dst, 16, 0, 0);
+        // (a slot that is not needed asks for an offset beyond the buffer: no memory access, zeros into the dummy block)
+        dma16(xrs, real ? xvo + (unsigned)i * xstep : 0xfffffff0u, (unsigned)slice * 64u,
+              real ? lds0 + (unsigned)(ab * A_BUF + pc * 16 * HK) * 2u : dummy_dst);
     };
     auto issue_b = [&](int bb, int hf, int slice, int tap, int j) {      // 16 weight rows j of this wave's BCt / 4, half-stage (slice, tap)
-        const char* p = wbase + (wro[j] + (long)((tap * CIN + slice * 32) * 2));
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Bbuf + bb * B_STAGE + hf * B_HALF + (wave * (BCt / 4) + j * 16) * HK), 16, 0, 0);
+        dma16(wrs, wvo[j], (unsigned)(tap * CIN + slice * 32) * 2u,
+              lds0 + (unsigned)(2 * A_BUF + bb * B_STAGE + hf * B_HALF + (wave * (BCt / 4) + j * 16) * HK) * 2u);
     };
 
     if (tid < BCt) {
@@ -434,61 +469,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int kbw0 = ((wc * TC) * 32 + r) * HK + ((hh ^ ((r >> 2) & 3)) * 8);             // weight fragment, K step 0 / 1 of a half-stage
     const int kbw1 = ((wc * TC) * 32 + r) * HK + (((2 + hh) ^ ((r >> 2) & 3)) * 8);
     half8 xf0[TP], wf0[TC], xf1[TP], wf1[TC];
-    // fragments of half-stage (run buffer ab, tap, weight buffer bb / half hf), K step ks
-    auto read_frags = [&](half8 (&xf)[TP], half8 (&wf)[TC], int ab, int tap, int bb, int hf, int ks) {
+    // fragment addresses of half-stage (run buffer ab, tap, weight buffer bb / half hf), K step ks
+    auto x_addr = [&](int ab, int tap, int ks) -> const half_t* {
         const int ky = tap / KSZ, kx = tap - ky * KSZ;
         const int rs = r + HALO + (ky * dil - pad) * W + (kx * dil - pad);             // run row of pixel tile 0, wave row 0
         const int sw = (rs >> 2) & 3;
-        const half_t* xa = Abuf + ab * A_BUF + (wp * (BPt / 2) + rs) * HK + (((2 * ks + hh) ^ sw) * 8);
-#pragma unroll
-        for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const half8*>(xa + j * 32 * HK);
-        const half_t* wb = Bbuf + bb * B_STAGE + hf * B_HALF + (ks ? kbw1 : kbw0);
-#pragma unroll
-        for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + i * 32 * HK);
+        return Abuf + ab * A_BUF + (wp * (BPt / 2) + rs) * HK + (((2 * ks + hh) ^ sw) * 8);
     };
-    auto mask_frags = [&](half8 (&xf)[TP], int tap) {
+    auto w_addr = [&](int bb, int hf, int ks) -> const half_t* { return Bbuf + bb * B_STAGE + hf * B_HALF + (ks ? kbw1 : kbw0); };
+    auto mask_frag = [&](half8& xf, int j, int tap) {
+        const unsigned mk = 0u - ((vm[j] >> tap) & 1u);
+        uint4 v = *reinterpret_cast<uint4*>(&xf);
+        v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+        xf = *reinterpret_cast<half8*>(&v);
+    };
+    // One phase: the TP x TC MFMAs of fragments (xc, wc). Between them, in the source order (a scheduling barrier closes every MFMA slot):
+    // from slot R0 on the TP + TC fragment reads of the NEXT phase (xn from xa, wn from wb), then the phase's DMA pieces (dma(k), ND of
+    // them, one per slot), and in the last TP slots the tap masks of the pixel fragments just read. SYNC: slot R0 opens with the stage's
+    // counted wait and barrier (what the reads of this phase need: the next stage's weights and, at a run switch, the next run).
+    auto phase = [&](const half8 (&xc)[TP], const half8 (&wc)[TC], half8 (&xn)[TP], half8 (&wn)[TC], const half_t* xa, const half_t* wb,
+                     int mtap, auto r0, auto nwait, int nd, auto&& dma) {
+        constexpr int R0 = decltype(r0)::value, NW = decltype(nwait)::value;
+        constexpr int D0 = R0 + TP + TC < NM ? R0 + TP + TC : NM - 1;
 #pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const unsigned mk = 0u - ((vm[j] >> tap) & 1u);
-            uint4 v = *reinterpret_cast<uint4*>(&xf[j]);
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
-            xf[j] = *reinterpret_cast<half8*>(&v);
+        for (int u = 0; u < NM; ++u) {
+            if constexpr (NW >= 0) {
+                if (u == R0) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(NW) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            acc[u / TP][u % TP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[u / TP], xc[u % TP], acc[u / TP][u % TP], 0, 0, 0);
+            const int q = u - R0;
+            if (q >= 0 && q < TP) xn[q] = *reinterpret_cast<const half8*>(xa + q * 32 * HK);
+            else if (q >= TP && q < TP + TC) wn[q - TP] = *reinterpret_cast<const half8*>(wb + (q - TP) * 32 * HK);
+#pragma unroll
+            for (int k = 0; k < nd; ++k)
+                if ((D0 + k < NM ? D0 + k : NM - 1) == u) dma(k);
+            if (u >= NM - TP) mask_frag(xn[u - (NM - TP)], u - (NM - TP), mtap);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto mfma16 = [&](const half8 (&xf)[TP], const half8 (&wf)[TC]) {
-#pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    };
+    using I_ = std::integral_constant<int, 0>;
+    using NoSync = std::integral_constant<int, -1>;
 
-#define CH_PHASE(nvm)                                                  \
-    do {                                                               \
-        for (int u_ = 0; u_ < 16; ++u_) {                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
-            if (u_ < TP + TC) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
-            else {                                                     \
-                __builtin_amdgcn_sched_group_barrier(0x002, (4 * TP + 15 - TP - TC) / (16 - TP - TC), 0); \
-                if (u_ - TP - TC < (nvm)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-            }                                                          \
-        }                                                              \
-        __builtin_amdgcn_sched_barrier(0);                             \
-    } while (0)
-
-    // ---- prologue: run of slice 0, weights of stage 0
+    // ---- prologue: run of slice 0, weights of stage 0 and the first half of stage 1 (what P3 of a stage -1 would have requested)
 #pragma unroll
     for (int i = 0; i < APW; ++i) issue_a(0, 0, i, true);
 #pragma unroll
     for (int j = 0; j < TC; ++j) { issue_b(0, 0, 0, 0, j); issue_b(0, 1, 0, 1, j); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < TC; ++j) issue_b(1, 0, 0, 2, j);
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(TC) : "memory");
     __syncthreads();
-    read_frags(xf0, wf0, 0, 0, 0, 0, 0);
-    mask_frags(xf0, 0);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) { xf0[j] = *reinterpret_cast<const half8*>(x_addr(0, 0, 0) + j * 32 * HK); mask_frag(xf0[j], j, 0); }
+#pragma unroll
+    for (int i = 0; i < TC; ++i) wf0[i] = *reinterpret_cast<const half8*>(w_addr(0, 0, 0) + i * 32 * HK);
 
     // One loop iteration = slices 2 it (run buffer 0) and 2 it + 1 (run buffer 1) = 18 half-stages h = 0..17 = 9 stages.
-    // Stage s: half-stages h0 = 2 s, h1 = 2 s + 1; phases P0 (h0, K step 0) P1 (h0, 1) P2 (h1, 0) P3 (h1, 1); every phase reads
-    // the fragments of the next one. The DMA of the next stage's weights goes out in P0..P2, two pieces of a pixel run per stage
-    // (stages 0-3: slice 2 it + 1 -> buffer 1; stages 5-8: slice 2 it + 2 -> buffer 0), the stage's barrier sits before P3's MFMAs.
+    // Stage s: half-stages h0 = 2 s, h1 = 2 s + 1; phases P0 (h0, K step 0) P1 (h0, 1) P2 (h1, 0) P3 (h1, 1); every phase reads the
+    // fragments of the next one. Weight buffers alternate per stage. DMA: P3 of stage s - 1 (behind its barrier: the buffer stage s - 1
+    // used is free) requests the first half-stage of stage s + 1, P0 of stage s the second; P1 two..five pieces of a pixel run (stages
+    // 0-2: slice 2 it + 1 -> run buffer 1, stages 5-7: slice 2 it + 2 -> run buffer 0; a run is complete one stage before its first read).
+    // The wait in front of the barrier of stage s (P3) retires everything but the run pieces of its own P1.
     for (int it = 0; it < NIT; ++it) {
         const int sA = 2 * it, sB = 2 * it + 1;
         const int itn = min(it + 1, NIT - 1);
@@ -496,48 +540,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int S = decltype(sc)::value;
             constexpr int H0 = 2 * S, H1 = 2 * S + 1;
             constexpr int T0 = H0 % NT, T1 = H1 % NT, AB0 = H0 / NT, AB1 = H1 / NT;
-            constexpr int SN = (S + 1) % 9;                                  // next stage
-            constexpr int NH0 = 2 * SN, NH1 = 2 * SN + 1;
-            constexpr int NT0 = NH0 % NT, NT1 = NH1 % NT, NAB0 = NH0 / NT, NAB1 = NH1 / NT;
+            constexpr int S1 = (S + 1) % 9, S2 = (S + 2) % 9;                // next stage, the one after
+            constexpr int N1H0 = 2 * S1, N1H1 = 2 * S1 + 1, N2H0 = 2 * S2;
             const int bb = (it + S) & 1, nb = bb ^ 1;                        // weight buffer of this / the next stage (9 stages per iteration)
-            const int itx = (S == 8) ? itn : it;                             // iteration of the next stage (the very last stage reloads its own)
-            const int nsl0 = 2 * itx + NAB0, nsl1 = 2 * itx + NAB1;
+            const int it1 = (S + 1 >= 9) ? itn : it, it2 = (S + 2 >= 9) ? itn : it;  // (beyond the last stage: its own slices again, never read)
+            constexpr int AQ = S <= 2 ? S : S >= 5 && S <= 7 ? S - 5 : -1;   // run pieces requested in this stage: AQ * APS ..
+            constexpr int NA = AQ < 0 ? 0 : (APW - APS * AQ < 0 ? 0 : APW - APS * AQ > APS ? APS : APW - APS * AQ);
             // P0
-            read_frags(xf1, wf1, AB0, T0, bb, 0, 1);
-#pragma unroll
-            for (int j = 0; j < TC; ++j) issue_b(nb, 0, nsl0, NT0, j);
-            mfma16(xf0, wf0);
-            mask_frags(xf1, T0);
-            CH_PHASE(TC);
+            phase(xf0, wf0, xf1, wf1, x_addr(AB0, T0, 1), w_addr(bb, 0, 1), T0, I_{}, NoSync{}, TC,
+                  [&](int j) { issue_b(nb, 1, 2 * it1 + N1H1 / NT, N1H1 % NT, j); });
             // P1
-            read_frags(xf0, wf0, AB1, T1, bb, 1, 0);
-#pragma unroll
-            for (int j = 0; j < TC; ++j) issue_b(nb, 1, nsl1, NT1, j);
-            mfma16(xf1, wf1);
-            mask_frags(xf0, T1);
-            CH_PHASE(TC);
+            phase(xf1, wf1, xf0, wf0, x_addr(AB1, T1, 0), w_addr(bb, 1, 0), T1, I_{}, NoSync{}, NA, [&](int u) {
+                if constexpr (S <= 2) issue_a(1, sB, APS * AQ + u, true);
+                else if constexpr (S >= 5 && S <= 7) issue_a(0, sA + 2, APS * AQ + u, it + 1 < NIT);
+            });
             // P2
-            read_frags(xf1, wf1, AB1, T1, bb, 1, 1);
-            if constexpr (S <= 3) {
-#pragma unroll
-                for (int u = 0; u < APS; ++u)
-                    if (APS * S + u < APW) issue_a(1, sB, APS * S + u, true);
-            }
-            if constexpr (S >= 5) {
-#pragma unroll
-                for (int u = 0; u < APS; ++u)
-                    if (APS * (S - 5) + u < APW) issue_a(0, sA + 2, APS * (S - 5) + u, it + 1 < NIT);
-            }
-            mfma16(xf0, wf0);
-            mask_frags(xf1, T1);
-            CH_PHASE(APS);
-            // P3: the barrier, then the next stage's first fragments
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            read_frags(xf0, wf0, NAB0, NT0, nb, 0, 0);
-            mfma16(xf1, wf1);
-            mask_frags(xf0, NT0);
-            CH_PHASE(0);
+            phase(xf0, wf0, xf1, wf1, x_addr(AB1, T1, 1), w_addr(bb, 1, 1), T1, I_{}, NoSync{}, 0, [&](int) {});
+            // P3: two MFMAs, the counted wait and the barrier, then the next stage's first fragments and the stage after's first weights
+            phase(xf1, wf1, xf0, wf0, x_addr(N1H0 / NT, N1H0 % NT, 0), w_addr(nb, 0, 0), N1H0 % NT, std::integral_constant<int, (NM >= 16 ? 2 : 1)>{},
+                  std::integral_constant<int, NA>{}, TC, [&](int j) { issue_b(bb, 0, 2 * it2 + N2H0 / NT, N2H0 % NT, j); });
         };
         stage(std::integral_constant<int, 0>{});
         stage(std::integral_constant<int, 1>{});
@@ -549,6 +570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         stage(std::integral_constant<int, 7>{});
         stage(std::integral_constant<int, 8>{});
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the requests of the stages that do not exist
     __syncthreads();
     if constexpr (HEAD) conv_epilogue_fp32<TP, TC>(acc, a, lds, bsh, m0, n0);
     else conv_epilogue<TP, TC>(acc, a, lds, bsh, m0, n0);
@@ -754,7 +776,9 @@ int launch_halo(const PwArgs& a, hipStream_t s, const char* name) {
     const size_t lds = (st > ot ? st : ot) * sizeof(half_t) + BCt * sizeof(float);
     DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_halo_kernel<3, TP, TC, HEAD>)));
     dn_note_kernel(name);
-    hipLaunchKernelGGL((conv_halo_kernel<3, TP, TC, HEAD>), dim3(dn_cdiv(a.m, BPt), dn_cdiv(a.cout + (HEAD ? a.cout_b : 0), BCt)), dim3(256), lds, s, a);
+    PwArgs b = a;
+    b.cv_plain_order = dn_knob("DN_CONV_PLAIN_ORDER", 0);
+    hipLaunchKernelGGL((conv_halo_kernel<3, TP, TC, HEAD>), dim3(dn_cdiv(a.m, BPt), dn_cdiv(a.cout + (HEAD ? a.cout_b : 0), BCt)), dim3(256), lds, s, b);
     return DN_OK;
 }
 
@@ -818,12 +842,37 @@ int launch_conv_patch_pool(const PwArgs& a, hipStream_t s) {
     return launch_patch(a, s);
 }
 
-bool conv_head_big_supported(const PwArgs& a) {
+// Tile of a dense fp32 head launch: 0 none, 1 = 256 px x 256 ch, 2 = 512 x 128, 3 = 256 x 128. The class + box channels of a level (380 / 570
+// for 91 classes) fill 74 % of two / three 256-channel tiles but 99 % / 89 % of three / five 128-channel tiles, and the 512 x 128 run tile
+// runs level with the 256 x 256 one per FLOP (conv3 .. conv5 of ssd512_vgg16: 1140-1330 vs 1150-1320 TFLOP/s): the idle channels were a
+// quarter of the head launches' time. A level too small for half the chip in 512-pixel tiles (the 16 x 16 level of ssd512 at batch 32: 80
+// workgroups) takes 256 x 128 tiles -- twice the workgroups at half the work each.
+static int head_variant(const PwArgs& a) {
     const int on = dn_knob("DN_CONV_HEAD_BIG", 1);
     const int minwg = dn_knob("DN_CONV_HEAD_BIG_MIN", 40);
-    if (!on || !a.out_fp32 || a.residual || a.se || !halo_shape(a) || 256 + halo_rows(a) > halo_run_rows(4, 4) || (a.cout & 1)) return false;
+    if (!on || !a.out_fp32 || a.residual || a.se || !halo_shape(a) || (a.cout & 1)) return 0;
+    const int hr = halo_rows(a), nc = a.cout + a.cout_b;
+    const int c256 = dn_cdiv(nc, 256), c128 = dn_cdiv(nc, 128);
+    const long p256 = dn_cdiv(a.m, 256), p512 = dn_cdiv(a.m, 512);
+    const int narrow = dn_knob("DN_CONV_HEAD_NARROW", 1);
+    if (narrow && c128 * 128 < c256 * 256 && a.cv_cin >= 128) {
+        if (512 + hr <= halo_run_rows(8, 2) && p512 * c128 >= 128) return 2;
+        if (256 + hr <= halo_run_rows(4, 2) && p256 * c128 >= 2 * minwg) return 3;      // (40 workgroups of the 8 x 8 level: slower than the group launch)
+    }
     const int tiles = dn_cdiv(a.cout, 256);
-    return a.cout * 10 >= tiles * 256 * 6 && (long)dn_cdiv(a.m, 256) * tiles >= minwg;      // at most 40 % of the channel tiles idle
+    if (256 + hr <= halo_run_rows(4, 4) && a.cout * 10 >= tiles * 256 * 6 && p256 * tiles >= minwg) return 1;      // at most 40 % of the channel tiles idle
+    return 0;
 }
 
-int launch_conv_head_big(const PwArgs& a, hipStream_t s) { return launch_halo<4, 4, true>(a, s, "conv_halo_kernel<3,4,4,head>"); }
+bool conv_head_big_supported(const PwArgs& a) { return head_variant(a) != 0; }
+
+int launch_conv_head_big(const PwArgs& a, hipStream_t s) {
+    switch (head_variant(a)) {
+        case 1: return launch_halo<4, 4, true>(a, s, "conv_halo_kernel<3,4,4,head>");
+        case 2: return launch_halo<8, 2, true>(a, s, "conv_halo_kernel<3,8,2,head>");
+        case 3: return launch_halo<4, 2, true>(a, s, "conv_halo_kernel<3,4,2,head>");
+        default: break;
+    }
+    dn_set_error("dense head: not supported by the run-staged tiles");
+    return DN_E_UNSUPPORTED;
+}

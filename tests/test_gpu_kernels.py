@@ -206,6 +206,8 @@ DENSE_CASES = [
     (1, 12, 256, 64, 128, 3, 1, 1, 1, 1, True),      # wide map, one 64-channel iteration: 256 x 128 tile
     (1, 10, 300, 64, 64, 3, 1, 1, 1, 1, True),       # conv1_2-like: 256 x 64 tile, W = 300
     (5, 9, 9, 64, 64, 3, 1, 1, 1, 1, True),          # tiles spanning several small images
+    (9, 19, 19, 128, 512, 3, 1, 1, 1, 1, True),      # 13 pixel tiles x 2 channel tiles: XCD-grouped tile order (8 + remainder 5), two K iterations
+    (16, 16, 16, 192, 256, 3, 1, 1, 1, 1, True),     # 16 pixel tiles, three K iterations (run buffers refilled twice)
 ]
 
 
