@@ -148,3 +148,46 @@ def test_persistent_expdw_has_no_scratch(tmp_path):
     assert one
     for name in one:
         assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[name]), f"{name}: scratch"
+
+
+def test_run_staged_conv_dma_is_hidden_from_the_compiler_and_m0_is_only_touched_in_asm(tmp_path):
+    """conv_halo_kernel issues its LDS-DMA (`buffer_load_dwordx4 ... lds`) from inline asm and writes M0 (the LDS address of the piece) there
+    without saving it -- M0 is a reserved register that cannot be declared clobbered. That is only sound while hipcc itself never uses M0 in
+    these kernels: every mention of m0 must sit inside an asm block, and no instruction that reads M0 implicitly may appear outside one. The
+    stage barriers must carry the counted waits (a run piece left in flight is retired by the next stage's wait), the loop must not contain a
+    compiler-issued vector-memory operation (it would shift the counts), and the kernels must not spill."""
+    text = _asm("convbig.hip", tmp_path)
+    kernels, meta = _kernels(text)
+    halo = {k: v for k, v in kernels.items() if "conv_halo_kernel" in k}
+    assert len(halo) >= 6, list(kernels)
+    implicit_m0 = ("s_movrel", "v_movrel", "ds_gws", "s_sendmsg", "v_interp", "ds_add_gs", "ds_sub_gs", "s_ttrace")
+    for name, lines in halo.items():
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[name]), f"{name}: scratch"
+        in_asm, dma, waits, barriers_after_first_dma = False, 0, [], 0
+        last_dma_line = max(i for i, l in enumerate(lines) if "buffer_load_dwordx4" in l and " lds" in l)
+        for ln, raw in enumerate(lines):
+            if "#ASMSTART" in raw:
+                in_asm = True
+                continue
+            if "#ASMEND" in raw:
+                in_asm = False
+                continue
+            op, ops = _operands(raw)
+            if op is None:
+                continue
+            if in_asm:
+                if op.startswith("buffer_load_dwordx4"):
+                    assert " lds" in raw, raw
+                    dma += 1
+                m = re.search(r"s_waitcnt vmcnt\((\d+)\)", raw)
+                if m:
+                    waits.append(int(m.group(1)))
+                continue
+            assert "m0" not in raw.split(";")[0], f"{name}: compiler-generated use of m0 (line {ln}): {raw.strip()}"
+            assert not op.startswith(implicit_m0), f"{name}: `{op}` reads M0 implicitly (line {ln})"
+            # between the first and the last DMA piece (prologue + main loop) the only vector-memory operations are the asm-issued pieces
+            if dma and ln < last_dma_line:
+                assert not op.startswith(VMEM), f"{name}: compiler-issued `{op}` inside the DMA-counted region (line {ln})"
+        assert dma >= 40, (name, dma)                                   # prologue + 9 unrolled stages
+        assert len(waits) >= 11 and waits[-1] == 0, (name, waits)       # prologue, 9 stage waits, the drain in front of the epilogue
+        assert any(w > 0 for w in waits[1:-1]), (name, waits)           # counted: stages that request run pieces leave them in flight
