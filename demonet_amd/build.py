@@ -31,15 +31,18 @@ def _stale(target, deps):
 
 
 def build_stamps(verbose=True):
-    """Dev build: lib/libdemonet_hip_stamps.so = the same objects with headfuse.hip compiled with -DDN_DEV_STAMPS (per-workgroup phase cycle
-    sums, tools/probe_headfuse.py). Load it with DEMONET_HIP_LIB=<path>; the product library never carries the stamps."""
+    """Dev build: lib/libdemonet_hip_stamps.so = the same objects with headfuse.hip and expdw.hip compiled with -DDN_DEV_STAMPS (per-workgroup phase
+    stamps, tools/probe_headfuse.py, tools/probe_expdw_block.py). Load it with DEMONET_HIP_LIB=<path>; the product library never carries the stamps."""
     build(verbose=verbose)
-    obj = os.path.join(LIBDIR, "headfuse_stamps.o")
-    cmd = [HIPCC] + COMMON + ["-DDN_DEV_STAMPS", "-c", os.path.join(CSRC, "headfuse.hip"), "-o", obj]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "headfuse.hip"] + [obj]
+    stamped = ["headfuse.hip", "expdw.hip"]
+    objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s not in stamped]
+    for src in stamped:
+        obj = os.path.join(LIBDIR, src.replace(".hip", "_stamps.o"))
+        cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + ["-DDN_DEV_STAMPS", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
     out = os.path.join(LIBDIR, "libdemonet_hip_stamps.so")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out

@@ -23,6 +23,14 @@
 static long long* g_xd_stamps = nullptr;     // dev hook (tools/probe_expdw.py): per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_expdw_stamps(void* dev_ptr) { g_xd_stamps = (long long*)dev_ptr; }
 #define XD_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#ifdef DN_DEV_STAMPS
+// dev build only (python -m demonet_amd.build --stamps): finer stamps inside the SECOND chunk of the run (the steady state), slots 5.. A stamp is a
+// global store: a phase that contains an `s_waitcnt vmcnt(0)` also waits for the previous stamp's acknowledgement -- read the LDS-only phases
+// (depthwise) at face value and the others as upper bounds.
+#define XD_STAMP2(k) do { if (a.stamps && threadIdx.x == 0 && c0 == c_begin + 64) a.stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define XD_STAMP2(k) do { } while (0)
+#endif
 
 namespace {
 
@@ -196,11 +204,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
         const bool wide = WIDE && c_end - c0 == EW;         // the last 72 channels in one go
         const int cw = wide ? EW : 64, ng = cw >> 3;
         {
+            XD_STAMP2(5);
             const int wrow_i = tid / 9, wc8 = tid - wrow_i * 9;
             const bool wok = tid < K * K * 9 && wc8 < ng && c0 + wc8 * 8 < cexp;
             if (tid < K * K * 9) *reinterpret_cast<uint4*>(&Wd[wrow_i * EW + wc8 * 8]) = wok ? wdreg : make_uint4(0, 0, 0, 0);
             if (tid < EW) Bd[tid] = (tid < cw && c0 + tid < cexp) ? bdreg : 0.f;
         }
+        XD_STAMP2(6);
         // ---- 2. expand on the matrix cores. A = weight rows (channels), B = pixel rows: the accumulator then holds, per lane,
         //         pixel (lane & 31) and channels 8g + 4*(lane >> 5) .. +3 in registers 4g .. 4g+3.
         //         wave w: channel tile t = w & 1 of the chunk, row tiles (w >> 1), (w >> 1) + 4, ...
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
                 }
             }
         }
+        XD_STAMP2(7);
         const int cnext = c0 + cw;
         if constexpr (!ONE) { if (cnext < c_end) request_chunk(cnext, WIDE && c_end - cnext == EW); }       // lands under the depthwise stage
         if constexpr (PROJ) {
@@ -257,6 +268,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
         }
         __syncthreads();
         if (c0 == c_begin) XD_STAMP(2);
+        XD_STAMP2(8);
 
         // ---- 3. depthwise over the LDS tile: item = (output pixel, 8-channel group)
         float psum[8];
@@ -297,6 +309,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
                 else *reinterpret_cast<half8*>(a.out + (((size_t)n * a.Ho + gy) * a.Wo + gx) * cexp + c0 + cg * 8) = hv;
             }
         }
+        XD_STAMP2(9);
         if (a.pool) {
             // per-tile channel sums in a fixed order: the 8 lanes of a wave that share a channel group, then the waves
 #pragma unroll
@@ -324,6 +337,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
             if (c0 + cw > cexp)
                 for (int item = tid; item < DROWS * 8; item += NT)
                     if (c0 + (item & 7) * 8 >= cexp) *reinterpret_cast<uint4*>(&Ds[(item >> 3) * EW + (item & 7) * 8]) = make_uint4(0, 0, 0, 0);
+            XD_STAMP2(10);
             __syncthreads();
             if (punit) {
                 const bool cok = pc * 32 + r < a.cout;
@@ -339,8 +353,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
                 }
             }
         }
+        XD_STAMP2(11);
         __syncthreads();        // Es / Wd / Bd / Ps / Ds are rewritten by the next chunk (and by the staged output tile)
         if (c0 == c_begin) XD_STAMP(3);
+        XD_STAMP2(12);
         if constexpr (ONE) break;
         c0 = cnext;
     }
