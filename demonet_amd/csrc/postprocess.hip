@@ -533,12 +533,26 @@ __device__ __forceinline__ void select_nms_one(const float* __restrict__ scoresT
 }
 
 
+// What the merge needs besides the per-class survivor lists (one struct: the fallback launch carries it too)
+struct MergeArgs {
+    const float* scale_xy; float* oboxes; float* oscores; long long* olabels; int* ocounts; int* oanchor; float* opacked;
+    const unsigned* tauKey; int* needFull; int D;
+};
+constexpr int MERGE_LCAP = 3072;
+// LDS of the merge, carved from one buffer (the stand-alone launch owns a static one; the fused fallback launch lends the selection's dynamic LDS)
+constexpr int MERGE_LDS = 2 * 512 * 8 + MERGE_LCAP * (8 + 4 + 2) + 256 * 4 + 256 + 256 * 4 + 1040;
+
+template <int MT>
+__device__ __forceinline__ void merge_body(char* __restrict__ mlds, const float* __restrict__ keptScore, const int* __restrict__ keptAnchor,
+                                           const int* __restrict__ keptCount, const float4* __restrict__ boxes, int A, int Km1, int topk,
+                                           const MergeArgs& g, int mode, int n);
+
 template <int NW, bool PERM>
 __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict__ scoresT, const float4* __restrict__ boxes,
                                                         int A, int Km1, float score_thr, float nms_thr, int topk,
                                                         float* __restrict__ keptScore, int* __restrict__ keptAnchor,
                                                         int* __restrict__ keptCount, const int* __restrict__ needFull,
-                                                        long long* stamps, int nimg, int xq, PostLevels lv, int islots) {
+                                                        long long* stamps, int nimg, int xq, PostLevels lv, int islots, MergeArgs mg, int* __restrict__ fbcnt) {
     // islots == 0: flat grid [image slot][class], one (image, class) per workgroup; cls 0..Km1-1 (label = cls + 1).
     // islots > 0 (the fallback behind the cut-off pass, usually with no flagged image at all): grid [islots][class], a workgroup walks the images
     // slot, slot + islots, ... and works on the flagged ones -- 8 x 90 workgroups that look at 8 flags each instead of 64 x 90 that look at one.
@@ -547,10 +561,26 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
         bool any = false;
         for (int n1 = slot; n1 < nimg; n1 += islots) any |= needFull[n1] != 0;
         if (!any) return;
+        __shared__ int s_lastm;
         for (int n1 = slot; n1 < nimg; n1 += islots) {
             if (!needFull[n1]) continue;
             select_nms_one<NW, PERM>(scoresT, boxes, A, Km1, score_thr, nms_thr, topk, keptScore, keptAnchor, keptCount, stamps, lv, n1, cls1);
             __syncthreads();                    // the next image reuses the workgroup's LDS
+            if (fbcnt) {
+                // The image's merge in the same launch: the workgroup that finishes the image's LAST class merges it (one launch less per forward; the
+                // path is rare, so the device-scope fences -- an L2 write-back / invalidate each on this chip -- are affordable here). The counter is
+                // zeroed by tau_kernel in every forward and left at zero.
+                __threadfence();
+                if (threadIdx.x == 0) s_lastm = atomicAdd(&fbcnt[n1], 1) == Km1 - 1;
+                __syncthreads();
+                if (s_lastm) {
+                    __threadfence();
+                    extern __shared__ __attribute__((aligned(16))) char dynlds[];      // the selection is done with it (launcher: >= MERGE_LDS bytes)
+                    merge_body<256>(dynlds, keptScore, keptAnchor, keptCount, boxes, A, Km1, topk, mg, 1, n1);
+                    if (threadIdx.x == 0) fbcnt[n1] = 0;
+                }
+                __syncthreads();
+            }
         }
         return;
     }
@@ -568,7 +598,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ phist, int tiles, int hb0, int clamped, unsigned want,
                                                  unsigned* __restrict__ tauKey, int* __restrict__ needFull, int nimg, int xq,
-                                                 int nb, int Km1, int* __restrict__ order) {
+                                                 int nb, int Km1, int* __restrict__ order, int* __restrict__ fbcnt) {
     __shared__ unsigned part[256];
     const int tid = threadIdx.x;
     int n, unused;
@@ -607,6 +637,7 @@ __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ p
         for (int t = 0; t < nb; ++t) total += part[t];
         if (total < want) tauKey[n] = 0u;        // fewer passing scores than wanted: take everything
         needFull[n] = 0;
+        fbcnt[n] = 0;                            // ticket of the fused fallback merge (select_nms_kernel)
     }
 }
 
@@ -713,24 +744,25 @@ __global__ __launch_bounds__(FT) void select_nms_fast_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------------------
 template <int MT>       // threads per workgroup: 1024 sorts fastest, 256 is scheduled at once beside the other chain's kernels (a 1024-thread
                         // workgroup waits for 16 free wave slots on ONE compute unit)
-__global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ keptScore, const int* __restrict__ keptAnchor,
-                                                    const int* __restrict__ keptCount, const float4* __restrict__ boxes,
-                                                    const float* __restrict__ scale_xy, int A, int Km1, int topk, int D,
-                                                    float* __restrict__ oboxes, float* __restrict__ oscores,
-                                                    long long* __restrict__ olabels, int* __restrict__ ocounts,
-                                                    int* __restrict__ oanchor, int mode, const unsigned* __restrict__ tauKey,
-                                                    int* __restrict__ needFull, float* __restrict__ opacked, int nimg, int xq) {
+__device__ __forceinline__ void merge_body(char* __restrict__ mlds, const float* __restrict__ keptScore, const int* __restrict__ keptAnchor,
+                                           const int* __restrict__ keptCount, const float4* __restrict__ boxes, int A, int Km1, int topk,
+                                           const MergeArgs& g, int mode, int n) {
     // mode 0: after the fast per-class pass (may raise needFull); mode 1: after the full pass (only flagged images);
     // mode 2: unconditional (fast path disabled)
-    int n, unused;
-    if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
-    if (mode == 0 && needFull[n]) return;
-    if (mode == 1 && !needFull[n]) return;
-    __shared__ unsigned long long fin[512];
-    __shared__ unsigned long long fin2[512];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned sh[40];
-    __shared__ int ccount[256];
+    const float* __restrict__ scale_xy = g.scale_xy;
+    float* __restrict__ oboxes = g.oboxes; float* __restrict__ oscores = g.oscores; long long* __restrict__ olabels = g.olabels;
+    int* __restrict__ ocounts = g.ocounts; int* __restrict__ oanchor = g.oanchor; float* __restrict__ opacked = g.opacked;
+    const unsigned* __restrict__ tauKey = g.tauKey; int* __restrict__ needFull = g.needFull;
+    const int D = g.D;
+    unsigned long long* fin = reinterpret_cast<unsigned long long*>(mlds);           // [512]
+    unsigned long long* fin2 = fin + 512;                                            // [512]
+    unsigned long long* lkey = fin2 + 512;                                           // [MERGE_LCAP]
+    int* lanc = reinterpret_cast<int*>(lkey + MERGE_LCAP);                           // [MERGE_LCAP]
+    unsigned short* llab = reinterpret_cast<unsigned short*>(lanc + MERGE_LCAP);     // [MERGE_LCAP]
+    unsigned* hist = reinterpret_cast<unsigned*>(llab + MERGE_LCAP);                 // [256]
+    unsigned* sh = hist + 256;                                                       // [40] (64 reserved)
+    int* ccount = reinterpret_cast<int*>(sh + 64);                                   // [256]
+    int* cpre = ccount + 256;                                                        // [257]
     const int tid = threadIdx.x;
     const int F = Km1 * topk;
     const float* ks = keptScore + (size_t)n * F;
@@ -754,7 +786,6 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
     }
     // survivors live in per-class slots [c][0..ccount[c]); walk them through the class prefix sums (e -> class by binary
     // search) instead of scanning all Km1*topk slots: `total` is a few thousand, the slot array 27k.
-    __shared__ int cpre[257];
     if (tid < 64) {
         // exclusive scan of ccount over classes, one wave (Km1 <= 256)
         int run = 0;
@@ -786,10 +817,7 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
     // per entry and pass (the kernel was five exposed memory round trips long: 20 us per launch at any batch size).
     // (round 3: the survivor's anchor and label are fetched in the same round trip and kept beside the key, whose low word is then the survivor's
     //  index e -- monotone in the slot f, so ties break exactly as before -- : the output gather is one dependent load shorter)
-    constexpr int LCAP = 3072;
-    __shared__ unsigned long long lkey[LCAP];
-    __shared__ int lanc[LCAP];
-    __shared__ unsigned short llab[LCAP];
+    constexpr int LCAP = MERGE_LCAP;
     const bool in_lds = total <= (unsigned)LCAP;
     if (in_lds) {
         for (int e = tid; e < (int)total; e += MT) {
@@ -890,6 +918,18 @@ __global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ kep
     }
 }
 
+template <int MT>
+__global__ __launch_bounds__(MT) void merge_kernel(const float* __restrict__ keptScore, const int* __restrict__ keptAnchor,
+                                                    const int* __restrict__ keptCount, const float4* __restrict__ boxes, int A, int Km1, int topk,
+                                                    MergeArgs g, int mode, int nimg, int xq) {
+    __shared__ __attribute__((aligned(16))) char mlds[MERGE_LDS];
+    int n, unused;
+    if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
+    if (mode == 0 && g.needFull[n]) return;
+    if (mode == 1 && !g.needFull[n]) return;
+    merge_body<MT>(mlds, keptScore, keptAnchor, keptCount, boxes, A, Km1, topk, g, mode, n);
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <int NW>
@@ -901,9 +941,10 @@ size_t p2_lds_bytes(int A) {
 
 template <int NW>
 int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, float* keptScore, int* keptAnchor, int* keptCount,
-              const int* needFull, hipStream_t s) {
-    const size_t lds = p2_lds_bytes<NW>(a.A);
-    if (lds > 160 * 1024) {
+              const int* needFull, const MergeArgs& mg, int* fbcnt, hipStream_t s) {
+    // (fbcnt: the image's merge runs in this launch, in the selection's LDS: the request covers both)
+    const size_t lds = fbcnt ? std::max<size_t>(p2_lds_bytes<NW>(a.A), MERGE_LDS) : p2_lds_bytes<NW>(a.A);
+    if (lds > 160 * 1024 - 64) {
         dn_set_error("postprocess: %d anchors need %zu B of LDS (> 160 KiB)", a.A, lds);
         return DN_E_UNSUPPORTED;
     }
@@ -911,14 +952,14 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
     // behind the cut-off pass (needFull given) only flagged images are worked on -- usually none: a small grid whose workgroups walk the images
     const int islots = (needFull && dn_knob("DN_PP_FALLBACK_SLOTS", 8) > 0) ? std::min(a.n, dn_knob("DN_PP_FALLBACK_SLOTS", 8)) : 0;
     if (perm) {
-        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, true>)));
+        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, true>), 160 * 1024 - 64));      // (minus the kernel's static LDS: the ticket flag)
         hipLaunchKernelGGL((select_nms_kernel<NW, true>), dim3((a.K - 1) * (islots > 0 ? islots : xcd_image_slots(a.xq, a.n))), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                           a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv, islots);
+                           a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv, islots, mg, islots > 0 ? fbcnt : nullptr);
         return DN_OK;
     }
-    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, false>)));
+    DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, false>), 160 * 1024 - 64));      // (minus the kernel's static LDS: the ticket flag)
     hipLaunchKernelGGL((select_nms_kernel<NW, false>), dim3((a.K - 1) * (islots > 0 ? islots : xcd_image_slots(a.xq, a.n))), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
-                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv, islots);
+                       a.score_thresh, a.nms_thresh, a.topk, keptScore, keptAnchor, keptCount, needFull, g_pp_stamps, a.n, a.xq, a.lv, islots, mg, islots > 0 ? fbcnt : nullptr);
     return DN_OK;
 }
 
@@ -943,7 +984,7 @@ size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
     (void)dets;
     const size_t Km1 = K - 1;
     return align256((size_t)n * Km1 * A * 4) + align256((size_t)n * A * 16) + 2 * align256((size_t)n * Km1 * topk * 4) +
-           align256((size_t)n * Km1 * 4) + align256((size_t)n * dn_cdiv(A, 64) * HBINS * 4 + (size_t)n * (8 + 4 * Km1));
+           align256((size_t)n * Km1 * 4) + align256((size_t)n * dn_cdiv(A, 64) * HBINS * 4 + (size_t)n * (12 + 4 * Km1));
 }
 
 void post_hist_range(float score_thresh, int* hb0_out, int* nb_out, int* clamped_out) {
@@ -1000,6 +1041,7 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     unsigned* tauKey = phist + (size_t)a.n * tiles * HBINS;
     int* needFull = reinterpret_cast<int*>(tauKey + a.n);
     int* order = needFull + a.n;                                           // [n][K-1] classes, heaviest first (tau_kernel)
+    int* fbcnt = order + (size_t)a.n * Km1;                                // [n] tickets of the fused fallback merge (zeroed by tau_kernel)
 
     const int fast = dn_knob("DN_PP_FAST", 1);
     // candidates per image kept by the cut-off, as a multiple of D. Any value is exact (too few survivors -> device-side
@@ -1008,6 +1050,7 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     const int want_mult = dn_knob("DN_PP_WANT", 4);
     long long* labels = reinterpret_cast<long long*>(a.labels);
     const int nw = (a.topk + 63) / 64;
+    const MergeArgs mg{a.scale_xy, a.boxes, a.scores, labels, a.counts, a.kept_anchor, a.packed, tauKey, needFull, a.dets};
 
     if (ev) (void)hipEventRecord(ev[0], s);
     int hb0, nb, clamped;
@@ -1029,7 +1072,7 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     int rc = DN_OK;
     if (fast) {
         hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, hist_rows, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq,
-                           nb, (int)Km1, order);
+                           nb, (int)Km1, order, fbcnt);
         const int* ord = dn_knob("DN_PP_ORDER", 1) ? order : nullptr;      // heaviest classes first (0: class order)
         if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
@@ -1037,27 +1080,29 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
         else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         if (dn_knob("DN_MERGE_THREADS", 1024) == 256)
-            hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                               (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed, a.n, a.xq);
+            hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 0, a.n, a.xq);
         else
-            hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                               (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 0, tauKey, needFull, a.packed, a.n, a.xq);
+            hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 0, a.n, a.xq);
     }
     const int* flag = fast ? needFull : nullptr;
-    if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
-    else if (nw <= 2) rc = launch_p2<2>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
-    else if (nw <= 4) rc = launch_p2<4>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
-    else if (nw <= 5) rc = launch_p2<5>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
-    else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, s);
+    // behind the cut-off pass: ONE launch redoes the flagged images (usually none) with the full kernel and merges each in the workgroup that
+    // finishes its last class (DN_PP_FUSE_FALLBACK, default 1; 0: a second merge launch as in rounds 1 - 3)
+    const bool fuse_fb = fast && dn_knob("DN_PP_FUSE_FALLBACK", 1) && dn_knob("DN_PP_FALLBACK_SLOTS", 8) > 0;
+    int* fb = fuse_fb ? fbcnt : nullptr;
+    if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
+    else if (nw <= 2) rc = launch_p2<2>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
+    else if (nw <= 4) rc = launch_p2<4>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
+    else if (nw <= 5) rc = launch_p2<5>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
+    else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
     if (rc != DN_OK) return rc;
     if (ev) (void)hipEventRecord(ev[2], s);
-    // the merge after the full pass: with the fast path on it only works for flagged images (usually none): 256 threads, scheduled at once
-    if (fast && dn_knob("DN_MERGE1_THREADS", 256) == 256)
-        hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, 1, tauKey, needFull, a.packed, a.n, a.xq);
-    else
-        hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.scale_xy, a.A,
-                           (int)Km1, a.topk, a.dets, a.boxes, a.scores, labels, a.counts, a.kept_anchor, fast ? 1 : 2, tauKey, needFull, a.packed, a.n, a.xq);
+    if (!fuse_fb) {
+        // the merge after the full pass: with the fast path on it only works for flagged images (usually none): 256 threads, scheduled at once
+        if (fast && dn_knob("DN_MERGE1_THREADS", 256) == 256)
+            hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 1, a.n, a.xq);
+        else
+            hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, fast ? 1 : 2, a.n, a.xq);
+    }
     if (ev) (void)hipEventRecord(ev[3], s);
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;
