@@ -384,19 +384,9 @@ class SSD(nn.Module):
             # are views into it (three copy launches instead of three per image: 0.2 -> 1 ms of launches at 64 images)
             boxes, scores, labels = boxes.clone(), scores.clone(), labels.clone()
             cnt = counts.tolist()                                                   # the one device->host sync
-            # per-image views of the valid rows: ONE tensor_split per output (cut points c_j and the image boundaries; the even pieces are
-            # the images' valid rows) instead of two indexing calls per image and output -- 384 dispatcher calls were 0.3 ms of a 64-image call
-            D = boxes.shape[1]
-            cuts: List[int] = []
-            for j, c in enumerate(cnt):
-                cuts.append(j * D + c)
-                cuts.append((j + 1) * D)
-            cuts.pop()
-            vb = torch.tensor_split(boxes.view(-1, 4), cuts)[0::2]
-            vs = torch.tensor_split(scores.view(-1), cuts)[0::2]
-            vl = torch.tensor_split(labels.view(-1), cuts)[0::2]
             for j, i in enumerate(idxs):
-                d = {"boxes": vb[j], "scores": vs[j], "labels": vl[j]}
+                c = cnt[j]
+                d = {"boxes": boxes[j, :c], "scores": scores[j, :c], "labels": labels[j, :c]}     # (192 view objects per 64 images: ~0.4 ms of host time, inherent to the list-of-dicts contract)
                 if legacy:
                     d = OrderedDict((k, d[k]) for k in ("scores", "labels", "boxes"))   # box_head.py:379 order
                 out[i] = d
