@@ -384,9 +384,13 @@ class SSD(nn.Module):
             # are views into it (three copy launches instead of three per image: 0.2 -> 1 ms of launches at 64 images)
             boxes, scores, labels = boxes.clone(), scores.clone(), labels.clone()
             cnt = counts.tolist()                                                   # the one device->host sync
+            # per-image views: one unbind per output (0.7 us per view) and a slice only where an image has fewer than D detections (2 us each);
+            # indexing [j, :c] for every image and output was 0.4 ms of host time per 64-image call
+            D = boxes.shape[1]
+            ub, us, ul = boxes.unbind(0), scores.unbind(0), labels.unbind(0)
             for j, i in enumerate(idxs):
                 c = cnt[j]
-                d = {"boxes": boxes[j, :c], "scores": scores[j, :c], "labels": labels[j, :c]}     # (192 view objects per 64 images: ~0.4 ms of host time, inherent to the list-of-dicts contract)
+                d = {"boxes": ub[j], "scores": us[j], "labels": ul[j]} if c == D else {"boxes": ub[j][:c], "scores": us[j][:c], "labels": ul[j][:c]}
                 if legacy:
                     d = OrderedDict((k, d[k]) for k in ("scores", "labels", "boxes"))   # box_head.py:379 order
                 out[i] = d
