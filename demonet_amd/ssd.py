@@ -363,22 +363,26 @@ class SSD(nn.Module):
         legacy = isinstance(images, Tensor) and images.dim() == 4                   # hub call form model(x[1,3,S,S], shapes)
         if legacy:
             images = list(images.unbind(0))
-        for img in images:
+        groups: Dict = {}                                                           # shape -> indices, in order of first appearance
+        for i, img in enumerate(images):
             if img.dim() != 3:
                 raise ValueError("images is expected to be a list of 3d tensors "
                                  "of shape [C, H, W], got {}".format(img.shape))    # transform.py:110-112
             if not img.is_floating_point():
                 raise TypeError(f"Expected input images to be of floating type (in range [0, 1]), "
                                 f"but found type {img.dtype} instead")              # transform.py:130-134
+            g = groups.get(img.shape)
+            if g is None:
+                groups[img.shape] = [i]
+            else:
+                g.append(i)
         out: List[Optional[Dict[str, Tensor]]] = [None] * len(images)
-        groups: Dict = OrderedDict()
-        for i, img in enumerate(images):
-            groups.setdefault(tuple(img.shape), []).append(i)
+        f32 = torch.float32
         for shape, idxs in groups.items():
             device = images[idxs[0]].device
             self._plan(device)
             b = self._buffers_for(len(idxs), shape[1], shape[2], device)
-            torch.stack([images[i].to(torch.float32) for i in idxs], out=b["images"])
+            torch.stack([images[i] if images[i].dtype is f32 else images[i].to(f32) for i in idxs], out=b["images"])
             boxes, scores, labels, counts = self.forward_batch(b["images"], persistent_input=True)
             # the padded outputs live in buffers that the next call overwrites: ONE private copy of each per call, the per-image results
             # are views into it (three copy launches instead of three per image: 0.2 -> 1 ms of launches at 64 images)
