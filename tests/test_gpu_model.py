@@ -135,6 +135,46 @@ def test_postprocess_random_vs_oracle(n, A, K, topk, dets, st, pp_fast):
         np.testing.assert_allclose(np.sort(s[i, :cnt])[::-1], np.sort(d["scores"])[::-1], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("n,A,K,topk,dets,st", [(3, 20000, 2, 400, 100, 0.0), (5, 3234, 91, 300, 300, 0.001)])
+def test_fallback_merge_in_the_selection_launch_equals_the_two_launch_form(n, A, K, topk, dets, st, monkeypatch):
+    """Round 4 (DN_PP_FUSE_FALLBACK, default 1): behind the cut-off pass the flagged images (here: a class with more scores above the cut-off than the
+    fast kernel's list holds; near-uniform scores, where fewer than `dets` boxes survive among the candidates above the cut-off) are redone by the full
+    per-class kernel, and the workgroup that finishes an image's last class -- a device-scope ticket -- merges the image in the same launch. Outputs
+    must equal the two-launch form (full selection, then a merge launch) exactly, and repeat (the ticket is left at zero)."""
+    from demonet_amd import _lib
+    rng = np.random.default_rng(A + K)
+    scale = 2.0 if K == 2 else 0.01        # K = 91: near-uniform softmax -> every image falls back
+    logits = torch.from_numpy(rng.normal(0, scale, (n, A, K)).astype(np.float32)).cuda()
+    reg = torch.from_numpy(rng.normal(0, 1.0, (n, A, 4)).astype(np.float32)).cuda()
+    ctr = rng.uniform(20, 300, (A, 2)).astype(np.float32)
+    wh = rng.uniform(10, 120, (A, 2)).astype(np.float32)
+    anchors = torch.from_numpy(np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)).cuda()
+    res = {}
+    for flag in ("0", "1", "1"):
+        monkeypatch.setenv("DN_PP_FUSE_FALLBACK", flag)
+        res.setdefault(flag, []).append(_postprocess(_lib, logits, reg, anchors, (320, 320), st, 0.5, topk, dets))
+    ref = res["0"][0]
+    for got in res["1"]:
+        for x, y in zip(ref, got):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.parametrize("name,n,size", [("ssd300_vgg16", 70, 300), ("ssd512_vgg16", 9, 512)])
+def test_vgg_head_tiles_of_128_channels_are_bit_identical(name, n, size, monkeypatch):
+    """Round 4 (DN_CONV_HEAD_NARROW, default 1): the dense 3x3 heads of the large levels run on 512 x 128 / 256 x 128 tiles of conv_halo_kernel instead of
+    256 x 256 (380 / 570 channels fill 3 / 5 narrow channel tiles to 99 % / 89 %, two / three wide ones to 74 %). Every output is ONE accumulator
+    walking K in the same order (slice outer, tap inner) whatever the tile: logits and box regressions equal bit for bit."""
+    imgs = torch.from_numpy(synth.images(31, n, size, size)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_CONV_HEAD_NARROW", flag)
+        m = _model(name, num_classes=91)
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+    assert torch.isfinite(res["1"][0]).all()
+    assert torch.equal(res["0"][0], res["1"][0]), (res["0"][0] - res["1"][0]).abs().max().item()
+    assert torch.equal(res["0"][1], res["1"][1]), (res["0"][1] - res["1"][1]).abs().max().item()
+
+
 def test_model_heads_match_golden(golden_dir):
     z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
     m = _model("ssdlite320_mobilenet_v3_large", z)
