@@ -145,7 +145,7 @@ struct PwArgs {
     // producing depthwise launch and the two FC weight sets; every workgroup computes the scale vector of its (at most two) images
     const float* sef_part = nullptr; int sef_nblk = 0, sef_sq = 0; float sef_inv = 0.f;
     const half_t* sef_w1t = nullptr; const half_t* sef_w2t = nullptr; const float* sef_b1 = nullptr; const float* sef_b2 = nullptr;
-    half_t* pool_out = nullptr;      // conv_patch_kernel only: write the 2x2 / stride-2 max-pooled map [n][h/2][w/2][cout] instead of `out`
+    half_t* pool_out = nullptr;      // conv_patch_kernel / conv_halo_kernel<3,4,4>: write the 2x2 / stride-2 max-pooled map [n][h/2][w/2][cout] instead of `out`
     const half_t* x;        // [m][cin]
     const half_t* w;        // [cout][cin]
     const float* bias;      // [cout]
@@ -172,7 +172,8 @@ int launch_conv_big(const PwArgs& a, hipStream_t s);
 // 3x3 "same" conv followed by MaxPool2d(2, 2) in one launch (the 16 x 16 output block of the patch kernel pools to 8 x 8 in its
 // epilogue): true where launch_conv_big would take the patch kernel for this geometry at every batch size
 bool conv_patch_pool_ok(int cin, int cout, int h, int w);
-int launch_conv_patch_pool(const PwArgs& a, hipStream_t s);      // a.pool_out set
+bool conv_pool_ok(int cin, int cout, int h, int w);             // conv 3x3 + MaxPool2d(2, 2) in one launch: the patch kernel or the run-staged 256 x 256 tile
+int launch_conv_pool(const PwArgs& a, hipStream_t s);          // a.pool_out set
 bool conv_head_big_supported(const PwArgs& a);
 int launch_conv_head_big(const PwArgs& a, hipStream_t s);
 struct DwArgs;

@@ -56,6 +56,30 @@ __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[TC][TP], const PwA
         }
     }
     __syncthreads();
+    if (a.pool_out) {
+        // fused MaxPool2d(2, 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the tile is BPt / W whole image rows starting at an even row
+        // (launcher: BPt % 2W == 0, H W % BPt == 0), so every 2 x 2 window lies inside it; the conv output itself never reaches HBM
+        const int W = a.cv_w, Wp = W >> 1, HWp = (a.cv_h >> 1) * Wp;
+        const int img = m0 / a.hw, y0 = (m0 - img * a.hw) / W;
+        half_t* pout = a.pool_out + ((size_t)img * HWp + (size_t)(y0 >> 1) * Wp) * NC + n0;
+        for (int c = tid; c < (BPt / 4) * (BCt / 8); c += 256) {
+            const int pp = c / (BCt / 8), ch = c - pp * (BCt / 8);
+            const int pr = pp / Wp, pc = pp - pr * Wp;
+            const int p00 = 2 * pr * W + 2 * pc;
+            const half8 v0 = *reinterpret_cast<const half8*>(&ot[p00 * ORW + ch * 8]);
+            const half8 v1 = *reinterpret_cast<const half8*>(&ot[(p00 + 1) * ORW + ch * 8]);
+            const half8 v2 = *reinterpret_cast<const half8*>(&ot[(p00 + W) * ORW + ch * 8]);
+            const half8 v3 = *reinterpret_cast<const half8*>(&ot[(p00 + W + 1) * ORW + ch * 8]);
+            half8 mx;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const half_t m01 = v0[e] > v1[e] ? v0[e] : v1[e], m23 = v2[e] > v3[e] ? v2[e] : v3[e];
+                mx[e] = m01 > m23 ? m01 : m23;
+            }
+            *reinterpret_cast<half8*>(pout + (size_t)(pr * Wp + pc) * NC + ch * 8) = mx;
+        }
+        return;
+    }
     half_t* outp = reinterpret_cast<half_t*>(a.out);
 #pragma unroll 4
     for (int c = tid; c < BPt * (BCt / 8); c += 256) {
@@ -837,9 +861,42 @@ bool conv_patch_pool_ok(int cin, int cout, int h, int w) {
     return patch_shape(a) && (cin <= 64 || halo_variant(a) == 0 || halo_variant(a) == 3) && (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= dn_knob("DN_CONV_BIG_MIN", 40);
 }
 
-int launch_conv_patch_pool(const PwArgs& a, hipStream_t s) {
-    DN_REQUIRE(a.pool_out && patch_shape(a) && !(a.cv_h & 1) && !(a.cv_w & 1), "conv + max-pool: geometry not supported by the patch kernel");
-    return launch_patch(a, s);
+// ... or, for the layers of the run-staged 256 x 256 tile (conv3_3 of ssd512: 256 channels on 128 x 128), in the epilogue of conv_halo_kernel<3,4,4>:
+// the tile must be whole row pairs of one image (256 % 2W == 0, H W % 256 == 0)
+static bool conv_halo_pool_geometry(int cin, int cout, int h, int w) {
+    if (!dn_knob("DN_CONV_BIG", 1) || !dn_knob("DN_CONV_POOL", 1) || !dn_knob("DN_CONV_HALO_POOL", 1) || (h & 1) || (w & 1)) return false;
+    static const half_t dummy_zero[8] = {};
+    PwArgs a{};
+    a.cv_k = 3; a.cv_stride = 1; a.cv_pad = 1; a.cv_dil = 1; a.cv_h = a.cv_ho = h; a.cv_w = a.cv_wo = w; a.cv_cin = cin;
+    a.zeros = dummy_zero; a.residual = nullptr; a.se = nullptr; a.out_fp32 = 0;
+    a.hw = h * w; a.m = a.hw; a.cin = 9 * cin; a.cout = cout;
+    return halo_variant(a) == 1 && !(patch_shape(a) && cin <= 64) && 256 % (2 * w) == 0 && (h * w) % 256 == 0 &&
+           (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= dn_knob("DN_CONV_BIG_MIN", 40);
+}
+bool conv_pool_ok(int cin, int cout, int h, int w) { return conv_patch_pool_ok(cin, cout, h, w) || conv_halo_pool_geometry(cin, cout, h, w); }
+
+int launch_conv_pool(const PwArgs& a, hipStream_t s) {
+    DN_REQUIRE(a.pool_out && !(a.cv_h & 1) && !(a.cv_w & 1), "conv + max-pool: needs the pooled output and an even map");
+    if (conv_patch_pool_ok(a.cv_cin, a.cout, a.cv_h, a.cv_w)) {
+        DN_REQUIRE(patch_shape(a), "conv + max-pool: geometry not supported by the patch kernel");
+        return launch_patch(a, s);
+    }
+    DN_REQUIRE(conv_halo_pool_geometry(a.cv_cin, a.cout, a.cv_h, a.cv_w), "conv + max-pool: geometry not supported by the run-staged tile");
+    // the run-staged tile addresses its input with 31-bit byte offsets: a batch beyond that goes in image ranges
+    const int n = a.m / a.hw;
+    const long per_img = (long)a.hw * a.cv_cin * 2;
+    const int step = (int)std::max<long>(1, ((1L << 31) - 1) / per_img);
+    for (int i0 = 0; i0 < n; i0 += step) {
+        PwArgs b = a;
+        const int cnt = std::min(step, n - i0);
+        b.m = cnt * a.hw;
+        b.x = a.x + (size_t)i0 * a.hw * a.cv_cin;
+        b.pool_out = a.pool_out + (size_t)i0 * (a.hw / 4) * a.cout;
+        DN_REQUIRE(halo_variant(b) == 1, "conv + max-pool: the run-staged 256 x 256 tile does not take %d x %d x %d", a.cv_h, a.cv_w, a.cv_cin);
+        const int rc = launch_halo<4, 4, false>(b, s, "conv_halo_kernel<3,4,4>");
+        if (rc != DN_OK) return rc;
+    }
+    return DN_OK;
 }
 
 // Tile of a dense fp32 head launch: 0 none, 1 = 256 px x 256 ch, 2 = 512 x 128, 3 = 256 x 128. The class + box channels of a level (380 / 570

@@ -392,7 +392,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             const dn_tensor_desc& tc = p->tensors[c.out];
             if (c.type == DN_OP_CONV && !c.head && c.k == 3 && c.stride == 1 && c.pad == 1 && c.dil == 1 && m.type == DN_OP_MAXPOOL && m.in == c.out &&
                 uses[c.out] == 1 && m.k == 2 && m.stride == 2 && m.pad == 0 && p->fused_len[i] == 0 && p->tensors[c.in].h == tc.h &&
-                conv_patch_pool_ok(c.cin, c.cout, tc.h, tc.w)) {
+                conv_pool_ok(c.cin, c.cout, tc.h, tc.w)) {
                 p->fused_len[i] = 2;
                 p->fused_kind[i] = 4;
                 ++i;
@@ -1005,7 +1005,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             PwArgs pa = conv_to_pw(make_conv(o));
             pa.out = nullptr;
             pa.pool_out = reinterpret_cast<half_t*>(tptr(p->ops[i + 1].out));
-            rc = launch_conv_patch_pool(pa, s);
+            rc = launch_conv_pool(pa, s);
             if (rc != DN_OK) return rc;
             note(i, i); note(i + 1, i);
             if (record) (void)hipEventRecord(p->events[ev++], s);

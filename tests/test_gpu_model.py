@@ -175,6 +175,26 @@ def test_vgg_head_tiles_of_128_channels_are_bit_identical(name, n, size, monkeyp
     assert torch.equal(res["0"][1], res["1"][1]), (res["0"][1] - res["1"][1]).abs().max().item()
 
 
+@pytest.mark.parametrize("name,n,size", [("ssd512_vgg16", 3, 512), ("ssd300_vgg16", 5, 300)])
+def test_max_pool_in_the_conv_epilogue_is_bit_identical(name, n, size, monkeypatch):
+    """DN_CONV_POOL (default 1): a 3x3 conv followed by MaxPool2d(2, 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features) is one launch -- the
+    16 x 16 block of conv_patch_kernel (conv1_2, conv2_2) or, since round 4, the row-pair tile of conv_halo_kernel<3,4,4> (conv3_3 of ssd512,
+    DN_CONV_HALO_POOL) pools in its epilogue and the full-resolution conv output never reaches memory. A maximum is exact: the head outputs must
+    equal the unfused form bit for bit."""
+    imgs = torch.from_numpy(synth.images(47, n, size, size)).cuda()
+    res = {}
+    for key, env in (("unfused", {"DN_CONV_POOL": "0"}), ("patch only", {"DN_CONV_HALO_POOL": "0"}), ("all", {})):
+        for k in ("DN_CONV_POOL", "DN_CONV_HALO_POOL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = _model(name, num_classes=91)
+        res[key] = [t.clone() for t in m.forward_heads(imgs)]
+    for key in ("patch only", "all"):
+        assert torch.equal(res["unfused"][0], res[key][0]), (key, (res["unfused"][0] - res[key][0]).abs().max().item())
+        assert torch.equal(res["unfused"][1], res[key][1]), key
+
+
 def test_model_heads_match_golden(golden_dir):
     z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
     m = _model("ssdlite320_mobilenet_v3_large", z)
