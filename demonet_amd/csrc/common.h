@@ -173,6 +173,7 @@ int launch_conv_big(const PwArgs& a, hipStream_t s);
 // epilogue): true where launch_conv_big would take the patch kernel for this geometry at every batch size
 bool conv_patch_pool_ok(int cin, int cout, int h, int w);
 bool conv_pool_ok(int cin, int cout, int h, int w);             // conv 3x3 + MaxPool2d(2, 2) in one launch: the patch kernel or the run-staged 256 x 256 tile
+bool conv_halo_pool_ok(int cin, int cout, int h, int w);        // ... the run-staged tile's form: may also write the conv output itself (a.out set)
 int launch_conv_pool(const PwArgs& a, hipStream_t s);          // a.pool_out set
 bool conv_head_big_supported(const PwArgs& a);
 int launch_conv_head_big(const PwArgs& a, hipStream_t s);

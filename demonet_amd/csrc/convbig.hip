@@ -78,7 +78,7 @@ __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[TC][TP], const PwA
             }
             *reinterpret_cast<half8*>(pout + (size_t)(pr * Wp + pc) * NC + ch * 8) = mx;
         }
-        return;
+        if (!a.out) return;         // (a conv output with other readers -- conv4_3 feeds the L2-norm level -- is written as well)
     }
     half_t* outp = reinterpret_cast<half_t*>(a.out);
 #pragma unroll 4
@@ -863,7 +863,7 @@ bool conv_patch_pool_ok(int cin, int cout, int h, int w) {
 
 // ... or, for the layers of the run-staged 256 x 256 tile (conv3_3 of ssd512: 256 channels on 128 x 128), in the epilogue of conv_halo_kernel<3,4,4>:
 // the tile must be whole row pairs of one image (256 % 2W == 0, H W % 256 == 0)
-static bool conv_halo_pool_geometry(int cin, int cout, int h, int w) {
+bool conv_halo_pool_ok(int cin, int cout, int h, int w) {
     if (!dn_knob("DN_CONV_BIG", 1) || !dn_knob("DN_CONV_POOL", 1) || !dn_knob("DN_CONV_HALO_POOL", 1) || (h & 1) || (w & 1)) return false;
     static const half_t dummy_zero[8] = {};
     PwArgs a{};
@@ -873,7 +873,7 @@ static bool conv_halo_pool_geometry(int cin, int cout, int h, int w) {
     return halo_variant(a) == 1 && !(patch_shape(a) && cin <= 64) && 256 % (2 * w) == 0 && (h * w) % 256 == 0 &&
            (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= dn_knob("DN_CONV_BIG_MIN", 40);
 }
-bool conv_pool_ok(int cin, int cout, int h, int w) { return conv_patch_pool_ok(cin, cout, h, w) || conv_halo_pool_geometry(cin, cout, h, w); }
+bool conv_pool_ok(int cin, int cout, int h, int w) { return conv_patch_pool_ok(cin, cout, h, w) || conv_halo_pool_ok(cin, cout, h, w); }
 
 int launch_conv_pool(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.pool_out && !(a.cv_h & 1) && !(a.cv_w & 1), "conv + max-pool: needs the pooled output and an even map");
@@ -881,7 +881,7 @@ int launch_conv_pool(const PwArgs& a, hipStream_t s) {
         DN_REQUIRE(patch_shape(a), "conv + max-pool: geometry not supported by the patch kernel");
         return launch_patch(a, s);
     }
-    DN_REQUIRE(conv_halo_pool_geometry(a.cv_cin, a.cout, a.cv_h, a.cv_w), "conv + max-pool: geometry not supported by the run-staged tile");
+    DN_REQUIRE(conv_halo_pool_ok(a.cv_cin, a.cout, a.cv_h, a.cv_w), "conv + max-pool: geometry not supported by the run-staged tile");
     // the run-staged tile addresses its input with 31-bit byte offsets: a batch beyond that goes in image ranges
     const int n = a.m / a.hw;
     const long per_img = (long)a.hw * a.cv_cin * 2;
@@ -892,6 +892,7 @@ int launch_conv_pool(const PwArgs& a, hipStream_t s) {
         b.m = cnt * a.hw;
         b.x = a.x + (size_t)i0 * a.hw * a.cv_cin;
         b.pool_out = a.pool_out + (size_t)i0 * (a.hw / 4) * a.cout;
+        if (a.out) b.out = reinterpret_cast<half_t*>(a.out) + (size_t)i0 * a.hw * a.cout;
         DN_REQUIRE(halo_variant(b) == 1, "conv + max-pool: the run-staged 256 x 256 tile does not take %d x %d x %d", a.cv_h, a.cv_w, a.cv_cin);
         const int rc = launch_halo<4, 4, false>(b, s, "conv_halo_kernel<3,4,4>");
         if (rc != DN_OK) return rc;

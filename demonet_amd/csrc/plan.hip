@@ -391,8 +391,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             const dn_op_desc& m = p->ops[i + 1];
             const dn_tensor_desc& tc = p->tensors[c.out];
             if (c.type == DN_OP_CONV && !c.head && c.k == 3 && c.stride == 1 && c.pad == 1 && c.dil == 1 && m.type == DN_OP_MAXPOOL && m.in == c.out &&
-                uses[c.out] == 1 && m.k == 2 && m.stride == 2 && m.pad == 0 && p->fused_len[i] == 0 && p->tensors[c.in].h == tc.h &&
-                conv_pool_ok(c.cin, c.cout, tc.h, tc.w)) {
+                m.k == 2 && m.stride == 2 && m.pad == 0 && p->fused_len[i] == 0 && p->tensors[c.in].h == tc.h &&
+                ((uses[c.out] == 1 && conv_pool_ok(c.cin, c.cout, tc.h, tc.w)) ||
+                 (!conv_patch_pool_ok(c.cin, c.cout, tc.h, tc.w) && conv_halo_pool_ok(c.cin, c.cout, tc.h, tc.w)))) {      // (the run-staged tile can write both maps)
                 p->fused_len[i] = 2;
                 p->fused_kind[i] = 4;
                 ++i;
@@ -1003,7 +1004,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         }
         if (p->fused_len[i] > 0 && p->fused_kind[i] == 4) {
             PwArgs pa = conv_to_pw(make_conv(o));
-            pa.out = nullptr;
+            if (L.toff[o.out] == (size_t)-1) pa.out = nullptr;      // (materialised only when something else reads the full-resolution map)
             pa.pool_out = reinterpret_cast<half_t*>(tptr(p->ops[i + 1].out));
             rc = launch_conv_pool(pa, s);
             if (rc != DN_OK) return rc;
