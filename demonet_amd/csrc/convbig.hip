@@ -56,7 +56,7 @@ __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[TC][TP], const PwA
         }
     }
     __syncthreads();
-    if (a.pool_out) {
+    if constexpr (TP == 4 && TC == 4) if (a.pool_out) {        // (compiled into the 256 x 256 tile only: in the 512 x 128 one it spilled the main loop)
         // fused MaxPool2d(2, 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the tile is BPt / W whole image rows starting at an even row
         // (launcher: BPt % 2W == 0, H W % BPt == 0), so every 2 x 2 window lies inside it; the conv output itself never reaches HBM
         const int W = a.cv_w, Wp = W >> 1, HWp = (a.cv_h >> 1) * Wp;
