@@ -863,8 +863,8 @@ bool conv_patch_pool_ok(int cin, int cout, int h, int w) {
 
 // ... or, for the layers of the run-staged 256 x 256 tile (conv3_3 of ssd512: 256 channels on 128 x 128), in the epilogue of conv_halo_kernel<3,4,4>:
 // the tile must be whole row pairs of one image (256 % 2W == 0, H W % 256 == 0)
-bool conv_halo_pool_ok(int cin, int cout, int h, int w) {
-    if (!dn_knob("DN_CONV_BIG", 1) || !dn_knob("DN_CONV_POOL", 1) || !dn_knob("DN_CONV_HALO_POOL", 1) || (h & 1) || (w & 1)) return false;
+static bool conv_halo_pool_geometry(int cin, int cout, int h, int w) {
+    if ((h & 1) || (w & 1)) return false;
     static const half_t dummy_zero[8] = {};
     PwArgs a{};
     a.cv_k = 3; a.cv_stride = 1; a.cv_pad = 1; a.cv_dil = 1; a.cv_h = a.cv_ho = h; a.cv_w = a.cv_wo = w; a.cv_cin = cin;
@@ -873,15 +873,16 @@ bool conv_halo_pool_ok(int cin, int cout, int h, int w) {
     return halo_variant(a) == 1 && !(patch_shape(a) && cin <= 64) && 256 % (2 * w) == 0 && (h * w) % 256 == 0 &&
            (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= dn_knob("DN_CONV_BIG_MIN", 40);
 }
+// (the knobs decide at plan creation; the launch only checks the geometry, so a knob flipped between dn_create and dn_forward cannot strand a fused pair)
+bool conv_halo_pool_ok(int cin, int cout, int h, int w) {
+    return dn_knob("DN_CONV_BIG", 1) && dn_knob("DN_CONV_POOL", 1) && dn_knob("DN_CONV_HALO_POOL", 1) && conv_halo_pool_geometry(cin, cout, h, w);
+}
 bool conv_pool_ok(int cin, int cout, int h, int w) { return conv_patch_pool_ok(cin, cout, h, w) || conv_halo_pool_ok(cin, cout, h, w); }
 
 int launch_conv_pool(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.pool_out && !(a.cv_h & 1) && !(a.cv_w & 1), "conv + max-pool: needs the pooled output and an even map");
-    if (conv_patch_pool_ok(a.cv_cin, a.cout, a.cv_h, a.cv_w)) {
-        DN_REQUIRE(patch_shape(a), "conv + max-pool: geometry not supported by the patch kernel");
-        return launch_patch(a, s);
-    }
-    DN_REQUIRE(conv_halo_pool_ok(a.cv_cin, a.cout, a.cv_h, a.cv_w), "conv + max-pool: geometry not supported by the run-staged tile");
+    if (!a.out && patch_shape(a) && (a.cv_cin <= 64 || !conv_halo_pool_geometry(a.cv_cin, a.cout, a.cv_h, a.cv_w))) return launch_patch(a, s);
+    DN_REQUIRE(conv_halo_pool_geometry(a.cv_cin, a.cout, a.cv_h, a.cv_w), "conv + max-pool: geometry not supported by the patch kernel or the run-staged tile");
     // the run-staged tile addresses its input with 31-bit byte offsets: a batch beyond that goes in image ranges
     const int n = a.m / a.hw;
     const long per_img = (long)a.hw * a.cv_cin * 2;
