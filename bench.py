@@ -1,7 +1,9 @@
 """Headline benchmark: images/sec of the SSD inference hot path (incl. NMS) on MI355X.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N ...          (N > 1, no launcher: starts N ranks itself, one per GPU, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(--gpus must equal the number of ranks the launcher started: a mismatch, or fewer devices than N, is an error, never a smaller run.)
 
 A step = one pass of the whole hot path (stem .. heads .. softmax/decode/top-k/NMS/merge) over one device-resident
 batch of synthetic 320x320 images (BASELINE.json configs[1]: ssdlite320_mobilenet_v3_large fp16, batch 64 per GPU).
@@ -221,6 +223,39 @@ class _StubPipe:
         pass
 
 
+def _launch_ranks(n, argv, stub):
+    """`python bench.py --gpus N` (N > 1) with no launcher environment: start N fresh rank processes -- one per GPU, the reference's launch
+    form (README.md:63 `python -m torch.distributed.launch --nproc_per_node=N`, util/misc.py:302-324 reads RANK / WORLD_SIZE / LOCAL_RANK) --
+    as `python -m torch.distributed.run --nproc-per-node N bench.py ...`, relay rank 0's JSON line as the LAST line of stdout and return the
+    children's status. The parent never initialises the GPU (torch.cuda.device_count() does not on this image) and never exec()s."""
+    import socket
+    import subprocess
+    if not stub:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.exit(f"bench.py: --gpus {n} but this node shows {have} GPU(s): refusing to print a {have}-GPU number as an {n}-GPU line")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        sys.exit(f"bench.py: the {n}-rank launch failed (status {p.returncode}, {'no' if line is None else 'a'} result line)")
+    print(line, flush=True)
+    return json.loads(line)
+
+
 def _on(stream):
     import contextlib
     return contextlib.nullcontext() if stream is None else torch.cuda.stream(stream)
@@ -253,6 +288,17 @@ def main(argv=None):
     args = ap.parse_args(argv)
     stub = args.stub_cpu
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: THIS process becomes the launcher (it has not touched the GPU and never will)
+            return _launch_ranks(args.gpus, list(sys.argv[1:] if argv is None else argv), stub)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # one rank per GPU (util/misc.py:302-324, README.md:63): a launcher that started a different number of ranks than --gpus names
+        # would produce a line whose n_gpus contradicts the command
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch exactly one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..., or plain `python bench.py --gpus {args.gpus}`)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -389,7 +435,7 @@ def main(argv=None):
         for r in range(world):
             want = _StubPipe.payload(B, D, r * B if scaling == "weak" else shard_lo[r], total_steps - 1)
             ok = ok and torch.equal(pk[r * per:(r + 1) * per], want[:, :D]) and torch.equal(cn[r * per:(r + 1) * per], want[:, D, 0].int())
-        result = {"metric": "stub", "value": round(value, 1), "n_gpus": world, "steps": args.steps, "ms_per_step": round(ms_per_step, 4), "scaling": scaling,
+        result = {"metric": "stub", "value": round(value, 1), "n_gpus": world, "rccl_ranks_seen": dist.get_world_size(), "steps": args.steps, "ms_per_step": round(ms_per_step, 4), "scaling": scaling,
                   "global_batch": B * world, "per_rank_batch": B, "shard": [lo, lo + B], "gather_windows": gatherer.gathered // gatherer.K,
                   "joins": pipe.joins, "stub_check": bool(ok)}
         dist.destroy_process_group()
@@ -410,6 +456,7 @@ def main(argv=None):
         "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "ms_per_img": round(ms_per_step / B, 5),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "rccl_ranks_seen": dist.get_world_size() if distributed else 1,        # what the communicator itself reports after init (1: no communicator)
         "dtype": "fp16", "data": "synthetic",
         "config": {"workload": (f"{args.model} fp16, global batch {B * world} image-sharded over {world} GPUs ({B} per GPU), " if scaling == "strong"
                                 else f"{args.model} fp16, batch {B} per GPU, ") + f"{H}x{W} synthetic images, K={ncls}, "

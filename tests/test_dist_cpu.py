@@ -129,3 +129,37 @@ def test_bench_main_c4_path_runs_at_world2_on_cpu():
             assert d["shard"] == [r * per, (r + 1) * per] and d["global_batch"] == 2 * per
             assert d["gather_windows"] == 3 and d["joins"] == 3          # 6 warm-up + 37 timed steps = two full windows of 16 + the flushed one
         assert ret[0]["ms_per_step"] == ret[1]["ms_per_step"]            # MAX over ranks
+
+
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2 --stub-cpu` with NO launcher environment: the process starts two ranks itself (torch.distributed.run,
+    one per GPU as README.md:63 / util/misc.py:302-324 do) and relays rank 0's line: n_gpus and the communicator's own world size are 2."""
+    import json
+    p = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "3", "--stub-cpu"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout.strip().splitlines()[-1]
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["stub_check"] and d["per_rank_batch"] == 128 and d["scaling"] == "strong"
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    p = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--stub-cpu"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_bench_gpus_n_fails_loudly_without_n_devices():
+    """--gpus 8 on a box with fewer GPUs (none here) must not print a 1-GPU number: non-zero status, no result line."""
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("this box has 8 GPUs")
+    p = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert p.returncode != 0 and '{"metric"' not in p.stdout and "refusing" in p.stderr
