@@ -66,7 +66,8 @@ def op_costs(graph, n):
             ob = 4 if nd.head else 2
             bi = 2 * m * (nd.cin if nd.op == "pw" else nd.cin * (ti.h * ti.w) / (to.h * to.w))
             bo = ob * m * nd.cout
-            bw = 2 * kk * nd.cout + 4 * nd.cout + (2 * m * nd.cout if nd.residual >= 0 else 0)
+            br = 2 * m * nd.cout if nd.residual >= 0 else 0         # the residual operand: read from HBM when it is not already an input of the launch
+            bw = 2 * kk * nd.cout + 4 * nd.cout + br
             b = bi + bo + bw
             f = 2 * m * kk * nd.cout
             kern = "pw_kernel"
@@ -91,7 +92,7 @@ def op_costs(graph, n):
             kern = "l2norm_kernel"
         c = dict(kernel=kern, bytes=float(b), flops=float(f))
         if nd.op in ("pw", "dw"):
-            c.update(b_in=float(bi), b_out=float(bo), b_w=float(bw))
+            c.update(b_in=float(bi), b_out=float(bo), b_w=float(bw), b_res=float(br) if nd.op == "pw" else 0.0)
         out.append(c)
     A, K = graph.num_anchors(), graph.num_classes
     topk, D = graph.post["topk_candidates"], graph.post["detections_per_img"]
@@ -103,6 +104,21 @@ def op_costs(graph, n):
     out.append(dict(kernel="select_nms_kernel", bytes=float(n * (K - 1) * (4 * A + 24 * topk)), flops=float(25 * n * (K - 1) * topk * topk / 2)))
     out.append(dict(kernel="merge_kernel", bytes=float(n * ((K - 1) * topk * 8 + D * 40)), flops=0.0))
     return out
+
+
+def fused_external_bytes(g, costs, mem, head):
+    """External (HBM) algorithmic bytes of ONE fused launch covering ops `mem` ("a fused kernel is credited with the external
+    bytes of the fused group")."""
+    if head:
+        # every level's two depthwise ops read the SAME feature map (once), their outputs never exist; the two 1x1 heads write the fp32 rows
+        return (sum(costs[i]["b_in"] for i in mem if g.nodes[i].op == "dw") / 2 + sum(costs[i]["b_out"] for i in mem if g.nodes[i].op == "pw") +
+                sum(costs[i]["b_w"] for i in mem))
+    # the block's input once, its output once, every member's weights -- and a residual only when it is NOT the block's own input (an
+    # inverted-residual block adds its input: those rows are already counted in first["b_in"]; round 4 counted them twice and
+    # over-credited the fused-block family by 21 %)
+    first, last = costs[mem[0]], costs[mem[-1]]
+    own_in = g.nodes[mem[0]].inp
+    return first["b_in"] + last["b_out"] + sum(costs[i]["b_w"] - (costs[i]["b_res"] if g.nodes[i].residual == own_in else 0.0) for i in mem)
 
 
 def cpu_baseline(name, graph, seed, budget_s=24.0):
@@ -557,13 +573,7 @@ def main(argv=None):
             if c["kernel"].startswith(("expdw_kernel", "expdw_one_kernel", "pw_dw_direct_kernel", "head_fused_kernel")):
                 fused.setdefault(c["owner"], []).append(i)
         for mem in fused.values():
-            if costs[mem[0]]["kernel"].startswith("head_fused_kernel"):
-                # every level's two depthwise ops read the SAME feature map (once), their outputs never exist; the two 1x1 heads write the fp32 rows
-                ext = (sum(costs[i]["b_in"] for i in mem if g.nodes[i].op == "dw") / 2 + sum(costs[i]["b_out"] for i in mem if g.nodes[i].op == "pw") +
-                       sum(costs[i]["b_w"] for i in mem))
-            else:
-                first, last = costs[mem[0]], costs[mem[-1]]
-                ext = first["b_in"] + last["b_out"] + sum(costs[i]["b_w"] for i in mem)
+            ext = fused_external_bytes(g, costs, mem, costs[mem[0]]["kernel"].startswith("head_fused_kernel"))
             for i in mem:
                 costs[i]["bytes"] = ext / len(mem)
         owners = {}

@@ -31,10 +31,11 @@ def _stale(target, deps):
 
 
 def build_stamps(verbose=True):
-    """Dev build: lib/libdemonet_hip_stamps.so = the same objects with headfuse.hip and expdw.hip compiled with -DDN_DEV_STAMPS (per-workgroup phase
-    stamps, tools/probe_headfuse.py, tools/probe_expdw_block.py). Load it with DEMONET_HIP_LIB=<path>; the product library never carries the stamps."""
+    """Dev build: lib/libdemonet_hip_stamps.so = the same objects with every kernel file that has probe hooks compiled with -DDN_DEV_STAMPS
+    (per-workgroup phase stamps and the dn_debug_*_stamps / dn_debug_pw_tile exports: tools/probe_*.py, tools/tune_pw.py). Load it with
+    DEMONET_HIP_LIB=<path>; the product library carries neither the stamps nor those exports."""
     build(verbose=verbose)
-    stamped = ["headfuse.hip", "expdw.hip"]
+    stamped = ["headfuse.hip", "expdw.hip", "pointwise.hip", "depthwise.hip", "postprocess.hip", "tail.hip"]
     objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s not in stamped]
     for src in stamped:
         obj = os.path.join(LIBDIR, src.replace(".hip", "_stamps.o"))
@@ -50,7 +51,8 @@ def build_stamps(verbose=True):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "demonet_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "demonet_hip.h"),
+               os.path.join(os.path.dirname(HERE), "include", "demonet_hip_debug.h")]
     objs = []
     procs = []
     for src in SOURCES:

@@ -881,7 +881,9 @@ bool conv_pool_ok(int cin, int cout, int h, int w) { return conv_patch_pool_ok(c
 
 int launch_conv_pool(const PwArgs& a, hipStream_t s) {
     DN_REQUIRE(a.pool_out && !(a.cv_h & 1) && !(a.cv_w & 1), "conv + max-pool: needs the pooled output and an even map");
-    if (!a.out && patch_shape(a) && (a.cv_cin <= 64 || !conv_halo_pool_geometry(a.cv_cin, a.cout, a.cv_h, a.cv_w))) return launch_patch(a, s);
+    // by geometry alone: the patch kernel never writes the full-resolution map (a pair whose map has other readers is only fused when the run-staged
+    // tile takes it: plan.hip), so a.out -- non-null for EVERY tensor with DN_WS_REUSE=0 -- must not steer the choice
+    if (patch_shape(a) && (a.cv_cin <= 64 || !conv_halo_pool_geometry(a.cv_cin, a.cout, a.cv_h, a.cv_w))) return launch_patch(a, s);
     DN_REQUIRE(conv_halo_pool_geometry(a.cv_cin, a.cout, a.cv_h, a.cv_w), "conv + max-pool: geometry not supported by the patch kernel or the run-staged tile");
     // the run-staged tile addresses its input with 31-bit byte offsets: a batch beyond that goes in image ranges
     const int n = a.m / a.hw;

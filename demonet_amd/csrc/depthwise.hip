@@ -9,8 +9,12 @@
 
 #include "common.h"
 
-static long long* g_se_stamps = nullptr;     // dev hook (tools/probe_se.py)
+#ifdef DN_DEV_STAMPS
+static long long* g_se_stamps = nullptr;     // dev build only (tools/probe_se.py)
 extern "C" __attribute__((visibility("default"))) void dn_debug_se_stamps(void* dev_ptr) { g_se_stamps = (long long*)dev_ptr; }
+#else
+constexpr long long* g_se_stamps = nullptr;
+#endif
 
 namespace {
 
@@ -439,7 +443,11 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ p
                                                    const float* __restrict__ b1, const unsigned* __restrict__ w2t,
                                                    const float* __restrict__ b2, float* __restrict__ scale,
                                                    int c, int sq, float inv_pixels, long long* __restrict__ stamps, int nimg, int xq) {
+#ifdef DN_DEV_STAMPS
 #define SE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SE_STAMP(k) do { } while (0)
+#endif
     // w1t: fc1 weight transposed [c][sq] fp16, read as [c][sq/2] half pairs; w2t: fc2 weight transposed [sq][c] fp16 as
     // [sq][c/2] pairs. A thread owns TWO adjacent outputs (one 4-byte load per weight row) and a K-slice.
     extern __shared__ float sh[];      // mean[c], z[sq], part[2][1024]

@@ -20,15 +20,17 @@
 
 #include "common.h"
 
-static long long* g_xd_stamps = nullptr;     // dev hook (tools/probe_expdw.py): per-workgroup phase stamps
+#ifdef DN_DEV_STAMPS
+static long long* g_xd_stamps = nullptr;     // dev build only (tools/probe_expdw.py): per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_expdw_stamps(void* dev_ptr) { g_xd_stamps = (long long*)dev_ptr; }
 #define XD_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-#ifdef DN_DEV_STAMPS
 // dev build only (python -m demonet_amd.build --stamps): finer stamps inside the SECOND chunk of the run (the steady state), slots 5.. A stamp is a
 // global store: a phase that contains an `s_waitcnt vmcnt(0)` also waits for the previous stamp's acknowledgement -- read the LDS-only phases
 // (depthwise) at face value and the others as upper bounds.
 #define XD_STAMP2(k) do { if (a.stamps && threadIdx.x == 0 && c0 == c_begin + 64) a.stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+constexpr long long* g_xd_stamps = nullptr;
+#define XD_STAMP(k) do { } while (0)
 #define XD_STAMP2(k) do { } while (0)
 #endif
 

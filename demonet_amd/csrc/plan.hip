@@ -895,10 +895,14 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                             rider = (int)u;
                     }
                     if (rider >= 0) {
+                        // the tile is chosen from cout + cout_b: the rider joins only if the launch still has a tile WITH it (21 classes x 6 anchors =
+                        // 126 + 24 channels cross a 128-channel tile boundary and fail the narrow-tile test the class head passed alone)
                         const PwArgs pb = conv_to_pw(make_conv(p->ops[lst[rider]]));
-                        pa.w_b = pb.w; pa.bias_b = pb.bias; pa.out_b = pb.out; pa.cout_b = pb.cout;
-                        pa.out_b_img_stride = pb.out_img_stride; pa.out_b_base = pb.out_base;
-                        taken.insert(lst[rider]);
+                        PwArgs with = pa;
+                        with.w_b = pb.w; with.bias_b = pb.bias; with.out_b = pb.out; with.cout_b = pb.cout;
+                        with.out_b_img_stride = pb.out_img_stride; with.out_b_base = pb.out_base;
+                        if (conv_head_big_supported(with)) { pa = with; taken.insert(lst[rider]); }
+                        else rider = -1;
                     }
                     rc = launch_conv_head_big(pa, hs);
                     if (rc != DN_OK) return rc;

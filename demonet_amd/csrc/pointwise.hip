@@ -15,11 +15,18 @@
 
 #include "common.h"
 
-static int g_pw_tile = 0;                   // dev hook (tools/tune_pw.py): force a tile variant for every launch
+// dev hooks: exported and compiled into the kernels only by the dev build (python -m demonet_amd.build --stamps, -DDN_DEV_STAMPS)
+#ifdef DN_DEV_STAMPS
+static int g_pw_tile = 0;                   // tools/tune_pw.py: force a tile variant for every launch
 extern "C" __attribute__((visibility("default"))) void dn_debug_pw_tile(int t) { g_pw_tile = t; }
-static long long* g_pw_stamps = nullptr;     // dev hook (tools/probe_pw_stamps.py): per-workgroup phase stamps
+static long long* g_pw_stamps = nullptr;     // tools/probe_pw_stamps.py: per-workgroup phase stamps
 extern "C" __attribute__((visibility("default"))) void dn_debug_pw_stamps(void* dev_ptr) { g_pw_stamps = (long long*)dev_ptr; }
 #define PW_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+constexpr int g_pw_tile = 0;
+constexpr long long* g_pw_stamps = nullptr;
+#define PW_STAMP(k) do { } while (0)
+#endif
 
 // row tiles of BP pixels: per XCD group of a.xq images when the grouping is on, else of the whole problem
 static inline int pw_row_tiles(const PwArgs& a, int BP) { return a.xq > 0 ? dn_cdiv((long)a.xq * a.hw, BP) : dn_cdiv(a.m, BP); }

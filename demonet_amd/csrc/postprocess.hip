@@ -22,12 +22,20 @@
 #include <algorithm>
 #include "common.h"
 
-static long long* g_pp_stamps = nullptr;     // dev hook: per-workgroup phase stamps of select_nms (dn_debug_pp_stamps)
+#ifdef DN_DEV_STAMPS
+static long long* g_pp_stamps = nullptr;     // dev build only: per-workgroup phase stamps of select_nms (tools/probe_pp_stamps.py)
 extern "C" __attribute__((visibility("default"))) void dn_debug_pp_stamps(void* dev_ptr) { g_pp_stamps = (long long*)dev_ptr; }
+#else
+constexpr long long* g_pp_stamps = nullptr;
+#endif
 
 namespace {
 
+#ifdef DN_DEV_STAMPS
 #define PP_STAMP(k) do { if (stamps && tid == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
 
 constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
 constexpr int HSHIFT = DN_PP_HSHIFT;                     // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
@@ -571,6 +579,7 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
                 // path is rare, so the device-scope fences -- an L2 write-back / invalidate each on this chip -- are affordable here). The counter is
                 // zeroed by tau_kernel in every forward and left at zero.
                 __threadfence();
+                __syncthreads();                // write, fence, BARRIER, ticket: every wave's release has completed before thread 0 publishes the arrival
                 if (threadIdx.x == 0) s_lastm = atomicAdd(&fbcnt[n1], 1) == Km1 - 1;
                 __syncthreads();
                 if (s_lastm) {

@@ -14,9 +14,14 @@
 // launch-per-layer path.
 #include "common.h"
 
-static long long* g_tail_stamps = nullptr;     // dev hook (tools/probe_tail.py): per-workgroup stamps [n][32]
+#ifdef DN_DEV_STAMPS
+static long long* g_tail_stamps = nullptr;     // dev build only (tools/probe_tail.py): per-workgroup stamps [n][32]
 extern "C" __attribute__((visibility("default"))) void dn_debug_tail_stamps(void* dev_ptr) { g_tail_stamps = (long long*)dev_ptr; }
 #define TL_STAMP(k) do { if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 32 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+constexpr long long* g_tail_stamps = nullptr;
+#define TL_STAMP(k) do { } while (0)
+#endif
 
 namespace {
 

@@ -101,10 +101,12 @@ class ForwardPipeline:
             raise RuntimeError("the pipeline is closed")
         if self.model._handle != self._handle or self.model._plan_gen != self._gen:
             raise RuntimeError("the model's plan was rebuilt (weights changed / invalidate()): build a new ForwardPipeline")
-        if not self.model._weights_unchanged(self.device) and (self.model._weights_signature(), str(self.device)) != self.model._sig:
+        if not self.model._weights_unchanged(self.device):
             # in-place weight updates do not rebuild the plan by themselves (only the model's own forward does): checked on EVERY submit
             # (the flat-list test of SSD._weights_unchanged, tens of microseconds), so a pipeline never replays stale folded weights
-            raise RuntimeError("the model's weights changed since the plan was lowered: close this pipeline and build a new one")
+            if (self.model._weights_signature(), str(self.device)) != self.model._sig:
+                raise RuntimeError("the model's weights changed since the plan was lowered: close this pipeline and build a new one")
+            self.model._remember_weights(self.device)      # only the structure epoch moved (another model was built): back to the cheap test
         s = self.slots[self.n % self.depth]
         if tuple(images.shape) != tuple(s.images.shape):
             raise ValueError("expected a batch of shape {}, got {}".format(tuple(s.images.shape), tuple(images.shape)))

@@ -19,25 +19,45 @@ from .plan import LoweredModel
 from .spec import Graph
 
 
-class _Node(nn.Module):
-    """Container that only exists to reproduce the reference's dotted parameter names."""
-
-
-# Structure epoch: bumped whenever ANY module registers a parameter, a buffer or a sub-module (torch's global registration hooks), i.e.
-# whenever the set of tensor OBJECTS behind a model can have changed (swapped Parameters, load_state_dict(assign=True), add_module ...).
-# SSD caches its tensor list per epoch, so the per-forward "did the weights change" test walks a flat list (data_ptr + _version of ~480
-# tensors: tens of microseconds) instead of the module tree (~0.4 ms per call -- a third of a synchronous 64-image forward).
+# Structure epoch: bumped whenever a module OF THIS PACKAGE (an SSD or one of its name containers) registers a parameter, a buffer or a
+# sub-module, i.e. whenever the set of tensor OBJECTS behind a model can have changed (swapped Parameters, load_state_dict(assign=True),
+# add_module ...). SSD caches its tensor list per epoch, so the per-forward "did the weights change" test walks a flat list (data_ptr +
+# _version of ~480 tensors: tens of microseconds) instead of the module tree (~0.4 ms per call -- a third of a synchronous 64-image
+# forward). The hooks live on these two classes only: unrelated modules in the process neither pay for them nor invalidate the cache.
 _STRUCT_EPOCH = [0]
 
 
-def _bump_epoch(*_args):
-    _STRUCT_EPOCH[0] += 1
-    return None
+class _Tracked(nn.Module):
+    def register_parameter(self, name, param):
+        _STRUCT_EPOCH[0] += 1
+        return super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        _STRUCT_EPOCH[0] += 1
+        return super().register_buffer(name, tensor, persistent)
+
+    def add_module(self, name, module):
+        _STRUCT_EPOCH[0] += 1
+        return super().add_module(name, module)
+
+    def register_module(self, name, module):
+        _STRUCT_EPOCH[0] += 1
+        return super().register_module(name, module)
+
+    def __setattr__(self, name, value):
+        # nn.Module.__setattr__ stores sub-modules and re-assigned buffers without going through the register_* methods
+        if isinstance(value, (Tensor, nn.Module)) or name in self.__dict__.get("_parameters", ()) or name in self.__dict__.get("_buffers", ()) \
+                or name in self.__dict__.get("_modules", ()):
+            _STRUCT_EPOCH[0] += 1
+        return super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _STRUCT_EPOCH[0] += 1
+        return super().__delattr__(name)
 
 
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
-torch.nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
-torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
+class _Node(_Tracked):
+    """Container that only exists to reproduce the reference's dotted parameter names."""
 
 
 def _attach(root: nn.Module, key: str, value: Tensor, buffer: bool):
@@ -53,7 +73,7 @@ def _attach(root: nn.Module, key: str, value: Tensor, buffer: bool):
         m.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
 
 
-class SSD(nn.Module):
+class SSD(_Tracked):
     def __init__(self, graph: Graph, init: str = "normal"):
         super().__init__()
         self.graph = graph
@@ -190,13 +210,14 @@ class SSD(nn.Module):
             L = _lib.lib()
             D = self.detections_per_img
             ws = L.dn_workspace_bytes(C.c_void_p(self._handle), n)
+            # the four outputs are typed views of ONE allocation, so that the list API takes its private copy of a call's results
+            # with one device copy (forward())
+            out = torch.empty(self._out_bytes(n), dtype=torch.uint8, device=device)
+            boxes, scores, labels, counts = self._out_views(out, n)
             b = dict(
                 images=torch.empty((n, 3, h, w), dtype=torch.float32, device=device),
                 ws=torch.empty(ws, dtype=torch.uint8, device=device),
-                boxes=torch.empty((n, D, 4), dtype=torch.float32, device=device),
-                scores=torch.empty((n, D), dtype=torch.float32, device=device),
-                labels=torch.empty((n, D), dtype=torch.int64, device=device),
-                counts=torch.empty((n,), dtype=torch.int32, device=device),
+                out=out, boxes=boxes, scores=scores, labels=labels, counts=counts,
             )
             if len(self._bufs) >= 4:
                 self._bufs.clear()
@@ -205,6 +226,16 @@ class SSD(nn.Module):
             if hasattr(self, "_graph_mode"):
                 _lib.check(L.dn_set_graph_mode(C.c_void_p(self._handle), int(self._graph_mode)))
         return b
+
+    def _out_bytes(self, n):
+        D = self.detections_per_img
+        return n * D * 16 + n * D * 8 + n * D * 4 + n * 4       # boxes fp32 x 4 | labels int64 | scores fp32 | counts int32 (every offset 8-byte aligned)
+
+    def _out_views(self, out: Tensor, n: int):
+        D = self.detections_per_img
+        o1, o2, o3 = n * D * 16, n * D * 24, n * D * 28
+        return (out[:o1].view(torch.float32).view(n, D, 4), out[o2:o3].view(torch.float32).view(n, D),
+                out[o1:o2].view(torch.int64).view(n, D), out[o3:o3 + 4 * n].view(torch.int32))
 
     # ------------------------------------------------------------------------------------------------------
     def forward_batch(self, images: Tensor, persistent_input: bool = False, packed: Optional[Tensor] = None):
@@ -383,15 +414,18 @@ class SSD(nn.Module):
             self._plan(device)
             b = self._buffers_for(len(idxs), shape[1], shape[2], device)
             torch.stack([images[i] if images[i].dtype is f32 else images[i].to(f32) for i in idxs], out=b["images"])
-            boxes, scores, labels, counts = self.forward_batch(b["images"], persistent_input=True)
-            # the padded outputs live in buffers that the next call overwrites: ONE private copy of each per call, the per-image results
-            # are views into it (three copy launches instead of three per image: 0.2 -> 1 ms of launches at 64 images)
-            boxes, scores, labels = boxes.clone(), scores.clone(), labels.clone()
-            cnt = counts.tolist()                                                   # the one device->host sync
-            # per-image views: one unbind per output (0.7 us per view) and a slice only where an image has fewer than D detections (2 us each);
-            # indexing [j, :c] for every image and output was 0.4 ms of host time per 64-image call
+            self.forward_batch(b["images"], persistent_input=True)
+            # The padded outputs live in buffers that the next call overwrites: ONE private copy per call (a single device copy of the
+            # allocation that holds all four), and the per-image results are views into it. They therefore SHARE storage: keeping one
+            # image's result alive keeps the whole batch copy (n x D x 28 bytes) alive, and an in-place edit of a full-length result
+            # edits that copy -- the reference returns independent tensors per image; clone() a result to detach it.
+            boxes, scores, labels, counts = self._out_views(b["out"].clone(), len(idxs))
+            # The full-length views are made BEFORE the host waits for the counts: 192 tensor objects cost ~0.13 ms of host time, which
+            # this way runs under the forward on the device instead of behind it. Only images with fewer than D detections need a slice
+            # afterwards (2 us each).
             D = boxes.shape[1]
             ub, us, ul = boxes.unbind(0), scores.unbind(0), labels.unbind(0)
+            cnt = counts.tolist()                                                   # the one device->host sync
             for j, i in enumerate(idxs):
                 c = cnt[j]
                 d = {"boxes": ub[j], "scores": us[j], "labels": ul[j]} if c == D else {"boxes": ub[j][:c], "scores": us[j][:c], "labels": ul[j][:c]}

@@ -36,6 +36,20 @@ def test_library_exports_every_declared_symbol():
     assert L.dn_abi_version() == _lib.DN_ABI_VERSION
 
 
+def test_library_exports_nothing_the_headers_do_not_declare():
+    """Every dn_* symbol the product library exports is declared in include/demonet_hip.h (the boundary) or include/demonet_hip_debug.h
+    (the two test-support entry points); the probe hooks (dn_debug_*_stamps, dn_debug_pw_tile) exist in the dev build only."""
+    if not os.path.exists(_lib.LIB_PATH):
+        from demonet_amd import build
+        build.build(verbose=False)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("dn_")})
+    dbg = open(os.path.join(ROOT, "include", "demonet_hip_debug.h")).read()
+    declared = set(_declared_symbols()) | set(re.findall(r"DN_API\s+[\w\s\*]+?\b(dn_\w+)\s*\(", dbg))
+    assert set(exported) == declared, sorted(set(exported) ^ declared)
+    assert sorted(s for s in exported if s.startswith("dn_debug_")) == ["dn_debug_clear_graphs", "dn_debug_head_fused_launches"]
+
+
 def test_struct_layout_matches_c(tmp_path):
     """sizeof/offsetof of the ctypes mirrors against the real header (compiled with gcc)."""
     src = tmp_path / "sz.c"
@@ -215,3 +229,23 @@ def test_plan_signature_tracks_weight_updates():
     m._handle = None
     m.invalidate()
     assert m._sig is None
+
+
+def test_bench_fused_block_bytes_count_the_residual_once():
+    """bench.py's roofline bytes of a fused inverted-residual launch: input once, output once, weights -- the residual of a block IS its
+    input and must not be added again (round-4 review: the expdw family was over-credited by 21 %)."""
+    import importlib.util
+    sp = importlib.util.spec_from_file_location("bench_for_costs", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(bench)
+    g = models.ssdlite320_mobilenet_v3_large(num_classes=91).graph
+    n = 64
+    costs = bench.op_costs(g, n)
+    # block b3 (features.0.3): pw 24->72, dw 72 k3 s1, pw 72->24 + residual, all on the 80 x 80 map
+    i = next(i for i, nd in enumerate(g.nodes) if nd.op == "pw" and nd.cin == 24 and nd.cout == 72 and g.t(nd.inp).h == 80 and g.nodes[i + 2].residual == nd.inp)
+    mem = [i, i + 1, i + 2]
+    m = n * 80 * 80
+    want = 2 * m * 24 + 2 * m * 24 + (2 * 24 * 72 + 4 * 72) + (2 * 9 * 72 + 4 * 72) + (2 * 72 * 24 + 4 * 24)
+    assert bench.fused_external_bytes(g, costs, mem, False) == want
+    # a projection whose residual comes from elsewhere (not this launch's input) still pays for it
+    assert bench.fused_external_bytes(g, costs, [i + 2], False) == 2 * m * 72 + 2 * m * 24 + (2 * 72 * 24 + 4 * 24) + 2 * m * 24
