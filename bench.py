@@ -103,6 +103,7 @@ def op_costs(graph, n):
         out.append(dict(kernel="softmax_decode_kernel", bytes=float(n * A * (4 * K + 16 + 4 * (K - 1) + 16)), flops=float(5 * n * A * K)))
     out.append(dict(kernel="select_nms_kernel", bytes=float(n * (K - 1) * (4 * A + 24 * topk)), flops=float(25 * n * (K - 1) * topk * topk / 2)))
     out.append(dict(kernel="merge_kernel", bytes=float(n * ((K - 1) * topk * 8 + D * 40)), flops=0.0))
+    out.append(dict(kernel="select_nms_kernel", bytes=float(4 * n), flops=0.0))      # the fallback launch behind the cut-off pass: reads the per-image flags (and redoes flagged images: usually none)
     return out
 
 
@@ -544,7 +545,7 @@ def main(argv=None):
         from demonet_amd import _lib
         L = _lib.lib()
         h = C.c_void_p(model._handle)
-        nseg = len(g.nodes) + 3
+        nseg = len(g.nodes) + 4
         if chains_timed == 1 and _lib.check(L.dn_batch_split(h, B)) != 1:
             # the timed region ran whole-batch chains: profile the kernels at that size
             _lib.check(L.dn_set_chains(h, 1))
@@ -559,7 +560,9 @@ def main(argv=None):
         # the library reports which kernel each op launched and which op's event segment holds a grouped launch's time
         name = C.create_string_buffer(96)
         owner = C.c_int32()
-        post = [costs[len(g.nodes)]["kernel"], "select_nms_fast_kernel (+tau, fallback select)", "merge_kernel"]
+        # the post-process launches have event segments of their own (dn_profile_end): softmax + decode (empty when the fused head launch does
+        # it) | tau + cut-off selection | merge | the fallback launch
+        post = [costs[len(g.nodes)]["kernel"], "select_nms_fast_kernel (+tau)", "merge_kernel", "select_nms_kernel (fallback)"]
         agg = {}
         for i, c in enumerate(costs):
             if i < len(g.nodes):
@@ -590,7 +593,7 @@ def main(argv=None):
                 a["launches"] += split
         if args.per_op:
             with open(args.per_op, "w") as f:
-                names = [f"{nd.op}:{nd.conv_key or nd.fc1_key or nd.scale_key}" for nd in g.nodes] + ["softmax_decode", "select_nms", "merge"]
+                names = [f"{nd.op}:{nd.conv_key or nd.fc1_key or nd.scale_key}" for nd in g.nodes] + ["softmax_decode", "tau + select_nms_fast", "merge", "fallback select"]
                 members = {}
                 for i, c in enumerate(costs):
                     members.setdefault(c["owner"], []).append(i)

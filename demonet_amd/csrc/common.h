@@ -182,6 +182,29 @@ bool pw_dw_direct_supported(const PwArgs& a, const DwArgs& d);      // depthwise
 int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s);
 // SSDLite heads, depthwise 3x3 inside the 1x1 GEMM's operand staging: every level, both heads, one launch (headfuse.hip).
 // Index 0 = class head, 1 = box head; both read the level's feature map x.
+// ... and, since round 5, the first launch of the post-process in its epilogue (generalized_ssd.py:354,362-363: softmax over the classes,
+// decode_single + clip): a workgroup holds ALL class and box channels of its 64 pixels, so every (pixel, anchor) row is complete in it.
+// The logits / regressions are then not written at all; what leaves is what softmax_decode_kernel (postprocess.hip) would have produced
+// from them, bit for bit: class-major scores, decoded boxes, score-histogram rows.
+struct HeadPost {
+    float* scoresT = nullptr;        // [n][K-1][A]; null: plain head launch (fp32 logits / regressions to HeadFuseLevel::out)
+    float4* boxes = nullptr;         // [n][A]
+    unsigned* hrows = nullptr;       // [n][rows_per_image][256] histogram rows: one per (32-pixel half tile, image) pair, see HistRows
+    const float* anchors = nullptr;  // [A][4]
+    int A = 0, K = 0, rows_per_image = 0, hb0 = 0, nb = 0;
+    float img_w = 0.f, img_h = 0.f, score_thr = 0.f;
+};
+// Which histogram rows belong to an image (written by head_fused_kernel, added up by tau_kernel). Level l owns slots [sbase[l], sbase[l] + S_l)
+// of an image's rows_per_image rows; the 32-pixel half tiles of the level that touch the image fill slots 0, 1, ... in order (an image of hw
+// pixels is touched by at most (hw + 30) / 32 + 1 of them). levels == 0: the layout of softmax_decode_kernel ([n][tiles][256], every row used).
+struct HistRows {
+    int levels = 0, rows_per_image = 0;
+    int hw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sbase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, grouped[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+inline int hist_rows_slots(int hw) { return (hw + 30) / 32 + 1; }
+// XCD grouping of a fused-head level (a group of xq images per workgroup residue mod 8) only where a group fills whole tiles
+inline bool head_fused_grouped(int xq, int hw) { return xq > 0 && (long)xq * hw >= 256; }
+
 struct HeadFuseLevel {
     const half_t* x;                 // [n][H][W][C]
     const half_t* wdg;               // the class head's depthwise 3x3 weights in GROUP-major order [C / 8][9 taps][8] fp16 (dn_op_desc::w2_off of its DW op)
@@ -190,9 +213,11 @@ struct HeadFuseLevel {
     float* out[2]; long out_img_stride[2], out_base[2];     // fp32 head arrays: elements between images, element offset of image 0's level rows
     int nc[2];                       // output channels (anchors per location x classes, x 4)
     int n, H, W, C, act;             // act: the depthwise activation
+    int aoff = 0, aloc = 0, sbase = 0;      // with a HeadPost: first anchor of the level, anchors per location, first histogram-row slot
 };
 bool head_fused_level_supported(const HeadFuseLevel& l);
-int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s);
+bool head_fused_post_supported(const HeadFuseLevel* lv, int count, const HeadPost& post);
+int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s, const HeadPost* post = nullptr);
 
 struct DwArgs {
     const half_t* x; const half_t* w; const float* bias; half_t* out;
@@ -326,7 +351,18 @@ struct PostArgs {
     void* ws; size_t ws_bytes;
     int xq = 0;                 // XCD grouping: images per group (0: plain mapping)
     PostLevels lv;              // default: one level with one anchor per location (stored order == canonical order)
+    // scores, boxes and histogram rows already written by the fused head launch (HeadPost): the softmax / decode launch is skipped and
+    // tau_kernel reads the rows through this table
+    bool scores_ready = false;
+    HistRows hrows;
 };
+// where launch_postprocess keeps its arrays inside the workspace it is given (the fused head launch writes the first three itself)
+struct PostBuffers {
+    float* scoresT; float4* boxes; float* keptScore; int* keptAnchor; int* keptCount;
+    unsigned* phist; unsigned* tauKey; int* needFull; int* order; int* fbcnt;
+    int tiles;
+};
+PostBuffers post_buffers(void* ws, int n, int A, int K, int topk);
 size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets);
 void post_hist_range(float score_thresh, int* hb0, int* nb, int* clamped);
-int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev /* optional [4] phase boundaries */);
+int launch_postprocess(const PostArgs& a, hipStream_t s, hipEvent_t* ev /* optional [5] phase boundaries: softmax+decode | cut-off + selection | merge | fallback */);

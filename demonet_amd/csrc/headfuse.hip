@@ -23,9 +23,20 @@
 //      requested before the depthwise phase). Accumulation order = pw_group_kernel's (one accumulator per output, K ascending in 16-deep
 //      steps, bias added in fp32 at the end): logits and box regressions are bit-identical to the two-launch path.
 // One barrier per chunk (B tiles and x runs double-buffered). Epilogue: straight from the accumulators, 32 contiguous bytes per pixel and store.
+//
+// Round 5, SM = true: the first launch of the post-process in the epilogue (generalized_ssd.py:354 softmax, :362-363 decode + clip). The
+// workgroup holds every class and box channel of its 64 pixels, so each (pixel, anchor) row of K logits is complete in it: per 32-pixel half
+// tile the accumulators (+ bias) go to LDS as [pixel][channel] fp32 rows (70 KB for 6 x 91 classes: the main loop's buffers are dead by then),
+// four lanes per row compute max / exp / sum exactly as softmax_decode_kernel does (post_math.h: same code, same bits), the scores leave
+// class-major -- a half tile's 32 x A_l rows are consecutive canonical anchors, 768-byte runs per class -- the boxes are decoded from the 4 A_l
+// regression channels, and the score histogram (+ per-class counts) of every (half tile, image) pair goes to a row of its own that tau_kernel
+// adds up (HistRows; no atomics in memory, nothing to clear). The fp32 logits (79 MB per 64 images) are neither written nor read back, and
+// softmax_decode_kernel's launch is gone. SM = false (dn_forward_heads, DN_HEAD_SOFTMAX=0) writes the logits as before.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
+#include "post_math.h"
 
 namespace {
 
@@ -36,6 +47,9 @@ constexpr int HF_WOFF = HF_ZOFF + 64;             // 1 KB slot: the box head's d
 constexpr int HF_XS = HF_WOFF + 1024;             // bytes per x buffer: four planes + the zero slot + the weight slot
 constexpr int HF_BS = 4 * HF_P * 16;              // bytes per B tile (one head, one buffer)
 constexpr int HF_LDS = 2 * HF_XS + 4 * HF_BS;     // 18 560 + 16 384 B
+constexpr int HF_NP = 2;            // softmax epilogue: images per histogram window (a 32-pixel half tile of a level with >= 32 pixels touches at most 2)
+// LDS of the softmax epilogue: [32][nc0] + [32][nc1] fp32 rows, row sum / row offset / anchor tables of 256 entries, HF_NP histograms, 256 part bytes
+constexpr int hf_post_lds(int nc0, int nc1) { return 32 * (nc0 + nc1) * 4 + 3 * 256 * 4 + HF_NP * 256 * 4 + 256; }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
@@ -58,11 +72,13 @@ struct HfLevel {
     int act;                         // depthwise activation
     int tiles;                       // 64-pixel tiles per XCD group; 0: this level uses the plain mapping (tiles of the whole level)
     int ct0;                         // channel tiles of the class head; the box head is tile ct0
+    int aoff, aloc, sbase;           // softmax epilogue: first anchor of the level, anchors per location, first histogram-row slot (HistRows)
 };
 struct HfGroup {
     int count, xq;
     int start[9];
     long long* stamps;               // dev builds only (-DDN_DEV_STAMPS, tools/probe_headfuse.py): per-workgroup phase cycle sums
+    HeadPost post;                   // SM instantiations only
     HfLevel lv[8];
 };
 #ifdef DN_DEV_STAMPS
@@ -88,7 +104,7 @@ __device__ __forceinline__ void hf_fma8v(float (&acc)[8], const u32x4& x, const 
     }
 }
 
-template <int TCW>
+template <int TCW, bool SM>
 __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hf_lds[];
     int p = 0;
@@ -311,6 +327,139 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
 #ifdef DN_DEV_STAMPS
     const long long st_end_loop = (long long)__builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (SM) {
+        // ---- softmax + decode epilogue (file header). Lane (r, hh) holds pixel r of each pixel tile and channels 8 g + 4 hh .. + 3 of each channel tile.
+        const HeadPost& P = g.post;
+        // the lane's coordinates again from threadIdx.x, opaque to value numbering: otherwise hipcc keeps the main loop's copies alive for
+        // the epilogue -- one register too many at TCW = 5 (a spill; and the lint refuses scratch in this kernel)
+        int te = threadIdx.x;
+        asm volatile("" : "+v"(te));
+        const int lane = te & 63, r = lane & 31, hh = lane >> 5;
+        const int K = P.K, Km1 = K - 1, AL = L.aloc, NC0 = L.nc[0], NC1 = L.nc[1], hw = L.hw;
+        float* const lg = reinterpret_cast<float*>(hf_lds);                        // [32][NC0] logits, then exp(x - max)
+        float* const rgt = lg + 32 * NC0;                                           // [32][NC1] box regressions
+        float* const rowsum = rgt + 32 * NC1;                                       // [256]
+        unsigned* const rowoff = reinterpret_cast<unsigned*>(rowsum + 256);         // [256] pixel * NC0 + anchor * K
+        unsigned* const ranc = rowoff + 256;                                        // [256] canonical anchor index of the row
+        unsigned* const lhist = ranc + 256;                                         // [HF_NP][256]
+        unsigned char* const rpart = reinterpret_cast<unsigned char*>(lhist + HF_NP * 256);      // [256] the row's image - first image of the half tile
+        const int ccb = (P.nb + Km1 <= 256) ? P.nb : -1;                            // per-class counts of passing scores in the free bins [nb, nb + K - 1)
+        const bool grouped = g.xq > 0 && L.tiles > 0;
+        const int img_g0 = grouped ? (flat & 7) * g.xq : 0;                         // first image / pixel of this workgroup's XCD group (plain mapping: 0)
+        const int r0 = img_g0 * hw;
+        __syncthreads();            // every wave is done with the x runs and B tiles: the LDS belongs to the epilogue now
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mj = m0 + 32 * j;
+            if (mj >= mend) break;
+            const int npx = min(32, mend - mj), nrows = npx * AL;
+            const int img_first = mj / hw, img_last = (mj + npx - 1) / hw;
+            // (W) accumulators + bias -> [pixel][channel] rows (float2 pieces: a row starts at an 8-byte boundary, nc is even)
+#pragma unroll
+            for (int i = 0; i < TCW; ++i) {
+                const bool reg = (i == TCW - 1) && last_reg;
+                if (i == TCW - 1 && !last_on) break;
+                const int ct = reg ? 0 : wave + 4 * i;
+                const int nc = reg ? NC1 : NC0;
+                const float* bias = reg ? L.bias[1] : L.bias[0];
+                float* drow = (reg ? rgt : lg) + r * nc;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch = 32 * ct + 8 * gq + 4 * hh;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] + bias[min(ch + e, nc - 1)];
+                    if (ch + 4 <= nc) {
+                        *reinterpret_cast<float2*>(drow + ch) = make_float2(v[0], v[1]);
+                        *reinterpret_cast<float2*>(drow + ch + 2) = make_float2(v[2], v[3]);
+                    } else if (ch + 2 <= nc) {
+                        *reinterpret_cast<float2*>(drow + ch) = make_float2(v[0], v[1]);
+                    }
+                }
+            }
+            // row tables: row = pixel * AL + anchor -- consecutive rows are consecutive canonical anchors
+            int bx_px = 0, bx_a = 0, bx_img = 0, bx_anc = 0;
+            if (te < nrows) {
+                bx_px = te / AL; bx_a = te - bx_px * AL;
+                const int m = mj + bx_px;
+                bx_img = m / hw;
+                bx_anc = L.aoff + (m - bx_img * hw) * AL + bx_a;
+                rowoff[te] = (unsigned)(bx_px * NC0 + bx_a * K);
+                ranc[te] = (unsigned)bx_anc;
+                rpart[te] = (unsigned char)(bx_img - img_first);
+            }
+            __syncthreads();
+            // (B) decode_single + clip of the row's box (_utils.py:187-224): the anchor load is in flight under the softmax
+            if (te < nrows) {
+                const float4 rg4 = *reinterpret_cast<const float4*>(rgt + bx_px * NC1 + bx_a * 4);
+                const float4 an = reinterpret_cast<const float4*>(P.anchors)[bx_anc];
+                P.boxes[(size_t)bx_img * P.A + bx_anc] = pp_decode_box(rg4, an, P.img_w, P.img_h);
+            }
+            // (S) softmax rows: four adjacent lanes per row, 64 rows per pass
+            for (int rb = 0; rb < nrows; rb += 64) {
+                const int row = rb + (te >> 2);
+                const bool valid = row < nrows;
+                const float sm = pp_softmax_row(lg + (valid ? rowoff[row] : 0u), K, te & 3, valid);
+                if (valid && (te & 3) == 0) rowsum[row] = sm;
+            }
+            __syncthreads();
+            // (P) scores out, class-major, + histogram rows: windows of HF_NP images (one window on every level with >= 32 pixels per image)
+            for (int w0 = img_first; w0 <= img_last; w0 += HF_NP) {
+                const int pa = max(mj, w0 * hw) - mj, pb = min(mj + npx, (w0 + HF_NP) * hw) - mj;
+                const int ra = pa * AL, wr = (pb - pa) * AL;
+                for (int t = te; t < HF_NP * 256; t += 256) lhist[t] = 0u;
+                __syncthreads();
+                if ((wr & 63) == 0) {
+                    // a wave = 64 consecutive rows of ONE class: 256-byte runs per store instruction, class counts by ballot
+                    const int nb64 = wr >> 6;
+                    int k1 = 0, b = wave;
+                    while (b >= nb64) { b -= nb64; ++k1; }
+                    while (k1 < Km1) {
+                        const int row = ra + (b << 6) + lane;
+                        const float sc = pp_score(lg[rowoff[row] + k1 + 1], rowsum[row]);
+                        const int q = (int)rpart[row] - (w0 - img_first);
+                        P.scoresT[((size_t)(w0 + q) * Km1 + k1) * P.A + ranc[row]] = sc;
+                        const bool pass = sc > P.score_thr;
+                        if (pass) atomicAdd(&lhist[q * 256 + pp_hist_bin(sc, P.hb0, P.nb)], 1u);
+                        if (ccb >= 0) {
+#pragma unroll
+                            for (int qq = 0; qq < HF_NP; ++qq) {
+                                const int c = __popcll(__ballot(pass && q == qq));
+                                if (lane == 0 && c) atomicAdd(&lhist[qq * 256 + ccb + k1], (unsigned)c);
+                            }
+                        }
+                        b += 4;
+                        while (b >= nb64) { b -= nb64; ++k1; }
+                    }
+                } else {
+                    // ragged or small window (levels with fewer than 32 pixels per image, the last tile of a range): rows fastest, classes slow
+                    for (int idx = te; idx < Km1 * wr; idx += 256) {
+                        const int k1 = idx / wr;
+                        const int row = ra + idx - k1 * wr;
+                        const float sc = pp_score(lg[rowoff[row] + k1 + 1], rowsum[row]);
+                        const int q = (int)rpart[row] - (w0 - img_first);
+                        P.scoresT[((size_t)(w0 + q) * Km1 + k1) * P.A + ranc[row]] = sc;
+                        if (sc > P.score_thr) {
+                            atomicAdd(&lhist[q * 256 + pp_hist_bin(sc, P.hb0, P.nb)], 1u);
+                            if (ccb >= 0) atomicAdd(&lhist[q * 256 + ccb + k1], 1u);
+                        }
+                    }
+                }
+                __syncthreads();
+                // this (half tile, image) pair's row: slot = half tiles of the range between the image's first one and this one
+#pragma unroll
+                for (int qq = 0; qq < HF_NP; ++qq) {
+                    const int img = w0 + qq;
+                    if (img <= img_last) {
+                        const int slot = ((mj - r0) >> 5) - (((img - img_g0) * hw) >> 5);
+                        P.hrows[((size_t)img * P.rows_per_image + L.sbase + slot) * 256 + te] = (te < P.nb + (ccb >= 0 ? Km1 : 0)) ? lhist[qq * 256 + te] : 0u;
+                    }
+                }
+                __syncthreads();    // (the next window / half tile rewrites the tables)
+            }
+        }
+        return;
+    }
     // ---- epilogue: straight from the accumulators. Lane (r, hh) holds pixel r of each pixel tile and channels 8 g + 4 hh .. + 3 of each channel
     // tile in registers 4 g .. 4 g + 3: one 16-byte store per (tile, g) -- the two half waves write adjacent pieces, 32 contiguous bytes per
     // pixel and instruction. (Through a per-wave LDS slab as row-contiguous float2 runs it was 80 dependent LDS round trips per wave: 20 000
@@ -386,13 +535,35 @@ bool head_fused_level_supported(const HeadFuseLevel& l) {
 static long long* g_hf_stamps = nullptr;
 extern "C" __attribute__((visibility("default"))) void dn_debug_hf_stamps(void* dev_ptr) { g_hf_stamps = (long long*)dev_ptr; }
 #endif
-static int g_head_fused_launches = 0;
+static int g_head_fused_launches = 0, g_head_softmax_launches = 0;
 extern "C" __attribute__((visibility("default"))) int dn_debug_head_fused_launches() { return g_head_fused_launches; }      // tests: the path was taken
+extern "C" __attribute__((visibility("default"))) int dn_debug_head_softmax_launches() { return g_head_softmax_launches; }  // ... with the softmax / decode epilogue
 
-int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s) {
+bool head_fused_post_supported(const HeadFuseLevel* lv, int count, const HeadPost& post) {
+    if (!post.scoresT || !post.boxes || !post.hrows || !post.anchors || post.K < 2 || post.A < 1 || post.nb < 1 || post.nb > 256) return false;
+    int rows = 0, anchors = 0;
+    for (int i = 0; i < count; ++i) {
+        const HeadFuseLevel& l = lv[i];
+        if (l.aloc < 1 || l.aloc > 8 || l.nc[0] != l.aloc * post.K || l.nc[1] != 4 * l.aloc) return false;       // 32 pixels x aloc rows fit the 256-entry tables
+        if (hf_post_lds(l.nc[0], l.nc[1]) > 80 * 1024) return false;                                            // two workgroups per CU stay resident
+        if (l.sbase != rows) return false;
+        rows += hist_rows_slots(l.H * l.W);
+        anchors += l.H * l.W * l.aloc;
+        if ((unsigned long long)l.n * (post.K - 1) * post.A >= 0x7fffffffull) return false;
+    }
+    return rows == post.rows_per_image && anchors <= post.A;
+}
+
+int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s, const HeadPost* post) {
     DN_REQUIRE(count >= 1 && count <= 8, "fused heads: %d levels", count);
     HfGroup g{};
     g.count = count; g.xq = xq;
+    int lds = HF_LDS;
+    if (post) {
+        DN_REQUIRE(head_fused_post_supported(lv, count, *post), "fused heads: softmax epilogue not supported for these levels");
+        g.post = *post;
+        for (int i = 0; i < count; ++i) lds = std::max(lds, hf_post_lds(lv[i].nc[0], lv[i].nc[1]));
+    }
     int acc = 0, tcw = 0;
     for (int i = 0; i < count; ++i) {
         const HeadFuseLevel& l = lv[i];
@@ -407,13 +578,14 @@ int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s)
         }
         d.H = l.H; d.W = l.W; d.C = l.C; d.hw = l.H * l.W; d.m = l.n * d.hw; d.act = l.act;
         d.ct0 = dn_cdiv(l.nc[0], 32);
+        d.aoff = l.aoff; d.aloc = l.aloc; d.sbase = l.sbase;
         const int t4 = dn_cdiv(d.ct0 + 1, 4);
         DN_REQUIRE(i == 0 || t4 == tcw, "fused heads: levels differ in channel tiles per wave (%d vs %d)", t4, tcw);
         tcw = t4;
         // XCD grouping (a group of xq images per workgroup residue mod 8) only where a group fills whole tiles: on the small maps the ragged last
         // tile of every group is most of the level (5 x 5: 32 workgroups instead of 25) and every workgroup beyond the 512 resident ones starts
         // a second round of the launch
-        const bool grouped = xq > 0 && (long)xq * d.hw >= 4 * HF_P;
+        const bool grouped = head_fused_grouped(xq, d.hw);      // (xq * hw >= 4 tiles)
         d.tiles = grouped ? dn_cdiv((long)xq * d.hw, HF_P) : 0;
         g.start[i] = acc;
         acc += grouped ? d.tiles * 8 : dn_cdiv(d.m, HF_P);
@@ -422,16 +594,24 @@ int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s)
 #ifdef DN_DEV_STAMPS
     g.stamps = g_hf_stamps;
 #endif
-    dn_note_kernel("head_fused_kernel<%d>", tcw);
+    dn_note_kernel(post ? "head_fused_kernel<%d,softmax>" : "head_fused_kernel<%d>", tcw);
     ++g_head_fused_launches;
+    if (post) ++g_head_softmax_launches;
     const dim3 grid(acc), block(256);
+#define HF_GO(T)                                                                                                            \
+    if (post) {                                                                                                             \
+        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(head_fused_kernel<T, true>), 80 * 1024));               \
+        hipLaunchKernelGGL((head_fused_kernel<T, true>), grid, block, lds, s, g);                                           \
+    } else                                                                                                                  \
+        hipLaunchKernelGGL((head_fused_kernel<T, false>), grid, block, lds, s, g)
     switch (tcw) {
-        case 1: hipLaunchKernelGGL((head_fused_kernel<1>), grid, block, HF_LDS, s, g); break;
-        case 2: hipLaunchKernelGGL((head_fused_kernel<2>), grid, block, HF_LDS, s, g); break;
-        case 3: hipLaunchKernelGGL((head_fused_kernel<3>), grid, block, HF_LDS, s, g); break;
-        case 4: hipLaunchKernelGGL((head_fused_kernel<4>), grid, block, HF_LDS, s, g); break;
-        case 5: hipLaunchKernelGGL((head_fused_kernel<5>), grid, block, HF_LDS, s, g); break;
+        case 1: HF_GO(1); break;
+        case 2: HF_GO(2); break;
+        case 3: HF_GO(3); break;
+        case 4: HF_GO(4); break;
+        case 5: HF_GO(5); break;
         default: DN_REQUIRE(false, "fused heads: %d channel tiles per wave", tcw);
     }
+#undef HF_GO
     return DN_OK;
 }

@@ -778,6 +778,9 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     };
     int ev = ev0;
     hipStream_t const main_stream = s;
+    // set by launch_heads when the fused head launch also ran softmax + decode (headfuse.hip, SM): the post-process starts at the cut-off
+    bool scores_ready = false;
+    HistRows fused_rows;
     // head launches of the pyramid levels [lv0, lv1): the depthwise group, then the 1x1 / dense group(s), on stream hs
     auto launch_heads = [&](int lv0, int lv1, hipStream_t hs, bool rec, size_t& seg) -> int {
         int rc = DN_OK;
@@ -834,7 +837,34 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 members.push_back(dc); members.push_back(dr); members.push_back(h_cls[q]); members.push_back(qr);
             }
             if (nl > 0) {
-                rc = launch_head_fused(fl, nl, xq, hs);
+                // softmax + decode + histogram rows in the same launch (DN_HEAD_SOFTMAX, default 1) when EVERY level's heads are in it and the
+                // post-process follows (dn_forward_heads wants the logits themselves)
+                HeadPost hp;
+                bool with_post = false;
+                if (!heads_only && dn_knob("DN_HEAD_SOFTMAX", 1) != 0 && members.size() == h_dw.size() + h_cls.size() + h_reg.size() && lv0 == 0 &&
+                    nl == d.n_levels) {
+                    const PostBuffers pb = post_buffers(ws + L.post_off, n, d.num_anchors, d.num_classes, d.topk_candidates);
+                    int clamped = 0;
+                    post_hist_range(d.score_thresh, &hp.hb0, &hp.nb, &clamped);
+                    hp.scoresT = pb.scoresT; hp.boxes = pb.boxes; hp.hrows = pb.phist; hp.anchors = p->anchors_dev;
+                    hp.A = d.num_anchors; hp.K = d.num_classes;
+                    hp.img_w = (float)d.image_w; hp.img_h = (float)d.image_h; hp.score_thr = d.score_thresh;
+                    HistRows hr;
+                    hr.levels = nl;
+                    int rows = 0;
+                    for (int q = 0; q < nl; ++q) {
+                        const int level = p->ops[members[4 * q + 2]].level;
+                        fl[q].aoff = p->level_off[level];
+                        fl[q].aloc = fl[q].nc[0] / d.num_classes;
+                        fl[q].sbase = rows;
+                        hr.hw[q] = fl[q].H * fl[q].W; hr.sbase[q] = rows; hr.grouped[q] = head_fused_grouped(xq, hr.hw[q]) ? 1 : 0;
+                        rows += hist_rows_slots(hr.hw[q]);
+                    }
+                    hr.rows_per_image = hp.rows_per_image = rows;
+                    with_post = rows <= pb.tiles && head_fused_post_supported(fl, nl, hp);
+                    if (with_post) { scores_ready = true; fused_rows = hr; }
+                }
+                rc = launch_head_fused(fl, nl, xq, hs, with_post ? &hp : nullptr);
                 if (rc != DN_OK) return rc;
                 for (int q : members) hnote(q, seg);
                 ++seg;
@@ -1103,10 +1133,11 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.packed = packed;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         a.xq = xq;
+        a.scores_ready = scores_ready; a.hrows = fused_rows;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
         if (rc) return rc;
-        ev += 4;
+        ev += 5;
     } else if (record) {
         (void)hipEventRecord(p->events[ev++], s);
     }
@@ -1125,7 +1156,7 @@ static int enqueue_all(dn_plan* p, const float* images, int n, int h, int w, flo
     const int S = batch_split(p, n);
     if (S == 1) return enqueue(p, images, n, h, w, boxes, scores, labels, counts, ws, get_layout(p, n), heads_only, s, record, p->packed_out, 0);
     const size_t D = (size_t)p->d.detections_per_img;
-    const int ev_stride = (int)p->ops.size() + 5;
+    const int ev_stride = (int)p->ops.size() + 6;
     if (!record) DN_HIP_CHECK(hipEventRecord(p->ev_fork, s));
     size_t n0 = 0;
     for (int k = 0; k < S; ++k) {
@@ -1187,7 +1218,7 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     if (p->profiling) {
         const int S = batch_split(p, n);
-        const size_t stride = p->ops.size() + 5;
+        const size_t stride = p->ops.size() + 6;
         const size_t need = stride * S;
         while (p->events.size() < need) {
             hipEvent_t e;
@@ -1199,8 +1230,8 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
         int rc = enqueue_all(p, images, n, h, w, boxes, scores, labels, counts, ws, heads_only, s, true);
         if (rc) return rc;
         DN_HIP_CHECK(hipStreamSynchronize(s));
-        const size_t nseg = heads_only ? p->ops.size() : p->ops.size() + 3;
-        if (p->prof_ms.size() < p->ops.size() + 3) p->prof_ms.assign(p->ops.size() + 3, 0.0);
+        const size_t nseg = heads_only ? p->ops.size() : p->ops.size() + 4;      // + softmax/decode | cut-off + selection | merge | fallback
+        if (p->prof_ms.size() < p->ops.size() + 4) p->prof_ms.assign(p->ops.size() + 4, 0.0);
         for (int k = 0; k < S; ++k)
             for (size_t i = 0; i < nseg; ++i) {
                 float ms = 0.f;
@@ -1333,7 +1364,7 @@ extern "C" int dn_set_packed_output(dn_plan* p, float* packed_dev) {
 extern "C" int dn_profile_begin(dn_plan* p) {
     DN_REQUIRE(p, "null plan");
     p->profiling = true;
-    p->prof_ms.assign(p->ops.size() + 3, 0.0);
+    p->prof_ms.assign(p->ops.size() + 4, 0.0);
     p->prof_runs = 0;
     return DN_OK;
 }
@@ -1349,7 +1380,7 @@ extern "C" int dn_profile_op_info(const dn_plan* p, int op_index, char* kernel, 
 extern "C" int dn_profile_end(dn_plan* p, float* ms_per_op, int capacity) {
     DN_REQUIRE(p && ms_per_op, "null argument");
     p->profiling = false;
-    const int nseg = (int)p->ops.size() + 3;
+    const int nseg = (int)p->ops.size() + 4;
     DN_REQUIRE(capacity >= nseg, "dn_profile_end: capacity %d < %d", capacity, nseg);
     for (int i = 0; i < nseg; ++i) ms_per_op[i] = p->prof_runs ? (float)(p->prof_ms[i] / p->prof_runs) : 0.f;
     return p->prof_runs;

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include "common.h"
+#include "post_math.h"
 
 #ifdef DN_DEV_STAMPS
 static long long* g_pp_stamps = nullptr;     // dev build only: per-workgroup phase stamps of select_nms (tools/probe_pp_stamps.py)
@@ -37,37 +38,8 @@ namespace {
 #define PP_STAMP(k) do { } while (0)
 #endif
 
-constexpr float BBOX_XFORM_CLIP = 4.135166556742356f;   // log(1000/16), _utils.py:135
 constexpr int HSHIFT = DN_PP_HSHIFT;                     // score histogram: float bits 30..19 (8 exponent + 4 mantissa bits)
 constexpr int HBINS = DN_PP_HBINS;                       // bins kept: the top 256 (scores down to 2^-16); anything lower shares bin 0
-
-// Box decode alone (BoxCoder.decode_single + clip, _utils.py:187-224, generalized_ssd.py:362-363): what is left of P1 when the class
-// scores come from the head launch's epilogue. Same expressions as softmax_decode_kernel's tail.
-__global__ __launch_bounds__(256) void decode_boxes_kernel(const float* __restrict__ reg, const float* __restrict__ anchors, float4* __restrict__ boxes,
-                                                          int A, float img_w, float img_h, int nimg, int tiles, int xq) {
-    int n, atile;
-    if (!xcd_image_of(blockIdx.x, tiles, xq, nimg, n, atile)) return;
-    const int a = atile * 256 + threadIdx.x;
-    if (a >= A) return;
-    const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
-    const float4 an = reinterpret_cast<const float4*>(anchors)[a];
-    const float w = an.z - an.x, h = an.w - an.y;
-    const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
-    const float dx = rg.x / 10.f, dy = rg.y / 10.f;
-    const float dw = fminf(rg.z / 5.f, BBOX_XFORM_CLIP), dh = fminf(rg.w / 5.f, BBOX_XFORM_CLIP);
-    const float pcx = dx * w + cx, pcy = dy * h + cy;
-    const float pw = expf(dw) * w, ph = expf(dh) * h;
-    float4 b;
-    b.x = pcx - 0.5f * pw;
-    b.y = pcy - 0.5f * ph;
-    b.z = pcx + 0.5f * pw;
-    b.w = pcy + 0.5f * ph;
-    b.x = fminf(fmaxf(b.x, 0.f), img_w);
-    b.z = fminf(fmaxf(b.z, 0.f), img_w);
-    b.y = fminf(fmaxf(b.y, 0.f), img_h);
-    b.w = fminf(fmaxf(b.w, 0.f), img_h);
-    boxes[(size_t)n * A + a] = b;
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // P1
@@ -127,20 +99,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     PP_STAMP(9);
     {
         const int row = tid >> 2, sub = tid & 3;
-        float mx = -INFINITY;
-        if (row < na)
-            for (int k = sub; k < K; k += 4) mx = fmaxf(mx, tile[row * K + k]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1));
-        mx = fmaxf(mx, __shfl_xor(mx, 2));
-        float sm = 0.f;
-        if (row < na)
-            for (int k = sub; k < K; k += 4) {
-                const float e = expf(tile[row * K + k] - mx);
-                tile[row * K + k] = e;
-                sm += e;
-            }
-        sm += __shfl_xor(sm, 1);
-        sm += __shfl_xor(sm, 2);
+        const float sm = pp_softmax_row(tile + row * K, K, sub, row < na);
         if (sub == 0) rowsum[row] = sm;
     }
     __syncthreads();
@@ -150,10 +109,10 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
         const int k = 1 + (idx >> 6), a = idx & 63;
         bool pass = false;
         if (a < na) {
-            const float sc = tile[a * K + k] / rowsum[a];
+            const float sc = pp_score(tile[a * K + k], rowsum[a]);
             scoresT[((size_t)n * Km1 + (k - 1)) * A + (ident ? a0 + a : pidx[a])] = sc;
             pass = sc > score_thr;
-            if (pass) atomicAdd(&lhist[min(max((int)(__float_as_uint(sc) >> HSHIFT) - hb0, 0), nb - 1)], 1u);
+            if (pass) atomicAdd(&lhist[pp_hist_bin(sc, hb0, nb)], 1u);
         }
         // a wave's 64 lanes hold the 64 anchors of ONE class per iteration, and no other wave or iteration sees that class
         const unsigned long long m = __ballot(pass);
@@ -168,22 +127,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
         const int a = a0 + tid;
         const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
         const float4 an = reinterpret_cast<const float4*>(anchors)[a];
-        const float w = an.z - an.x, h = an.w - an.y;
-        const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
-        const float dx = rg.x / 10.f, dy = rg.y / 10.f;
-        const float dw = fminf(rg.z / 5.f, BBOX_XFORM_CLIP), dh = fminf(rg.w / 5.f, BBOX_XFORM_CLIP);
-        const float pcx = dx * w + cx, pcy = dy * h + cy;
-        const float pw = expf(dw) * w, ph = expf(dh) * h;
-        float4 b;
-        b.x = pcx - 0.5f * pw;
-        b.y = pcy - 0.5f * ph;
-        b.z = pcx + 0.5f * pw;
-        b.w = pcy + 0.5f * ph;
-        b.x = fminf(fmaxf(b.x, 0.f), img_w);
-        b.z = fminf(fmaxf(b.z, 0.f), img_w);
-        b.y = fminf(fmaxf(b.y, 0.f), img_h);
-        b.w = fminf(fmaxf(b.w, 0.f), img_h);
-        boxes[(size_t)n * A + a] = b;
+        boxes[(size_t)n * A + a] = pp_decode_box(rg, an, img_w, img_h);
     }
     PP_STAMP(12);
 }
@@ -607,20 +551,38 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ phist, int tiles, int hb0, int clamped, unsigned want,
                                                  unsigned* __restrict__ tauKey, int* __restrict__ needFull, int nimg, int xq,
-                                                 int nb, int Km1, int* __restrict__ order, int* __restrict__ fbcnt) {
+                                                 int nb, int Km1, int* __restrict__ order, int* __restrict__ fbcnt, HistRows hr) {
     __shared__ unsigned part[256];
     const int tid = threadIdx.x;
     int n, unused;
     if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
-    // thread t owns bin t: sum of the per-workgroup rows of softmax_decode_kernel (fixed order, 16 loads in flight)
-    const unsigned* h = phist + ((size_t)n * tiles << 8) + tid;
     unsigned s = 0;
-    for (int t0 = 0; t0 < tiles; t0 += 16) {
-        unsigned v[16];
+    if (hr.levels == 0) {
+        // thread t owns bin t: sum of the per-workgroup rows of softmax_decode_kernel (fixed order, 16 loads in flight)
+        const unsigned* h = phist + ((size_t)n * tiles << 8) + tid;
+        for (int t0 = 0; t0 < tiles; t0 += 16) {
+            unsigned v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = h[(size_t)min(t0 + u, tiles - 1) << 8];
+            for (int u = 0; u < 16; ++u) v[u] = h[(size_t)min(t0 + u, tiles - 1) << 8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += (t0 + u < tiles) ? v[u] : 0u;
+            for (int u = 0; u < 16; ++u) s += (t0 + u < tiles) ? v[u] : 0u;
+        }
+    } else {
+        // rows of head_fused_kernel's epilogue: per level, the 32-pixel half tiles that touch this image, in slots sbase .. (HistRows). Exactly
+        // the slots counted here were written in this forward; integer sums, so the order does not matter.
+        const unsigned* h = phist + (size_t)n * hr.rows_per_image * 256 + tid;
+        for (int l = 0; l < hr.levels; ++l) {
+            const int nl = hr.grouped[l] ? n - (n / xq) * xq : n;                    // image index inside its XCD group's pixel range
+            const int cnt = (((nl + 1) * hr.hw[l] - 1) >> 5) - ((nl * hr.hw[l]) >> 5) + 1;
+            const unsigned* hl = h + (size_t)hr.sbase[l] * 256;
+            for (int t0 = 0; t0 < cnt; t0 += 8) {
+                unsigned v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = hl[(size_t)min(t0 + u, cnt - 1) << 8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (t0 + u < cnt) ? v[u] : 0u;
+            }
+        }
     }
     part[tid] = s;
     __syncthreads();
@@ -989,6 +951,29 @@ int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes,
 
 }  // namespace
 
+PostBuffers post_buffers(void* ws, int n, int A, int K, int topk) {
+    const size_t Km1 = K - 1;
+    PostBuffers b;
+    unsigned char* p = reinterpret_cast<unsigned char*>(ws);
+    b.scoresT = reinterpret_cast<float*>(p);
+    p += align256((size_t)n * Km1 * A * 4);
+    b.boxes = reinterpret_cast<float4*>(p);
+    p += align256((size_t)n * A * 16);
+    b.keptScore = reinterpret_cast<float*>(p);
+    p += align256((size_t)n * Km1 * topk * 4);
+    b.keptAnchor = reinterpret_cast<int*>(p);
+    p += align256((size_t)n * Km1 * topk * 4);
+    b.keptCount = reinterpret_cast<int*>(p);
+    p += align256((size_t)n * Km1 * 4);
+    b.tiles = dn_cdiv(A, 64);
+    b.phist = reinterpret_cast<unsigned*>(p);                              // [n][tiles][HBINS], then tauKey[n], needFull[n]
+    b.tauKey = b.phist + (size_t)n * b.tiles * HBINS;
+    b.needFull = reinterpret_cast<int*>(b.tauKey + n);
+    b.order = b.needFull + n;                                              // [n][K-1] classes, heaviest first (tau_kernel)
+    b.fbcnt = b.order + (size_t)n * Km1;                                   // [n] tickets of the fused fallback merge (zeroed by tau_kernel)
+    return b;
+}
+
 size_t postprocess_ws_bytes(int n, int A, int K, int topk, int dets) {
     (void)dets;
     const size_t Km1 = K - 1;
@@ -1034,23 +1019,16 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
         DN_REQUIRE(ok, "postprocess: the level table does not cover the %d anchors", a.A);
     }
     const size_t Km1 = a.K - 1;
-    unsigned char* p = reinterpret_cast<unsigned char*>(a.ws);
-    float* scoresT = reinterpret_cast<float*>(p);
-    p += align256((size_t)a.n * Km1 * a.A * 4);
-    float4* boxes = reinterpret_cast<float4*>(p);
-    p += align256((size_t)a.n * a.A * 16);
-    float* keptScore = reinterpret_cast<float*>(p);
-    p += align256((size_t)a.n * Km1 * a.topk * 4);
-    int* keptAnchor = reinterpret_cast<int*>(p);
-    p += align256((size_t)a.n * Km1 * a.topk * 4);
-    int* keptCount = reinterpret_cast<int*>(p);
-    p += align256((size_t)a.n * Km1 * 4);
-    const int tiles = dn_cdiv(a.A, 64);
-    unsigned* phist = reinterpret_cast<unsigned*>(p);                      // [n][tiles][HBINS], then tauKey[n], needFull[n]
-    unsigned* tauKey = phist + (size_t)a.n * tiles * HBINS;
-    int* needFull = reinterpret_cast<int*>(tauKey + a.n);
-    int* order = needFull + a.n;                                           // [n][K-1] classes, heaviest first (tau_kernel)
-    int* fbcnt = order + (size_t)a.n * Km1;                                // [n] tickets of the fused fallback merge (zeroed by tau_kernel)
+    const PostBuffers pb = post_buffers(a.ws, a.n, a.A, a.K, a.topk);
+    float* const scoresT = pb.scoresT; float4* const boxes = pb.boxes;
+    float* const keptScore = pb.keptScore; int* const keptAnchor = pb.keptAnchor; int* const keptCount = pb.keptCount;
+    const int tiles = pb.tiles;
+    unsigned* const phist = pb.phist; unsigned* const tauKey = pb.tauKey;
+    int* const needFull = pb.needFull; int* const order = pb.order; int* const fbcnt = pb.fbcnt;
+    if (a.scores_ready) {
+        DN_REQUIRE(a.hrows.levels >= 1 && a.hrows.levels <= 8 && a.hrows.rows_per_image <= tiles && a.lv.n == 1 && a.lv.aloc[0] == 1,
+                   "postprocess: scores from the head launch need a histogram-row table that fits (%d rows per image, %d available)", a.hrows.rows_per_image, tiles);
+    }
 
     const int fast = dn_knob("DN_PP_FAST", 1);
     // candidates per image kept by the cut-off, as a multiple of D. Any value is exact (too few survivors -> device-side
@@ -1067,32 +1045,36 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)HBINS * sizeof(unsigned);
     const int slots = xcd_image_slots(a.xq, a.n);
     const int hist_rows = tiles;    // per-image rows of the histogram table tau_kernel adds up
-    {
+    if (!a.scores_ready) {
+        const long long* const stp = pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr;
         if (!(a.lv.n == 1 && a.lv.aloc[0] == 1))
             hipLaunchKernelGGL(softmax_decode_kernel<true>, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,
+                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
                                a.n, tiles, a.xq, a.lv);
         else
             hipLaunchKernelGGL(softmax_decode_kernel<false>, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr,
+                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
                                a.n, tiles, a.xq, a.lv);
     }
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
     if (fast) {
         hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, hist_rows, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq,
-                           nb, (int)Km1, order, fbcnt);
+                           nb, (int)Km1, order, fbcnt, a.scores_ready ? a.hrows : HistRows{});
         const int* ord = dn_knob("DN_PP_ORDER", 1) ? order : nullptr;      // heaviest classes first (0: class order)
         if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else if (nw <= 4) rc = launch_p2_fast<4>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
+        if (ev) (void)hipEventRecord(ev[2], s);
         if (dn_knob("DN_MERGE_THREADS", 1024) == 256)
             hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 0, a.n, a.xq);
         else
             hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 0, a.n, a.xq);
     }
+    else if (ev) (void)hipEventRecord(ev[2], s);
+    if (ev) (void)hipEventRecord(ev[3], s);
     const int* flag = fast ? needFull : nullptr;
     // behind the cut-off pass: ONE launch redoes the flagged images (usually none) with the full kernel and merges each in the workgroup that
     // finishes its last class (DN_PP_FUSE_FALLBACK, default 1; 0: a second merge launch as in rounds 1 - 3)
@@ -1104,7 +1086,6 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     else if (nw <= 5) rc = launch_p2<5>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
     else rc = launch_p2<8>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
     if (rc != DN_OK) return rc;
-    if (ev) (void)hipEventRecord(ev[2], s);
     if (!fuse_fb) {
         // the merge after the full pass: with the fast path on it only works for flagged images (usually none): 256 threads, scheduled at once
         if (fast && dn_knob("DN_MERGE1_THREADS", 256) == 256)
@@ -1112,7 +1093,7 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
         else
             hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, fast ? 1 : 2, a.n, a.xq);
     }
-    if (ev) (void)hipEventRecord(ev[3], s);
+    if (ev) (void)hipEventRecord(ev[4], s);
     DN_HIP_CHECK(hipGetLastError());
     return DN_OK;
 }

@@ -160,7 +160,7 @@ DN_API int dn_set_graph_mode(dn_plan* plan, int enabled);
 /* Timing hook for bench.py: average device time in ms of the op at `op_index` over the forwards recorded since
  * dn_profile_begin (HIP events on the forward stream, eager mode). */
 DN_API int dn_profile_begin(dn_plan* plan);
-DN_API int dn_profile_end(dn_plan* plan, float* ms_per_op /* [n_ops + 3] : ops..., softmax/decode, select/NMS, merge */, int capacity);
+DN_API int dn_profile_end(dn_plan* plan, float* ms_per_op /* [n_ops + 4] : ops..., softmax/decode (0 when the fused head launch does it), cut-off + select/NMS, merge, fallback select + merge */, int capacity);
 /* After a profiled forward: the label of the kernel launch op `op_index` took part in (same spelling as rocprofv3's kernel
  * names, e.g. "pw_kernel<128,64,4,1,false,32>") and the op whose ms_per_op slot holds that launch's time (grouped launches
  * serve several ops; their members report the same owner). */

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_exports_nothing_the_headers_do_not_declare():
     """Every dn_* symbol the product library exports is declared in include/demonet_hip.h (the boundary) or include/demonet_hip_debug.h
-    (the two test-support entry points); the probe hooks (dn_debug_*_stamps, dn_debug_pw_tile) exist in the dev build only."""
+    (the test-support entry points); the probe hooks (dn_debug_*_stamps, dn_debug_pw_tile) exist in the dev build only."""
     if not os.path.exists(_lib.LIB_PATH):
         from demonet_amd import build
         build.build(verbose=False)
@@ -47,7 +47,7 @@ def test_library_exports_nothing_the_headers_do_not_declare():
     dbg = open(os.path.join(ROOT, "include", "demonet_hip_debug.h")).read()
     declared = set(_declared_symbols()) | set(re.findall(r"DN_API\s+[\w\s\*]+?\b(dn_\w+)\s*\(", dbg))
     assert set(exported) == declared, sorted(set(exported) ^ declared)
-    assert sorted(s for s in exported if s.startswith("dn_debug_")) == ["dn_debug_clear_graphs", "dn_debug_head_fused_launches"]
+    assert sorted(s for s in exported if s.startswith("dn_debug_")) == ["dn_debug_clear_graphs", "dn_debug_head_fused_launches", "dn_debug_head_softmax_launches"]
 
 
 def test_struct_layout_matches_c(tmp_path):

@@ -942,3 +942,86 @@ def test_hub_model_legacy_two_argument_call():
         for k in ("boxes", "scores", "labels"):
             assert torch.equal(a[k], b[k])
         assert a["boxes"].shape[0] > 0 and a["boxes"].shape[1] == 4
+
+
+@pytest.mark.parametrize("name,n,size", [("ssd300_vgg16", 64, 300), ("ssd512_vgg16", 16, 512)])
+def test_vgg_21_class_heads_on_the_big_tile_path(name, n, size, monkeypatch):
+    """VOC-sized heads (21 classes: 126 / 84 class channels per level): the class head passes the narrow-tile test alone (one 128-channel tile)
+    and fails it with its box head riding along (126 + 24 = 150 channels). The rider is only attached when the launch still has a tile with it
+    (round-4 advice: dn_forward returned DN_E_UNSUPPORTED). Outputs must equal the path without the big head tiles (DN_CONV_HEAD_BIG=0: grouped
+    launches) within the fp16 tolerance -- the reduction order of the two tilings differs."""
+    imgs = torch.from_numpy(synth.images(53, n, size, size)).cuda()
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DN_CONV_HEAD_BIG", flag)
+        m = _model(name, num_classes=21)
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        boxes, scores, labels, counts = m.forward_batch(imgs)
+        assert bool(torch.isfinite(scores).all()) and int(counts.min()) > 0 and int(labels.max()) <= 20
+    for q in (0, 1):
+        tol = LOGIT_ATOL + LOGIT_RTOL * res["0"][q].abs()
+        assert bool(((res["1"][q] - res["0"][q]).abs() <= tol).all()), q
+
+
+@pytest.mark.parametrize("name,n,size", [("ssd300_vgg16", 5, 300), ("ssd512_vgg16", 3, 512)])
+def test_vgg_without_workspace_reuse(name, n, size, monkeypatch):
+    """DN_WS_REUSE=0 (every tensor its own block: what tools/layer_errors.py runs with) gives every conv output an address, also the ones in
+    front of a fused max-pool: the conv + pool launch must pick its kernel by geometry, not by whether an output pointer exists (round-4 advice:
+    the forward failed on every VGG model). Same kernels, same arithmetic: bit-identical head outputs."""
+    imgs = torch.from_numpy(synth.images(59, n, size, size)).cuda()
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DN_WS_REUSE", flag)
+        m = _model(name, num_classes=91)
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
+@pytest.mark.parametrize("ncls,n,post", [(91, 64, {}), (91, 37, {}), (91, 3, {}), (91, 1, {}), (21, 9, {}),
+                                          (91, 5, {"score_thresh": 0.05, "detections_per_img": 100, "topk_candidates": 200}),
+                                          (91, 8, {"score_thresh": 1e-6})])
+def test_softmax_and_decode_in_the_head_launch_are_bit_identical(ncls, n, post, monkeypatch):
+    """Round 5 (headfuse.hip SM = true, DN_HEAD_SOFTMAX default 1): softmax over the classes, decode_single + clip and the score-histogram rows
+    (generalized_ssd.py:354,362-363; _utils.py:187-224) run in the epilogue of the fused head launch -- the logits never reach memory and
+    softmax_decode_kernel's launch is gone. Same arithmetic from the same accumulators (post_math.h is shared by both kernels), so the
+    detections -- boxes, scores, labels, counts -- equal the logit-writing path + softmax_decode_kernel BIT FOR BIT, and so does the cut-off
+    the histogram rows produce (the heaviest-first class order and tau only steer the work, but a wrong row table would show up as fallbacks
+    or missing candidates). Batch 64 (XCD grouping: 8 images per group, tiles spanning two images), 37 (two chains, ragged groups), 3 and 1
+    (plain mapping; the 1-pixel level's tile holds every image), K = 21 (126 channels per pixel: other row geometry), non-default thresholds
+    (a clamped / shifted histogram range)."""
+    import ctypes
+    from demonet_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    imgs = torch.from_numpy(synth.images(83, n, 320, 320)).cuda()
+    res, launches = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_HEAD_SOFTMAX", flag)
+        m = _model("ssdlite320_mobilenet_v3_large", num_classes=ncls, **post)
+        before = raw.dn_debug_head_softmax_launches()
+        res[flag] = [t.clone() for t in m.forward_batch(imgs)]
+        launches[flag] = raw.dn_debug_head_softmax_launches() - before
+        again = m.forward_batch(imgs)                       # graph replay
+        for x, y in zip(res[flag], again):
+            assert torch.equal(x, y)
+    assert launches["0"] == 0 and launches["1"] >= 1, launches
+    assert int(res["1"][3].min()) > 0
+    for q, what in enumerate(("boxes", "scores", "labels", "counts")):
+        assert torch.equal(res["0"][q], res["1"][q]), what
+
+
+def test_softmax_in_the_head_launch_feeds_the_same_cut_off(monkeypatch):
+    """The histogram rows of the fused epilogue (one per 32-pixel half tile and image, HistRows) must add up to the same per-image histogram and
+    per-class counts as softmax_decode_kernel's rows: tau and the class order are read back through the kept anchors' scores -- a forward whose
+    cut-off is too high flags images for the fallback, too low costs time only; so compare the kept-anchor lists of the two paths with the
+    fallback forced off-limits: DN_PP_FAST=1 results must equal DN_PP_FAST=0 (no cut-off at all) on both paths."""
+    imgs = torch.from_numpy(synth.images(89, 16, 320, 320)).cuda()
+    res = {}
+    for sm in ("0", "1"):
+        for fast in ("0", "1"):
+            monkeypatch.setenv("DN_HEAD_SOFTMAX", sm)
+            monkeypatch.setenv("DN_PP_FAST", fast)
+            m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+            res[sm, fast] = [t.clone() for t in m.forward_batch(imgs)]
+    for key in (("0", "1"), ("1", "0"), ("1", "1")):
+        for q in range(4):
+            assert torch.equal(res["0", "0"][q], res[key][q]), (key, q)

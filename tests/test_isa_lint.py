@@ -131,7 +131,7 @@ def test_fused_head_kernel_has_no_scratch_and_its_dma_is_counted(tmp_path):
     text = _asm("headfuse.hip", tmp_path)
     kernels, meta = _kernels(text)
     hf = {k: v for k, v in kernels.items() if "head_fused_kernel" in k}
-    assert len(hf) == 5
+    assert len(hf) == 10                # TCW = 1 .. 5, each with and without the softmax / decode epilogue
     for name, lines in hf.items():
         assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[name]), f"{name}: scratch"
         body = "\n".join(lines)
