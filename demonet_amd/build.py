@@ -72,6 +72,9 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    # a library that links but does not load (an unresolved kernel stub) must fail HERE, not on the GPU box
+    import ctypes
+    ctypes.CDLL(LIB)
     return LIB
 
 

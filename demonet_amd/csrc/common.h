@@ -200,6 +200,7 @@ struct HeadPost {
 struct HistRows {
     int levels = 0, rows_per_image = 0;
     int hw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sbase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, grouped[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int extra_base = 0, extra_rows = 0;      // + rows [extra_base, extra_base + extra_rows) of every image, all of them used (the softmax_decode_kernel tiles of the small levels)
 };
 inline int hist_rows_slots(int hw) { return (hw + 30) / 32 + 1; }
 // XCD grouping of a fused-head level (a group of xq images per workgroup residue mod 8) only where a group fills whole tiles
@@ -214,6 +215,7 @@ struct HeadFuseLevel {
     int nc[2];                       // output channels (anchors per location x classes, x 4)
     int n, H, W, C, act;             // act: the depthwise activation
     int aoff = 0, aloc = 0, sbase = 0;      // with a HeadPost: first anchor of the level, anchors per location, first histogram-row slot
+    int sm = 0;                             // with a HeadPost: 1 = this level's workgroups run the softmax / decode epilogue, 0 = they write logits
 };
 bool head_fused_level_supported(const HeadFuseLevel& l);
 bool head_fused_post_supported(const HeadFuseLevel* lv, int count, const HeadPost& post);
@@ -355,6 +357,7 @@ struct PostArgs {
     // tau_kernel reads the rows through this table
     bool scores_ready = false;
     HistRows hrows;
+    int small_first = -1;       // with scores_ready: first anchor still in logit form (the levels below 32 pixels per image); -1 / A: none
 };
 // where launch_postprocess keeps its arrays inside the workspace it is given (the fused head launch writes the first three itself)
 struct PostBuffers {

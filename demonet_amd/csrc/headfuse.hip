@@ -30,8 +30,11 @@
 // four lanes per row compute max / exp / sum exactly as softmax_decode_kernel does (post_math.h: same code, same bits), the scores leave
 // class-major -- a half tile's 32 x A_l rows are consecutive canonical anchors, 768-byte runs per class -- the boxes are decoded from the 4 A_l
 // regression channels, and the score histogram (+ per-class counts) of every (half tile, image) pair goes to a row of its own that tau_kernel
-// adds up (HistRows; no atomics in memory, nothing to clear). The fp32 logits (79 MB per 64 images) are neither written nor read back, and
-// softmax_decode_kernel's launch is gone. SM = false (dn_forward_heads, DN_HEAD_SOFTMAX=0) writes the logits as before.
+// adds up (HistRows; no atomics in memory, nothing to clear). The fp32 logits of these levels (73 of 79 MB per 64 images) are neither written nor
+// read back, and softmax_decode_kernel's launch is gone. Only the levels with >= 32 pixels per image take this epilogue (HeadFuseLevel::sm): a
+// workgroup with it lives ~85 us at batch 64 whatever its level, the launch is 543 workgroups on 512 residency slots, and late starters with the
+// epilogue were a 65 us tail. The small levels (7 % of the anchors) keep the plain logit epilogue, are launched last, and get their softmax in
+// the cut-off launch that follows (tau_kernel, TauSmall). SM = false (dn_forward_heads, DN_HEAD_SOFTMAX=0) writes every level's logits.
 #include <algorithm>
 #include <type_traits>
 
@@ -47,9 +50,14 @@ constexpr int HF_WOFF = HF_ZOFF + 64;             // 1 KB slot: the box head's d
 constexpr int HF_XS = HF_WOFF + 1024;             // bytes per x buffer: four planes + the zero slot + the weight slot
 constexpr int HF_BS = 4 * HF_P * 16;              // bytes per B tile (one head, one buffer)
 constexpr int HF_LDS = 2 * HF_XS + 4 * HF_BS;     // 18 560 + 16 384 B
-constexpr int HF_NP = 2;            // softmax epilogue: images per histogram window (a 32-pixel half tile of a level with >= 32 pixels touches at most 2)
+constexpr int HF_NP = 2;            // softmax epilogue: a 32-pixel half tile of a level with >= 32 pixels per image touches at most 2 images
 // LDS of the softmax epilogue: [32][nc0] + [32][nc1] fp32 rows, row sum / row offset / anchor tables of 256 entries, HF_NP histograms, 256 part bytes
-constexpr int hf_post_lds(int nc0, int nc1) { return 32 * (nc0 + nc1) * 4 + 3 * 256 * 4 + HF_NP * 256 * 4 + 256; }
+constexpr int hf_post_tabs(int nc0, int nc1) {       // (at least the main loop's buffers: what follows -- the biases -- is written while the loop runs)
+    const int t = 32 * (nc0 + nc1) * 4 + 3 * 256 * 4 + HF_NP * 256 * 4 + 256;
+    return t > HF_LDS ? t : HF_LDS;
+}
+// ... + both heads' biases (each padded to a multiple of 4 floats), copied in at the start of the workgroup behind everything the main loop uses
+constexpr int hf_post_lds(int nc0, int nc1) { return hf_post_tabs(nc0, nc1) + (((nc0 + 3) & ~3) + ((nc1 + 3) & ~3)) * 4; }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
@@ -73,6 +81,7 @@ struct HfLevel {
     int tiles;                       // 64-pixel tiles per XCD group; 0: this level uses the plain mapping (tiles of the whole level)
     int ct0;                         // channel tiles of the class head; the box head is tile ct0
     int aoff, aloc, sbase;           // softmax epilogue: first anchor of the level, anchors per location, first histogram-row slot (HistRows)
+    int sm;                          // this level's workgroups run the softmax epilogue (SM instantiations; levels with >= 32 pixels per image)
 };
 struct HfGroup {
     int count, xq;
@@ -101,6 +110,65 @@ __device__ __forceinline__ void hf_fma8v(float (&acc)[8], const u32x4& x, const 
     for (int i = 0; i < 4; ++i) {
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[2 * i]) : "v"(x[i]), "v"(w[i]));
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * i + 1]) : "v"(x[i]), "v"(w[i]));
+    }
+}
+
+// Scores of one histogram window: rows [ra, ra + wr) of the half tile, lying in at most HF_NP images. Wave w takes the classes w, w + 4, ...; per
+// class its lanes hold NB x 64 rows (rows beyond wr masked): NB independent read -> multiply -> store chains per class (the epilogue runs at two waves
+// per SIMD; everything per row -- LDS address, reciprocal of the row sum, byte offset of the score, histogram of its image -- sits in registers and
+// advances by constants). A store instruction writes 64 consecutive anchors of one class (256 contiguous bytes; rows are consecutive canonical
+// anchors). A class belongs to ONE wave, so its counts of passing scores are ballots added up in scalar registers and written once, no atomics.
+// The rows lie in at most two images (levels with >= 32 pixels per image).
+template <int NB>
+__device__ __forceinline__ void hf_scores(const HeadPost& P, const float* __restrict__ lg, const float* __restrict__ rowrcp, const unsigned* __restrict__ rowoff,
+                                          const unsigned* __restrict__ ranc, const unsigned char* __restrict__ rpart, unsigned* __restrict__ lhist,
+                                          const int ra, const int wr, const int w0, const int wq0, const int wave, const int lane, const int Km1, const int ccb) {
+    unsigned eo[NB], ob4[NB], hb[NB];       // (LDS element index, not a pointer: a pointer array loses the LDS address space and turns into flat loads)
+    float rinv[NB];
+    bool ok[NB];
+    unsigned long long q1m[NB];             // lanes whose row lies in the half tile's second image (wave-uniform mask: the per-class counts are scalar work)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        ok[b] = 64 * b + lane < wr;
+        const int row = ra + (ok[b] ? 64 * b + lane : 0);
+        eo[b] = rowoff[row] + 1u + (unsigned)wave;
+        rinv[b] = rowrcp[row];
+        const int q = (int)rpart[row] - wq0;
+        q1m[b] = __ballot(q != 0);
+        hb[b] = (unsigned)q * 256u;
+        ob4[b] = (((unsigned)(w0 + q) * (unsigned)Km1 + (unsigned)wave) * (unsigned)P.A + ranc[row]) * 4u;      // (host: n (K - 1) A < 2^30)
+    }
+    const unsigned step4 = 16u * (unsigned)P.A;             // bytes between class k and class k + 4
+    char* const sbase = reinterpret_cast<char*>(P.scoresT);
+    // software-pipelined: the LDS reads of class k + 4 are issued before the stores / histogram atomics of class k (LDS operations are ordered:
+    // behind the atomics every read would wait for them, and a lone wave per SIMD has nothing else to run)
+    float cur[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) cur[b] = lg[eo[b]];
+    for (int k1 = wave; k1 < Km1; k1 += 4) {
+        float sc[NB], nxt[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            eo[b] += (k1 + 4 < Km1) ? 4u : 0u;             // (the last iteration re-reads its own element)
+            nxt[b] = lg[eo[b]];
+            sc[b] = pp_score(cur[b], rinv[b]);
+        }
+        int c_all = 0, c_1 = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (ok[b]) *reinterpret_cast<float*>(sbase + ob4[b]) = sc[b];
+            ob4[b] += step4;
+            const bool pass = ok[b] && sc[b] > P.score_thr;
+            if (pass) atomicAdd(&lhist[hb[b] + (unsigned)pp_hist_bin(sc[b], P.hb0, P.nb)], 1u);
+            const unsigned long long pm = __ballot(pass);
+            c_all += __popcll(pm);
+            c_1 += __popcll(pm & q1m[b]);
+            cur[b] = nxt[b];
+        }
+        if (ccb >= 0 && lane == 0) {
+            lhist[ccb + k1] = (unsigned)(c_all - c_1);
+            lhist[256 + ccb + k1] = (unsigned)c_1;
+        }
     }
 }
 
@@ -233,6 +301,14 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
     const long long st_begin = (long long)__builtin_amdgcn_s_memtime();
     const long long st_begin_rt = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    if constexpr (SM) if (L.sm) {
+        // both heads' biases -> LDS (the epilogue adds them to 64 x 570 accumulators; read from memory there, their latency was exposed in front of
+        // its first barrier). Published by the barrier below, far from the buffers of the main loop.
+        float* const lb = reinterpret_cast<float*>(hf_lds + hf_post_tabs(L.nc[0], L.nc[1]));
+        const int p0 = (L.nc[0] + 3) & ~3;
+        for (int i = tid; i < L.nc[0]; i += 256) lb[i] = L.bias[0][i];
+        if (tid < L.nc[1]) lb[p0 + tid] = L.bias[1][tid];
+    }
     stage_x(0);
     load_w0(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -327,14 +403,16 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
 #ifdef DN_DEV_STAMPS
     const long long st_end_loop = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (SM) {
+    // the lane's coordinates for the epilogues. SM instantiations take them from threadIdx.x again, opaque to value numbering: otherwise hipcc keeps
+    // the main loop's copies alive across it for the epilogue -- registers the 256-register budget at TCW = 5 does not have (a spill; the lint
+    // refuses scratch in this kernel)
+    int te = threadIdx.x;
+    if constexpr (SM) asm volatile("" : "+v"(te));
+    const int lane_e = SM ? (te & 63) : lane, r_e = SM ? (lane_e & 31) : r, hh_e = SM ? (lane_e >> 5) : hh;
+    if constexpr (SM) if (L.sm) {
         // ---- softmax + decode epilogue (file header). Lane (r, hh) holds pixel r of each pixel tile and channels 8 g + 4 hh .. + 3 of each channel tile.
         const HeadPost& P = g.post;
-        // the lane's coordinates again from threadIdx.x, opaque to value numbering: otherwise hipcc keeps the main loop's copies alive for
-        // the epilogue -- one register too many at TCW = 5 (a spill; and the lint refuses scratch in this kernel)
-        int te = threadIdx.x;
-        asm volatile("" : "+v"(te));
-        const int lane = te & 63, r = lane & 31, hh = lane >> 5;
+        const int lane = lane_e, r = r_e, hh = hh_e;
         const int K = P.K, Km1 = K - 1, AL = L.aloc, NC0 = L.nc[0], NC1 = L.nc[1], hw = L.hw;
         float* const lg = reinterpret_cast<float*>(hf_lds);                        // [32][NC0] logits, then exp(x - max)
         float* const rgt = lg + 32 * NC0;                                           // [32][NC1] box regressions
@@ -348,10 +426,14 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
         const int img_g0 = grouped ? (flat & 7) * g.xq : 0;                         // first image / pixel of this workgroup's XCD group (plain mapping: 0)
         const int r0 = img_g0 * hw;
         __syncthreads();            // every wave is done with the x runs and B tiles: the LDS belongs to the epilogue now
+#ifdef DN_DEV_STAMPS
+        long long st_w = 0, st_s = 0, st_p = 0;
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int mj = m0 + 32 * j;
             if (mj >= mend) break;
+            HF_T(se0);
             const int npx = min(32, mend - mj), nrows = npx * AL;
             const int img_first = mj / hw, img_last = (mj + npx - 1) / hw;
             // (W) accumulators + bias -> [pixel][channel] rows (float2 pieces: a row starts at an 8-byte boundary, nc is even)
@@ -361,14 +443,14 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
                 if (i == TCW - 1 && !last_on) break;
                 const int ct = reg ? 0 : wave + 4 * i;
                 const int nc = reg ? NC1 : NC0;
-                const float* bias = reg ? L.bias[1] : L.bias[0];
+                const float* bias = reinterpret_cast<const float*>(hf_lds + hf_post_tabs(NC0, NC1)) + (reg ? ((NC0 + 3) & ~3) : 0);      // (LDS copy)
                 float* drow = (reg ? rgt : lg) + r * nc;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int ch = 32 * ct + 8 * gq + 4 * hh;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] + bias[min(ch + e, nc - 1)];
+                    // (a group of four is one 16-byte LDS read; the pad behind a head's last channel is never stored)
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + min(ch, ((nc + 3) & ~3) - 4));
+                    const float v[4] = {acc[i][j][4 * gq] + b4.x, acc[i][j][4 * gq + 1] + b4.y, acc[i][j][4 * gq + 2] + b4.z, acc[i][j][4 * gq + 3] + b4.w};
                     if (ch + 4 <= nc) {
                         *reinterpret_cast<float2*>(drow + ch) = make_float2(v[0], v[1]);
                         *reinterpret_cast<float2*>(drow + ch + 2) = make_float2(v[2], v[3]);
@@ -389,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
                 rpart[te] = (unsigned char)(bx_img - img_first);
             }
             __syncthreads();
+            HF_T(se1);
             // (B) decode_single + clip of the row's box (_utils.py:187-224): the anchor load is in flight under the softmax
             if (te < nrows) {
                 const float4 rg4 = *reinterpret_cast<const float4*>(rgt + bx_px * NC1 + bx_a * 4);
@@ -400,67 +483,50 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
                 const int row = rb + (te >> 2);
                 const bool valid = row < nrows;
                 const float sm = pp_softmax_row(lg + (valid ? rowoff[row] : 0u), K, te & 3, valid);
-                if (valid && (te & 3) == 0) rowsum[row] = sm;
+                if (valid && (te & 3) == 0) rowsum[row] = pp_row_rcp(sm);      // (the reciprocal: scores are e * (1 / sum), post_math.h)
             }
             __syncthreads();
-            // (P) scores out, class-major, + histogram rows: windows of HF_NP images (one window on every level with >= 32 pixels per image)
-            for (int w0 = img_first; w0 <= img_last; w0 += HF_NP) {
-                const int pa = max(mj, w0 * hw) - mj, pb = min(mj + npx, (w0 + HF_NP) * hw) - mj;
-                const int ra = pa * AL, wr = (pb - pa) * AL;
-                for (int t = te; t < HF_NP * 256; t += 256) lhist[t] = 0u;
-                __syncthreads();
-                if ((wr & 63) == 0) {
-                    // a wave = 64 consecutive rows of ONE class: 256-byte runs per store instruction, class counts by ballot
-                    const int nb64 = wr >> 6;
-                    int k1 = 0, b = wave;
-                    while (b >= nb64) { b -= nb64; ++k1; }
-                    while (k1 < Km1) {
-                        const int row = ra + (b << 6) + lane;
-                        const float sc = pp_score(lg[rowoff[row] + k1 + 1], rowsum[row]);
-                        const int q = (int)rpart[row] - (w0 - img_first);
-                        P.scoresT[((size_t)(w0 + q) * Km1 + k1) * P.A + ranc[row]] = sc;
-                        const bool pass = sc > P.score_thr;
-                        if (pass) atomicAdd(&lhist[q * 256 + pp_hist_bin(sc, P.hb0, P.nb)], 1u);
-                        if (ccb >= 0) {
-#pragma unroll
-                            for (int qq = 0; qq < HF_NP; ++qq) {
-                                const int c = __popcll(__ballot(pass && q == qq));
-                                if (lane == 0 && c) atomicAdd(&lhist[qq * 256 + ccb + k1], (unsigned)c);
-                            }
-                        }
-                        b += 4;
-                        while (b >= nb64) { b -= nb64; ++k1; }
-                    }
-                } else {
-                    // ragged or small window (levels with fewer than 32 pixels per image, the last tile of a range): rows fastest, classes slow
-                    for (int idx = te; idx < Km1 * wr; idx += 256) {
-                        const int k1 = idx / wr;
-                        const int row = ra + idx - k1 * wr;
-                        const float sc = pp_score(lg[rowoff[row] + k1 + 1], rowsum[row]);
-                        const int q = (int)rpart[row] - (w0 - img_first);
-                        P.scoresT[((size_t)(w0 + q) * Km1 + k1) * P.A + ranc[row]] = sc;
-                        if (sc > P.score_thr) {
-                            atomicAdd(&lhist[q * 256 + pp_hist_bin(sc, P.hb0, P.nb)], 1u);
-                            if (ccb >= 0) atomicAdd(&lhist[q * 256 + ccb + k1], 1u);
-                        }
-                    }
-                }
-                __syncthreads();
-                // this (half tile, image) pair's row: slot = half tiles of the range between the image's first one and this one
-#pragma unroll
-                for (int qq = 0; qq < HF_NP; ++qq) {
-                    const int img = w0 + qq;
-                    if (img <= img_last) {
-                        const int slot = ((mj - r0) >> 5) - (((img - img_g0) * hw) >> 5);
-                        P.hrows[((size_t)img * P.rows_per_image + L.sbase + slot) * 256 + te] = (te < P.nb + (ccb >= 0 ? Km1 : 0)) ? lhist[qq * 256 + te] : 0u;
-                    }
-                }
-                __syncthreads();    // (the next window / half tile rewrites the tables)
+            HF_T(se2);
+            // (P) scores out, class-major, + histogram rows
+            for (int t = te; t < HF_NP * 256; t += 256) lhist[t] = 0u;
+            __syncthreads();
+            {
+                const int nb64 = (nrows + 63) >> 6;
+                if (nb64 == 1) hf_scores<1>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
+                else if (nb64 == 2) hf_scores<2>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
+                else if (nb64 == 3) hf_scores<3>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
+                else hf_scores<4>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
             }
+            __syncthreads();
+            // the rows of this half tile's (at most two) images: slot = half tiles of the range between the image's first one and this one
+#pragma unroll
+            for (int qq = 0; qq < HF_NP; ++qq) {
+                const int img = img_first + qq;
+                if (img <= img_last) {
+                    const int slot = ((mj - r0) >> 5) - (((img - img_g0) * hw) >> 5);
+                    P.hrows[((size_t)img * P.rows_per_image + L.sbase + slot) * 256 + te] = (te < P.nb + (ccb >= 0 ? Km1 : 0)) ? lhist[qq * 256 + te] : 0u;
+                }
+            }
+            __syncthreads();        // (the next half tile rewrites the rows and tables)
+#ifdef DN_DEV_STAMPS
+            const long long se3 = (long long)__builtin_amdgcn_s_memtime();
+            st_w += se1 - se0; st_s += se2 - se1; st_p += se3 - se2;
+#endif
         }
+#ifdef DN_DEV_STAMPS
+        if (g.stamps && te == 0) {
+            long long* sp = g.stamps + (size_t)blockIdx.x * 16;
+            sp[8] = st_begin_rt;
+            sp[9] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+            sp[10] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+            sp[0] = st_loop - st_begin; sp[1] = st_dw; sp[2] = st_wait; sp[3] = st_mm; sp[4] = st_end_loop - st_loop;
+            sp[5] = (long long)__builtin_amdgcn_s_memtime() - st_end_loop; sp[6] = NCH; sp[7] = (long long)__builtin_amdgcn_s_memrealtime();
+            sp[11] = st_w; sp[12] = st_s; sp[13] = st_p;
+        }
+#endif
         return;
     }
-    // ---- epilogue: straight from the accumulators. Lane (r, hh) holds pixel r of each pixel tile and channels 8 g + 4 hh .. + 3 of each channel
+    // ---- epilogue: straight from the accumulators. Lane (r_e, hh_e) holds pixel r_e of each pixel tile and channels 8 g + 4 hh_e .. + 3 of each channel
     // tile in registers 4 g .. 4 g + 3: one 16-byte store per (tile, g) -- the two half waves write adjacent pieces, 32 contiguous bytes per
     // pixel and instruction. (Through a per-wave LDS slab as row-contiguous float2 runs it was 80 dependent LDS round trips per wave: 20 000
     // cycles of a 100 000-cycle workgroup.) Rows are 8-byte aligned only (nc * 4 B = 2184): global_store_dwordx4 needs dword alignment.
@@ -468,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
     bool rok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int m = m0 + 32 * j + r;
+        const int m = m0 + 32 * j + r_e;
         const int img = m / L.hw, pix = m - img * L.hw;
         rok[j] = m < mend;
 #pragma unroll
@@ -486,13 +552,13 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[4 * gq + e] = bias[min(32 * ct + 8 * gq + 4 * hh + e, nc - 1)];
+            for (int e = 0; e < 4; ++e) bv[4 * gq + e] = bias[min(32 * ct + 8 * gq + 4 * hh_e + e, nc - 1)];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float* orow = outp + (reg ? ro[1][j] : ro[0][j]);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int ch = 32 * ct + 8 * gq + 4 * hh;
+                const int ch = 32 * ct + 8 * gq + 4 * hh_e;
                 floatx4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] + bv[4 * gq + e];
@@ -505,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
     }
 #ifdef DN_DEV_STAMPS
     if (g.stamps && tid == 0) {
-        long long* sp = g.stamps + (size_t)blockIdx.x * 12;
+        long long* sp = g.stamps + (size_t)blockIdx.x * 16;
         sp[8] = st_begin_rt;
         sp[9] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
         sp[10] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
@@ -541,17 +607,19 @@ extern "C" __attribute__((visibility("default"))) int dn_debug_head_softmax_laun
 
 bool head_fused_post_supported(const HeadFuseLevel* lv, int count, const HeadPost& post) {
     if (!post.scoresT || !post.boxes || !post.hrows || !post.anchors || post.K < 2 || post.A < 1 || post.nb < 1 || post.nb > 256) return false;
-    int rows = 0, anchors = 0;
+    int rows = 0, nsm = 0;
     for (int i = 0; i < count; ++i) {
         const HeadFuseLevel& l = lv[i];
+        if (!l.sm) continue;
+        ++nsm;
+        if (l.H * l.W < 32) return false;                                                                       // (a half tile of such a level spans more than two images)
         if (l.aloc < 1 || l.aloc > 8 || l.nc[0] != l.aloc * post.K || l.nc[1] != 4 * l.aloc) return false;       // 32 pixels x aloc rows fit the 256-entry tables
         if (hf_post_lds(l.nc[0], l.nc[1]) > 80 * 1024) return false;                                            // two workgroups per CU stay resident
         if (l.sbase != rows) return false;
         rows += hist_rows_slots(l.H * l.W);
-        anchors += l.H * l.W * l.aloc;
-        if ((unsigned long long)l.n * (post.K - 1) * post.A >= 0x7fffffffull) return false;
+        if ((unsigned long long)l.n * (post.K - 1) * post.A >= 0x3fffffffull) return false;       // byte offsets of the scores in 32 bits
     }
-    return rows == post.rows_per_image && anchors <= post.A;
+    return nsm > 0 && rows <= post.rows_per_image;      // (rows behind these belong to the softmax tiles of the logit-writing levels)
 }
 
 int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s, const HeadPost* post) {
@@ -562,12 +630,22 @@ int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s,
     if (post) {
         DN_REQUIRE(head_fused_post_supported(lv, count, *post), "fused heads: softmax epilogue not supported for these levels");
         g.post = *post;
-        for (int i = 0; i < count; ++i) lds = std::max(lds, hf_post_lds(lv[i].nc[0], lv[i].nc[1]));
+        for (int i = 0; i < count; ++i)
+            if (lv[i].sm) lds = std::max(lds, hf_post_lds(lv[i].nc[0], lv[i].nc[1]));
     }
+    // Launch order: the levels with the softmax epilogue first, longest reduction first (their workgroups live longest); the small, logit-writing
+    // levels last -- they are the ones that may start late (543 workgroups on 512 residency slots at batch 64) and they are short.
+    int ord[8];
+    for (int i = 0; i < count; ++i) ord[i] = i;
+    if (post)
+        std::stable_sort(ord, ord + count, [&](int x, int y) {
+            if (lv[x].sm != lv[y].sm) return lv[x].sm > lv[y].sm;
+            return lv[x].sm ? lv[x].C > lv[y].C : false;
+        });
     int acc = 0, tcw = 0;
     for (int i = 0; i < count; ++i) {
-        const HeadFuseLevel& l = lv[i];
-        DN_REQUIRE(head_fused_level_supported(l), "fused heads: level %d unsupported (C=%d W=%d nc=%d/%d)", i, l.C, l.W, l.nc[0], l.nc[1]);
+        const HeadFuseLevel& l = lv[ord[i]];
+        DN_REQUIRE(head_fused_level_supported(l), "fused heads: level %d unsupported (C=%d W=%d nc=%d/%d)", ord[i], l.C, l.W, l.nc[0], l.nc[1]);
         HfLevel& d = g.lv[i];
         d.x = l.x; d.wd = l.wdg; d.wslot = l.wslot;
         for (int h = 0; h < 2; ++h) {
@@ -578,7 +656,7 @@ int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s,
         }
         d.H = l.H; d.W = l.W; d.C = l.C; d.hw = l.H * l.W; d.m = l.n * d.hw; d.act = l.act;
         d.ct0 = dn_cdiv(l.nc[0], 32);
-        d.aoff = l.aoff; d.aloc = l.aloc; d.sbase = l.sbase;
+        d.aoff = l.aoff; d.aloc = l.aloc; d.sbase = l.sbase; d.sm = post ? l.sm : 0;
         const int t4 = dn_cdiv(d.ct0 + 1, 4);
         DN_REQUIRE(i == 0 || t4 == tcw, "fused heads: levels differ in channel tiles per wave (%d vs %d)", t4, tcw);
         tcw = t4;
@@ -600,10 +678,12 @@ int launch_head_fused(const HeadFuseLevel* lv, int count, int xq, hipStream_t s,
     const dim3 grid(acc), block(256);
 #define HF_GO(T)                                                                                                            \
     if (post) {                                                                                                             \
-        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(head_fused_kernel<T, true>), 80 * 1024));               \
+        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(head_fused_kernel<T, true>), 160 * 1024));               \
         hipLaunchKernelGGL((head_fused_kernel<T, true>), grid, block, lds, s, g);                                           \
-    } else                                                                                                                  \
-        hipLaunchKernelGGL((head_fused_kernel<T, false>), grid, block, lds, s, g)
+    } else {                                                                                                                \
+        if (lds > 64 * 1024) DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(head_fused_kernel<T, false>), 160 * 1024)); \
+        hipLaunchKernelGGL((head_fused_kernel<T, false>), grid, block, lds, s, g);                                          \
+    }
     switch (tcw) {
         case 1: HF_GO(1); break;
         case 2: HF_GO(2); break;

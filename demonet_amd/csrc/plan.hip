@@ -781,6 +781,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
     // set by launch_heads when the fused head launch also ran softmax + decode (headfuse.hip, SM): the post-process starts at the cut-off
     bool scores_ready = false;
     HistRows fused_rows;
+    int small_first = -1;
     // head launches of the pyramid levels [lv0, lv1): the depthwise group, then the 1x1 / dense group(s), on stream hs
     auto launch_heads = [&](int lv0, int lv1, hipStream_t hs, bool rec, size_t& seg) -> int {
         int rc = DN_OK;
@@ -849,20 +850,34 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                     hp.scoresT = pb.scoresT; hp.boxes = pb.boxes; hp.hrows = pb.phist; hp.anchors = p->anchors_dev;
                     hp.A = d.num_anchors; hp.K = d.num_classes;
                     hp.img_w = (float)d.image_w; hp.img_h = (float)d.image_h; hp.score_thr = d.score_thresh;
+                    // the levels with >= 32 pixels per image take the epilogue; they must be a prefix of the anchor axis (the rest -- anchors
+                    // [small_first, A) -- gets its softmax in the cut-off launch, from the logits this launch writes for them)
                     HistRows hr;
-                    hr.levels = nl;
-                    int rows = 0;
+                    int rows = 0, nsm = 0;
+                    bool prefix = true;
                     for (int q = 0; q < nl; ++q) {
                         const int level = p->ops[members[4 * q + 2]].level;
                         fl[q].aoff = p->level_off[level];
                         fl[q].aloc = fl[q].nc[0] / d.num_classes;
-                        fl[q].sbase = rows;
-                        hr.hw[q] = fl[q].H * fl[q].W; hr.sbase[q] = rows; hr.grouped[q] = head_fused_grouped(xq, hr.hw[q]) ? 1 : 0;
-                        rows += hist_rows_slots(hr.hw[q]);
+                        fl[q].sm = fl[q].H * fl[q].W >= 32 ? 1 : 0;
+                        if (fl[q].sm) {
+                            prefix = prefix && nsm == q && (q == 0 ? fl[q].aoff == 0 : fl[q].aoff == fl[q - 1].aoff + fl[q - 1].H * fl[q - 1].W * fl[q - 1].aloc);
+                            fl[q].sbase = rows;
+                            hr.hw[nsm] = fl[q].H * fl[q].W; hr.sbase[nsm] = rows; hr.grouped[nsm] = head_fused_grouped(xq, hr.hw[nsm]) ? 1 : 0;
+                            rows += hist_rows_slots(hr.hw[nsm]);
+                            ++nsm;
+                        }
                     }
-                    hr.rows_per_image = hp.rows_per_image = rows;
-                    with_post = rows <= pb.tiles && head_fused_post_supported(fl, nl, hp);
-                    if (with_post) { scores_ready = true; fused_rows = hr; }
+                    hr.levels = nsm;
+                    hr.rows_per_image = rows;
+                    // (the softmax tiles of the small levels put their histogram rows behind these: the row stride of an image covers both)
+                    const int sfirst = nsm < nl ? fl[nsm].aoff : d.num_anchors;
+                    hp.rows_per_image = rows + dn_cdiv(d.num_anchors - sfirst, 64);
+                    with_post = prefix && nsm > 0 && hp.rows_per_image <= pb.tiles && head_fused_post_supported(fl, nl, hp);
+                    if (with_post) {
+                        scores_ready = true; fused_rows = hr;
+                        small_first = sfirst;
+                    }
                 }
                 rc = launch_head_fused(fl, nl, xq, hs, with_post ? &hp : nullptr);
                 if (rc != DN_OK) return rc;
@@ -1133,7 +1148,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.packed = packed;
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         a.xq = xq;
-        a.scores_ready = scores_ready; a.hrows = fused_rows;
+        a.scores_ready = scores_ready; a.hrows = fused_rows; a.small_first = small_first;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
         if (rc) return rc;

@@ -44,25 +44,16 @@ constexpr int HBINS = DN_PP_HBINS;                       // bins kept: the top 2
 // ------------------------------------------------------------------------------------------------------------
 // P1
 // ------------------------------------------------------------------------------------------------------------
+// One tile of 64 anchors [a0, a0 + na) of image n: softmax over the classes, scores out class-major, score histogram + per-class counts of the
+// passing scores ADDED to lhist (the caller zeroes and flushes it), boxes decoded. tile: [64][K] floats + rowsum[64] of LDS. Ends with its LDS
+// reads done only after the caller's next barrier.
 template <bool PERM>      // PERM: scores stored anchor-major within a level (PostLevels); false: canonical order, no index code at all
-__global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __restrict__ logits, const float* __restrict__ reg,
-                                                            const float* __restrict__ anchors, float* __restrict__ scoresT,
-                                                            float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
-                                                            float score_thr, unsigned* __restrict__ phist, int hb0, int nb,
-                                                            long long* __restrict__ stamps, int nimg, int tiles, int xq, PostLevels lv) {
-    extern __shared__ float tile[];            // [64][K] then rowsum[64] then hist[HBINS]
-    float* rowsum = tile + 64 * K;
-    unsigned* lhist = reinterpret_cast<unsigned*>(rowsum + 64);
-    __shared__ int pidx[64];                   // stored (anchor-major within the level) index of the tile's anchors
-    // only bins [hb0, hb0 + nb) can be hit: scores lie in (score_thr, 1] (161 bins for score_thr = 0.001; nb <= HBINS)
-    // bins [nb, nb + K-1), when they fit the 256-entry row, count each class's passing scores: tau_kernel ranks the classes by them
-    const int ccb = (nb + K - 1 <= HBINS) ? nb : -1;
-    if (threadIdx.x < nb + (ccb >= 0 ? K - 1 : 0)) lhist[threadIdx.x] = 0u;
+__device__ __forceinline__ void softmax_decode_tile(float* __restrict__ tile, float* __restrict__ rowsum, unsigned* __restrict__ lhist, int* __restrict__ pidx,
+                                                    const float* __restrict__ logits, const float* __restrict__ reg, const float* __restrict__ anchors,
+                                                    float* __restrict__ scoresT, float4* __restrict__ boxes, const int A, const int K, const float img_w,
+                                                    const float img_h, const float score_thr, const int hb0, const int nb, const int ccb,
+                                                    long long* __restrict__ stamps, const int n, const int a0, const PostLevels& lv) {
     const int tid = threadIdx.x;
-    int n, atile;                              // flat grid [image slot][anchor tile] (XCD grouping: common.h)
-    if (!xcd_image_of(blockIdx.x, tiles, xq, nimg, n, atile)) return;
-    const int a0 = atile * 64;
-    PP_STAMP(8);
     const int na = min(64, A - a0);
     constexpr bool ident = !PERM;
     if (!ident && tid < 64) pidx[tid] = post_perm(lv, min(a0 + tid, A - 1));      // (visible after the barrier behind the tile load)
@@ -100,7 +91,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     {
         const int row = tid >> 2, sub = tid & 3;
         const float sm = pp_softmax_row(tile + row * K, K, sub, row < na);
-        if (sub == 0) rowsum[row] = sm;
+        if (sub == 0) rowsum[row] = pp_row_rcp(sm);       // (the reciprocal: scores are e * (1 / sum), post_math.h)
     }
     __syncthreads();
     PP_STAMP(10);
@@ -114,21 +105,44 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
             pass = sc > score_thr;
             if (pass) atomicAdd(&lhist[pp_hist_bin(sc, hb0, nb)], 1u);
         }
-        // a wave's 64 lanes hold the 64 anchors of ONE class per iteration, and no other wave or iteration sees that class
+        // a wave's 64 lanes hold the 64 anchors of ONE class per iteration, and no other wave or iteration of this tile sees that class
         const unsigned long long m = __ballot(pass);
-        if (ccb >= 0 && a == 0) lhist[ccb + k - 1] = (unsigned)__popcll(m);
+        if (ccb >= 0 && a == 0) lhist[ccb + k - 1] += (unsigned)__popcll(m);
     }
-    __syncthreads();
-    PP_STAMP(11);
-    // this workgroup's histogram goes to its own row; tau_kernel adds the rows. (Device-scope atomics into one per-image table
-    // made a few workgroups per launch wait 15-25 us on the hot bins: the kernel's whole tail.)
-    phist[(((size_t)n * tiles + atile) << 8) + threadIdx.x] = (threadIdx.x < nb + (ccb >= 0 ? Km1 : 0)) ? lhist[threadIdx.x] : 0u;
     if (tid < na) {
         const int a = a0 + tid;
         const float4 rg = reinterpret_cast<const float4*>(reg)[(size_t)n * A + a];
         const float4 an = reinterpret_cast<const float4*>(anchors)[a];
         boxes[(size_t)n * A + a] = pp_decode_box(rg, an, img_w, img_h);
     }
+}
+
+template <bool PERM>
+__global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __restrict__ logits, const float* __restrict__ reg,
+                                                            const float* __restrict__ anchors, float* __restrict__ scoresT,
+                                                            float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
+                                                            float score_thr, unsigned* __restrict__ phist, int hb0, int nb,
+                                                            long long* __restrict__ stamps, int nimg, int tiles, int xq, PostLevels lv,
+                                                            int a_base, int row_stride, int row_base) {
+    // the launch covers the anchors [a_base, a_base + 64 tiles) of every image; a tile's histogram goes to row row_base + tile of the image's row_stride rows
+    extern __shared__ float tile[];            // [64][K] then rowsum[64] then hist[HBINS]
+    float* rowsum = tile + 64 * K;
+    unsigned* lhist = reinterpret_cast<unsigned*>(rowsum + 64);
+    __shared__ int pidx[64];                   // stored (anchor-major within the level) index of the tile's anchors
+    // only bins [hb0, hb0 + nb) can be hit: scores lie in (score_thr, 1] (161 bins for score_thr = 0.001; nb <= HBINS)
+    // bins [nb, nb + K-1), when they fit the 256-entry row, count each class's passing scores: tau_kernel ranks the classes by them
+    const int ccb = (nb + K - 1 <= HBINS) ? nb : -1;
+    if (threadIdx.x < nb + (ccb >= 0 ? K - 1 : 0)) lhist[threadIdx.x] = 0u;
+    const int tid = threadIdx.x;
+    int n, atile;                              // flat grid [image slot][anchor tile] (XCD grouping: common.h)
+    if (!xcd_image_of(blockIdx.x, tiles, xq, nimg, n, atile)) return;
+    PP_STAMP(8);
+    softmax_decode_tile<PERM>(tile, rowsum, lhist, pidx, logits, reg, anchors, scoresT, boxes, A, K, img_w, img_h, score_thr, hb0, nb, ccb, stamps, n, a_base + atile * 64, lv);
+    __syncthreads();
+    PP_STAMP(11);
+    // this workgroup's histogram goes to its own row; tau_kernel adds the rows. (Device-scope atomics into one per-image table
+    // made a few workgroups per launch wait 15-25 us on the hot bins: the kernel's whole tail.)
+    phist[(((size_t)n * row_stride + row_base + atile) << 8) + threadIdx.x] = (threadIdx.x < nb + (ccb >= 0 ? K - 1 : 0)) ? lhist[threadIdx.x] : 0u;
     PP_STAMP(12);
 }
 
@@ -583,6 +597,7 @@ __global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ p
                 for (int u = 0; u < 8; ++u) s += (t0 + u < cnt) ? v[u] : 0u;
             }
         }
+        for (int t = 0; t < hr.extra_rows; ++t) s += h[(size_t)(hr.extra_base + t) << 8];
     }
     part[tid] = s;
     __syncthreads();
@@ -1025,9 +1040,16 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     const int tiles = pb.tiles;
     unsigned* const phist = pb.phist; unsigned* const tauKey = pb.tauKey;
     int* const needFull = pb.needFull; int* const order = pb.order; int* const fbcnt = pb.fbcnt;
+    HistRows hrows = a.scores_ready ? a.hrows : HistRows{};
+    const bool small = a.scores_ready && a.small_first >= 0 && a.small_first < a.A;      // the levels the head launch left in logit form
+    const int small_tiles = small ? dn_cdiv(a.A - a.small_first, 64) : 0;
     if (a.scores_ready) {
-        DN_REQUIRE(a.hrows.levels >= 1 && a.hrows.levels <= 8 && a.hrows.rows_per_image <= tiles && a.lv.n == 1 && a.lv.aloc[0] == 1,
-                   "postprocess: scores from the head launch need a histogram-row table that fits (%d rows per image, %d available)", a.hrows.rows_per_image, tiles);
+        DN_REQUIRE(hrows.levels >= 1 && hrows.levels <= 8 && a.lv.n == 1 && a.lv.aloc[0] == 1, "postprocess: scores from the head launch need a histogram-row table");
+        hrows.extra_base = hrows.rows_per_image;
+        hrows.extra_rows = small_tiles;
+        hrows.rows_per_image += small_tiles;
+        DN_REQUIRE(hrows.rows_per_image <= tiles, "postprocess: %d histogram rows per image, %d available", hrows.rows_per_image, tiles);
+        DN_REQUIRE(!small || (a.logits && a.reg), "postprocess: the small levels arrive as logits: null logits / regressions");
     }
 
     const int fast = dn_knob("DN_PP_FAST", 1);
@@ -1045,22 +1067,29 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)HBINS * sizeof(unsigned);
     const int slots = xcd_image_slots(a.xq, a.n);
     const int hist_rows = tiles;    // per-image rows of the histogram table tau_kernel adds up
-    if (!a.scores_ready) {
+    {
+        // every anchor (plain path), or the anchors [small_first, A) the fused head launch left in logit form: a few tiles per image, their histogram
+        // rows behind the head launch's rows
         const long long* const stp = pp_env("DN_PP_STAMP_SOFTMAX", 0) ? g_pp_stamps : nullptr;
-        if (!(a.lv.n == 1 && a.lv.aloc[0] == 1))
-            hipLaunchKernelGGL(softmax_decode_kernel<true>, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
-                               a.n, tiles, a.xq, a.lv);
-        else
-            hipLaunchKernelGGL(softmax_decode_kernel<false>, dim3(tiles * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
-                               scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
-                               a.n, tiles, a.xq, a.lv);
+        const int t1 = a.scores_ready ? small_tiles : tiles, abase = a.scores_ready ? a.small_first : 0;
+        const int rstride = a.scores_ready ? hrows.rows_per_image : tiles, rbase = a.scores_ready ? hrows.extra_base : 0;
+        if (t1 > 0) {
+            if (!(a.lv.n == 1 && a.lv.aloc[0] == 1))
+                hipLaunchKernelGGL(softmax_decode_kernel<true>, dim3(t1 * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
+                                   scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
+                                   a.n, t1, a.xq, a.lv, abase, rstride, rbase);
+            else
+                hipLaunchKernelGGL(softmax_decode_kernel<false>, dim3(t1 * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
+                                   scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
+                                   a.n, t1, a.xq, a.lv, abase, rstride, rbase);
+        }
     }
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
-    if (fast) {
+    if (fast)
         hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, hist_rows, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq,
-                           nb, (int)Km1, order, fbcnt, a.scores_ready ? a.hrows : HistRows{});
+                           nb, (int)Km1, order, fbcnt, hrows);
+    if (fast) {
         const int* ord = dn_knob("DN_PP_ORDER", 1) ? order : nullptr;      // heaviest classes first (0: class order)
         if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else if (nw <= 2) rc = launch_p2_fast<2>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);

@@ -24,25 +24,27 @@ m = models.load_synthetic(models.ssdlite320_mobilenet_v3_large(num_classes=91), 
 m.set_graph_mode(False) if hasattr(m, "set_graph_mode") else None
 os.environ["DN_GRAPH"] = "0"
 imgs = torch.from_numpy(synth.images(5, n, 320, 320)).cuda()
-m.forward_heads(imgs)
+fwd = (lambda: m.forward_batch(imgs)) if os.environ.get('PROBE_SM') else (lambda: m.forward_heads(imgs))
+fwd()
 if os.environ.get("PROBE_CHAINS"):       # e.g. 1: the whole batch as ONE chain (what a forward in flight runs)
     _lib.check(L.dn_set_chains(C.c_void_p(m._handle), int(os.environ["PROBE_CHAINS"])))
 for _ in range(3):
-    m.forward_heads(imgs)
+    fwd()
 torch.cuda.synchronize()
-st = torch.zeros(12 * 4096, dtype=torch.int64, device="cuda")
+st = torch.zeros(16 * 4096, dtype=torch.int64, device="cuda")
 raw.dn_debug_hf_stamps(C.c_void_p(st.data_ptr()))
-m.forward_heads(imgs)
+fwd()
 torch.cuda.synchronize()
 raw.dn_debug_hf_stamps(None)
-s = st.cpu().numpy().reshape(-1, 12)
+s = st.cpu().numpy().reshape(-1, 16)
 s = s[s[:, 6] > 0]
 print(f"batch {n}: {len(s)} workgroups stamped; kernel span by s_memrealtime {(s[:, 7].max() - s[:, 7].min()) * 0.01:.1f} us (last - first END)")
 for nch in sorted(set(s[:, 6]), reverse=True):
     q = s[s[:, 6] == nch].astype(np.float64)
     f = lambda k: q[:, k].mean()
     print(f"  K chunks {int(nch):3d}: {len(q):4d} WGs | prologue {f(0):8.0f} | dw {f(1):8.0f} ({f(1) / nch:6.0f}/chunk) | wait+barrier {f(2):8.0f} ({f(2) / nch:6.0f}) | "
-          f"mfma {f(3):8.0f} ({f(3) / nch:6.0f}) | loop {f(4):8.0f} | epilogue {f(5):8.0f} cycles; max loop {q[:, 4].max():.0f}")
+          f"mfma {f(3):8.0f} ({f(3) / nch:6.0f}) | loop {f(4):8.0f} | epilogue {f(5):8.0f} cycles; max loop {q[:, 4].max():.0f}"
+          + (f" | SM epilogue: write+tables {f(11):7.0f} softmax {f(12):7.0f} scores {f(13):7.0f}" if q[:, 13].max() > 0 else ""))
 
 # residency: workgroups alive at the same time on one compute unit (HW_ID: cu_id bits 11:8, sh_id 12, se_id 15:13; XCC_ID bits 3:0)
 cu = ((s[:, 10] & 0xf) << 8) | (((s[:, 9] >> 13) & 0x7) << 5) | (((s[:, 9] >> 12) & 1) << 4) | ((s[:, 9] >> 8) & 0xf)
