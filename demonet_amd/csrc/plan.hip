@@ -842,8 +842,9 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 // post-process follows (dn_forward_heads wants the logits themselves)
                 HeadPost hp;
                 bool with_post = false;
-                if (!heads_only && dn_knob("DN_HEAD_SOFTMAX", 1) != 0 && members.size() == h_dw.size() + h_cls.size() + h_reg.size() && lv0 == 0 &&
-                    nl == d.n_levels) {
+                // From 32 images per chain up (DN_HEAD_SOFTMAX_MINN): below that the launch is far from filling the chip and the epilogue is pure
+                // latency on the chain (batch 32 as two chains of 16: 0.630 -> 0.648 ms one forward at a time; from 32 per chain up it gains).
+                if (!heads_only && dn_knob("DN_HEAD_SOFTMAX", 1) != 0 && n >= dn_knob("DN_HEAD_SOFTMAX_MINN", 32) && lv0 == 0 && lv1 >= d.n_levels) {
                     const PostBuffers pb = post_buffers(ws + L.post_off, n, d.num_anchors, d.num_classes, d.topk_candidates);
                     int clamped = 0;
                     post_hist_range(d.score_thresh, &hp.hb0, &hp.nb, &clamped);
@@ -870,8 +871,11 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                     }
                     hr.levels = nsm;
                     hr.rows_per_image = rows;
-                    // (the softmax tiles of the small levels put their histogram rows behind these: the row stride of an image covers both)
-                    const int sfirst = nsm < nl ? fl[nsm].aoff : d.num_anchors;
+                    // the epilogue levels must be pyramid levels 0 .. nsm - 1: everything behind them -- small levels of this launch and levels that did
+                    // not join it (the V2 model's last level is a plain 1x1 conv on the grouped launches) -- stays in logit form
+                    for (int q = 0; q < nsm; ++q) prefix = prefix && p->ops[members[4 * q + 2]].level == q;
+                    // (the softmax tiles of those levels put their histogram rows behind these: the row stride of an image covers both)
+                    const int sfirst = nsm < d.n_levels ? p->level_off[nsm] : d.num_anchors;
                     hp.rows_per_image = rows + dn_cdiv(d.num_anchors - sfirst, 64);
                     with_post = prefix && nsm > 0 && hp.rows_per_image <= pb.tiles && head_fused_post_supported(fl, nl, hp);
                     if (with_post) {

@@ -977,26 +977,33 @@ def test_vgg_without_workspace_reuse(name, n, size, monkeypatch):
     assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
 
 
-@pytest.mark.parametrize("ncls,n,post", [(91, 64, {}), (91, 37, {}), (91, 3, {}), (91, 1, {}), (21, 9, {}),
-                                          (91, 5, {"score_thresh": 0.05, "detections_per_img": 100, "topk_candidates": 200}),
-                                          (91, 8, {"score_thresh": 1e-6})])
-def test_softmax_and_decode_in_the_head_launch_are_bit_identical(ncls, n, post, monkeypatch):
+@pytest.mark.parametrize("name,ncls,n,post", [("ssdlite320_mobilenet_v3_large", 91, 64, {}), ("ssdlite320_mobilenet_v3_large", 91, 37, {}),
+                                               ("ssdlite320_mobilenet_v3_large", 91, 3, {}), ("ssdlite320_mobilenet_v3_large", 91, 1, {}),
+                                               ("ssdlite320_mobilenet_v3_large", 21, 9, {}),
+                                               ("ssdlite320_mobilenet_v3_large", 91, 5, {"score_thresh": 0.05, "detections_per_img": 100, "topk_candidates": 200}),
+                                               ("ssdlite320_mobilenet_v3_large", 91, 8, {"score_thresh": 1e-6}),
+                                               ("ssd_lite_mobilenet_v2", 21, 40, {"image_size": 300}), ("ssd_lite_mobilenet_v2", 91, 5, {})])
+def test_softmax_and_decode_in_the_head_launch_are_bit_identical(name, ncls, n, post, monkeypatch):
     """Round 5 (headfuse.hip SM = true, DN_HEAD_SOFTMAX default 1): softmax over the classes, decode_single + clip and the score-histogram rows
     (generalized_ssd.py:354,362-363; _utils.py:187-224) run in the epilogue of the fused head launch -- the logits never reach memory and
     softmax_decode_kernel's launch is gone. Same arithmetic from the same accumulators (post_math.h is shared by both kernels), so the
     detections -- boxes, scores, labels, counts -- equal the logit-writing path + softmax_decode_kernel BIT FOR BIT, and so does the cut-off
     the histogram rows produce (the heaviest-first class order and tau only steer the work, but a wrong row table would show up as fallbacks
-    or missing candidates). Batch 64 (XCD grouping: 8 images per group, tiles spanning two images), 37 (two chains, ragged groups), 3 and 1
-    (plain mapping; the 1-pixel level's tile holds every image), K = 21 (126 channels per pixel: other row geometry), non-default thresholds
-    (a clamped / shifted histogram range)."""
+    or missing candidates). Only the levels with >= 32 pixels per image take the epilogue; the small ones keep their logits and get their
+    softmax from a few tiles of softmax_decode_kernel (one score array, one histogram-row table for both). Batch 64 (XCD grouping: 8 images per
+    group, tiles spanning two images), 37 (two chains, ragged groups), 3 and 1 (plain mapping), K = 21 (126 channels per pixel: other row
+    geometry), non-default thresholds (a clamped / shifted histogram range), the V2 model at 300 x 300 (19 x 19 / 10 x 10 maps; its last level
+    is a plain 1x1 conv outside the fused launch) and at 320."""
     import ctypes
     from demonet_amd import _lib
     raw = ctypes.CDLL(_lib.LIB_PATH)
-    imgs = torch.from_numpy(synth.images(83, n, 320, 320)).cuda()
+    size = post.get("image_size", 320)
+    imgs = torch.from_numpy(synth.images(83, n, size, size)).cuda()
     res, launches = {}, {}
+    monkeypatch.setenv("DN_HEAD_SOFTMAX_MINN", "1")          # (by default the epilogue is used from 32 images per chain up)
     for flag in ("0", "1"):
         monkeypatch.setenv("DN_HEAD_SOFTMAX", flag)
-        m = _model("ssdlite320_mobilenet_v3_large", num_classes=ncls, **post)
+        m = _model(name, num_classes=ncls, **post)
         before = raw.dn_debug_head_softmax_launches()
         res[flag] = [t.clone() for t in m.forward_batch(imgs)]
         launches[flag] = raw.dn_debug_head_softmax_launches() - before
@@ -1016,6 +1023,7 @@ def test_softmax_in_the_head_launch_feeds_the_same_cut_off(monkeypatch):
     fallback forced off-limits: DN_PP_FAST=1 results must equal DN_PP_FAST=0 (no cut-off at all) on both paths."""
     imgs = torch.from_numpy(synth.images(89, 16, 320, 320)).cuda()
     res = {}
+    monkeypatch.setenv("DN_HEAD_SOFTMAX_MINN", "1")
     for sm in ("0", "1"):
         for fast in ("0", "1"):
             monkeypatch.setenv("DN_HEAD_SOFTMAX", sm)
