@@ -118,8 +118,15 @@ def fused_external_bytes(g, costs, mem, head):
     # inverted-residual block adds its input: those rows are already counted in first["b_in"]; round 4 counted them twice and
     # over-credited the fused-block family by 21 %)
     first, last = costs[mem[0]], costs[mem[-1]]
-    own_in = g.nodes[mem[0]].inp
-    return first["b_in"] + last["b_out"] + sum(costs[i]["b_w"] - (costs[i]["b_res"] if g.nodes[i].residual == own_in else 0.0) for i in mem)
+    inside = {g.nodes[mem[0]].inp} | {g.nodes[i].out for i in mem}          # a residual read from one of these never comes from HBM again
+    ext = first["b_in"] + last["b_out"]
+    for i in mem:
+        c, nd = costs[i], g.nodes[i]
+        if nd.op == "se":
+            ext += 4 * 2 * nd.cin * nd.squeeze                                # the FC weights (the pooled vectors stay on chip)
+        else:
+            ext += c["b_w"] - (c["b_res"] if nd.residual in inside else 0.0)
+    return ext
 
 
 def cpu_baseline(name, graph, seed, budget_s=24.0):
@@ -573,7 +580,7 @@ def main(argv=None):
         # fused inverted-residual launches: the intermediate activations never reach HBM -> external bytes only
         fused = {}
         for i, c in enumerate(costs):
-            if c["kernel"].startswith(("expdw_kernel", "expdw_one_kernel", "pw_dw_direct_kernel", "head_fused_kernel")):
+            if c["kernel"].startswith(("expdw_kernel", "expdw_one_kernel", "pw_dw_direct_kernel", "head_fused_kernel", "coop_kernel")):
                 fused.setdefault(c["owner"], []).append(i)
         for mem in fused.values():
             ext = fused_external_bytes(g, costs, mem, costs[mem[0]]["kernel"].startswith("head_fused_kernel"))
