@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
 int patch_max_cin() { return 128; }
 
 bool patch_shape(const PwArgs& a) {
-    const int on = dn_knob("DN_CONV_PATCH", 1);
+    const int on = 1;
     return on && a.zeros && !a.out_fp32 && !a.residual && !a.se && a.cv_k == 3 && a.cv_stride == 1 && a.cv_pad == 1 && a.cv_dil == 1 &&
            a.cv_ho == a.cv_h && a.cv_wo == a.cv_w && a.cv_cin % 64 == 0 && a.cv_cin <= patch_max_cin() && a.cout % 64 == 0 && a.m / a.hw <= 65535;
 }
@@ -801,7 +801,7 @@ int launch_halo(const PwArgs& a, hipStream_t s, const char* name) {
     DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_halo_kernel<3, TP, TC, HEAD>)));
     dn_note_kernel(name);
     PwArgs b = a;
-    b.cv_plain_order = dn_knob("DN_CONV_PLAIN_ORDER", 0);
+    b.cv_plain_order = 0;
     hipLaunchKernelGGL((conv_halo_kernel<3, TP, TC, HEAD>), dim3(dn_cdiv(a.m, BPt), dn_cdiv(a.cout + (HEAD ? a.cout_b : 0), BCt)), dim3(256), lds, s, b);
     return DN_OK;
 }
@@ -810,7 +810,7 @@ int launch_halo(const PwArgs& a, hipStream_t s, const char* name) {
 int halo_variant(const PwArgs& a) {
     if (a.out_fp32 || a.residual || a.se || !halo_shape(a)) return 0;
     const int hr = halo_rows(a);
-    const int force = dn_knob("DN_CONV_HALO_VARIANT", 0);      // dev knob: prefer the 512 x 128 (2) / 256 x 128 (3) tile where it applies
+    const int force = 0;      // dev knob: prefer the 512 x 128 (2) / 256 x 128 (3) tile where it applies
     if (force == 2 && a.cout % 128 == 0 && a.cv_cin >= 128 && 512 + hr <= halo_run_rows(8, 2)) return 2;
     if (force == 3 && a.cout % 128 == 0 && a.cv_cin >= 128 && 256 + hr <= halo_run_rows(4, 2)) return 3;
     if (a.cout % 256 == 0 && 256 + hr <= halo_run_rows(4, 4)) return 1;
@@ -858,7 +858,7 @@ bool conv_patch_pool_ok(int cin, int cout, int h, int w) {
     a.hw = h * w; a.m = a.hw; a.cin = 9 * cin; a.cout = cout;
     // the patch kernel is what launch_conv_big picks when the run-staged 512 x 128 tile does not apply; a larger batch can only
     // take the run-staged tiles away (their 2 GB addressing limit), never the patch kernel
-    return patch_shape(a) && (cin <= 64 || halo_variant(a) == 0 || halo_variant(a) == 3) && (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= dn_knob("DN_CONV_BIG_MIN", 40);
+    return patch_shape(a) && (cin <= 64 || halo_variant(a) == 0 || halo_variant(a) == 3) && (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= 40;
 }
 
 // ... or, for the layers of the run-staged 256 x 256 tile (conv3_3 of ssd512: 256 channels on 128 x 128), in the epilogue of conv_halo_kernel<3,4,4>:
@@ -871,7 +871,7 @@ static bool conv_halo_pool_geometry(int cin, int cout, int h, int w) {
     a.zeros = dummy_zero; a.residual = nullptr; a.se = nullptr; a.out_fp32 = 0;
     a.hw = h * w; a.m = a.hw; a.cin = 9 * cin; a.cout = cout;
     return halo_variant(a) == 1 && !(patch_shape(a) && cin <= 64) && 256 % (2 * w) == 0 && (h * w) % 256 == 0 &&
-           (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= dn_knob("DN_CONV_BIG_MIN", 40);
+           (long)dn_cdiv(a.m, 256) * dn_cdiv(cout, 256) >= 40;
 }
 // (the knobs decide at plan creation; the launch only checks the geometry, so a knob flipped between dn_create and dn_forward cannot strand a fused pair)
 bool conv_halo_pool_ok(int cin, int cout, int h, int w) {
@@ -910,7 +910,7 @@ int launch_conv_pool(const PwArgs& a, hipStream_t s) {
 // workgroups) takes 256 x 128 tiles -- twice the workgroups at half the work each.
 static int head_variant(const PwArgs& a) {
     const int on = dn_knob("DN_CONV_HEAD_BIG", 1);
-    const int minwg = dn_knob("DN_CONV_HEAD_BIG_MIN", 40);
+    const int minwg = 40;
     if (!on || !a.out_fp32 || a.residual || a.se || !halo_shape(a) || (a.cout & 1)) return 0;
     const int hr = halo_rows(a), nc = a.cout + a.cout_b;
     const int c256 = dn_cdiv(nc, 256), c128 = dn_cdiv(nc, 128);

@@ -374,7 +374,7 @@ bool dw_fill(DwArgs& a) {
     // row blocks: the largest power of two <= DN_DW_RB that divides the output height (the thread count, and with it the number of
     // pooled partial rows the plan sized, stays what it is)
     int rb = 0;
-    for (int want = dn_knob("DN_DW_RB", 1); (2 << rb) <= want && a.ho % (2 << rb) == 0; ) ++rb;
+    for (int want = 1; (2 << rb) <= want && a.ho % (2 << rb) == 0; ) ++rb;
     a.rb_log2 = rb;
     a.fd_rbxs = fastdiv(xs << rb);
     const unsigned long long threads = (unsigned long long)a.ho * xs * c8 + 256;
@@ -396,7 +396,7 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
     }
     g.start[count] = acc;
     dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
-    if (dn_knob("DN_DW_PIPE3", 1)) hipLaunchKernelGGL((dw_group_kernel<K, S, TW, 4>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
+    if (1) hipLaunchKernelGGL((dw_group_kernel<K, S, TW, 4>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
     else hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
     return DN_OK;
 }
@@ -415,7 +415,7 @@ int launch_dw(const DwArgs& a0, hipStream_t s) {
     // software-pipelined rows, default on, stress-tested. 5x5 (DN_DW_PIPE): one exposed round trip instead of three, 29 -> 25.7 us per 40 x 40 launch. 3x3 (DN_DW_PIPE3): the batched form already takes its three rows in one round trip, but two row sets instead of three are 127 registers instead of 140 -- 4 waves per SIMD: the head group 36.4 -> 33.8 us.
     // (Round 2 - 3 also carried a ONE-row-at-a-time form, 70 - 116 registers: with it a forward's result depended on what else ran on the chip; cause not found in
     //  two rounds of hunting (profiles/r03_dw_rows_hunt.txt), deleted in round 4 -- the poison test of tests/test_gpu_pipeline.py and the in-flight stress test guard what is left.)
-    const bool pipe = K == 5 ? (dn_knob("DN_DW_PIPE", 7) & cls) != 0 : (dn_knob("DN_DW_PIPE3", 7) & cls) != 0;
+    const bool pipe = K == 5 ? (7 & cls) != 0 : (7 & cls) != 0;
     const size_t lds = a.pool ? pool_lds : 0;
     if (pipe) {
         if (a.pool && a.se_scale) hipLaunchKernelGGL((dw_kernel<K, S, TW, 2, 4>), grid, dim3(256), lds, s, a, nblocks);
@@ -1037,7 +1037,7 @@ int launch_se_fc(const float* partial, int nblk, const void* w1t, const float* b
         auto k = wide ? se_fc8_kernel<15, 4> : se_fc8_kernel<14, 6>;
         hipLaunchKernelGGL(k, dim3(xq > 0 ? 8 * xq : n), dim3(1024), (size_t)(c + squeeze + pf) * sizeof(float), s, partial, nblk,
                            reinterpret_cast<const half_t*>(w1t), b1, reinterpret_cast<const half_t*>(w2t), b2, scale, c, squeeze,
-                           1.0f / (float)pool_pixels, g_se_stamps, n, xq, dn_knob("DN_SE_ROT", 5));
+                           1.0f / (float)pool_pixels, g_se_stamps, n, xq, 5);
         return DN_OK;
     }
     dn_note_kernel("se_fc_kernel");

@@ -242,7 +242,7 @@ static const Layout& get_layout(dn_plan* p, int n) {
                 if (born[t] >= 0) born[t] = std::min(born[t], when[i]);
             }
         const int t_end = NO + 2;
-        if (const int slack = dn_knob("DN_WS_SLACK", 0))        // diagnostics: every block stays reserved `slack` launches beyond its last reader
+        if (const int slack = 0)        // diagnostics: every block stays reserved `slack` launches beyond its last reader
             for (size_t t = 0; t < T; ++t) if (dies[t] >= 0) dies[t] += slack;
         for (int l = 0; l < p->d.n_levels; ++l) dies[p->d.level_tensor[l]] = t_end;      // read back by tests / callers after the forward
         struct Blk { size_t off, bytes; int born, dies; };
@@ -351,7 +351,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
         auto dw_ok = [&](const dn_op_desc& o) { return o.type == DN_OP_DW && !o.head && o.dil == 1; };
         auto proj_ok = [&](const dn_op_desc& pj, const dn_op_desc& d, int block_in) {
             const dn_tensor_desc& to = p->tensors[d.out];
-            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= dn_knob("DN_EXPDW_PROJ_MAXCEXP", 640) &&
+            return plain_pw(pj) && pj.in == d.out && uses[d.out] == 1 && d.pool < 0 && pj.act == DN_ACT_NONE && d.cin <= 640 &&
                    to.h * to.w >= proj_min_hw && expdw_project_supported(d.cin, pj.cout, to.h, to.w, d.stride) &&
                    (pj.residual < 0 || (pj.residual == block_in && d.stride == 1 && pj.cout == p->tensors[block_in].c));
         };
@@ -362,7 +362,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
                 expdw_supported(a.cin, a.cout, d.k, d.stride)) {
                 const dn_tensor_desc& to = p->tensors[d.out];
                 if (to.h * to.w > max_hw) continue;
-                const bool can_proj = i + 2 < desc->n_ops && a.cin <= dn_knob("DN_EXPDW_PROJ_MAXCIN", 96) && proj_ok(p->ops[i + 2], d, a.in);
+                const bool can_proj = i + 2 < desc->n_ops && a.cin <= 96 && proj_ok(p->ops[i + 2], d, a.in);
                 if (to.h * to.w < min_hw && !can_proj) continue;      // below the expand+depthwise threshold only whole blocks fuse
                 if (can_proj) {
                     p->fused_len[i] = 3; p->fused_kind[i] = 3; i += 2;
@@ -384,7 +384,7 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             }
             // the same pair through the LDS-tiled block kernel: correct but measured slower than the two
             // launches (16 channels leave half of the workgroup idle in the depthwise stage) -- opt-in
-            const bool noexp = dn_knob("DN_EXPDW_NOEXP", 0) != 0;
+            const bool noexp = 0 != 0;
             if (noexp && dw_ok(a) && p->tensors[a.in].kind == DN_T_ACT && expdw_supported(a.cin, a.cin, a.k, a.stride) && a.cin <= 32 &&
                 proj_ok(d, a, a.in)) {
                 p->fused_len[i] = 2; p->fused_kind[i] = 2; i += 1;
@@ -899,7 +899,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 if (!head_fused_level_supported(f)) continue;
                 // DN_HEAD_FUSE_MINHW: levels with fewer pixels per image stay on the grouped launches. The fused workgroups take 512 residency
                 // slots (2 per CU); at batch 64 levels 0 - 1 are 504 of them, every further workgroup starts a second round of the whole launch
-                if (ti.h * ti.w < dn_knob("DN_HEAD_FUSE_MINHW", 0)) continue;
+                if (ti.h * ti.w < 0) continue;
                 if (nl > 0 && (dn_cdiv(f.nc[0], 32) + 4) / 4 != (dn_cdiv(fl[0].nc[0], 32) + 4) / 4) continue;      // (one instantiation per launch: channel tiles per wave)
                 ++nl;
                 members.push_back(dc); members.push_back(dr); members.push_back(h_cls[q]); members.push_back(qr);

@@ -927,7 +927,7 @@ int launch_cfg(const PwArgs& a, hipStream_t s) {
     if constexpr (CONV && BP == 128 && BC == 128) {
         // MFMA-bound dense convolutions (VGG): 64-deep stages halve the barriers per MFMA; the tile is register-limited to two
         // workgroups per CU either way, and 2 x 74 KB of LDS fit
-        const int bk64 = dn_knob("DN_CONV_BK64", 1);
+        const int bk64 = 1;
         if (bk64 && a.cv_cin % 64 == 0) return launch_bk<BP, BC, WP, WC, CONV, 64>(a, s, 2);
     }
     return launch_bk<BP, BC, WP, WC, CONV, 32>(a, s, 2);
@@ -957,7 +957,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         // of the model shows the small tiles (most workgroups, fewest registers: 64 VGPRs -> 8 waves/SIMD) winning or tying
         // everywhere, 128x32 when there is a single channel tile. The big tiles only pay off for MFMA-bound shapes.
         if (a.cin < 256 || a.cout < 128) {
-            const int shortk = dn_knob("DN_PW_SHORTK", 1);
+            const int shortk = 1;
             if (shortk && a.cin > 32 && a.cin <= 128) {       // 2..4 K stages: all loads up front
                 const_cast<PwArgs&>(a).stamps = g_pw_stamps;
                 if constexpr (!CONV) {
@@ -977,7 +977,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
     }
     if constexpr (CONV) {
         const int big = dn_knob("DN_CONV_BIG", 1);
-        const int bigmin = dn_knob("DN_CONV_BIG_MIN", 40);       // measured on both VGG models: 40 < 90 < 200; the sub-batch chains fill the chip together
+        const int bigmin = 40;       // measured on both VGG models: 40 < 90 < 200; the sub-batch chains fill the chip together
         if (big && conv_big_supported(a) && wgs(256, 256) >= bigmin) return launch_conv_big(a, s);
     }
     if (a.cout <= 32) {
@@ -992,7 +992,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         // small dense convs (the extras of the VGG models: <= 16 x 16 maps, K = 9 cin up to 4608): a few workgroups walking 70 - 140
         // K stages, each an exposed memory round trip with the plain double buffer (60 - 130 us per layer for < 1 us of MFMA work):
         // request the stages 4 ahead through the register ring of the short-K pointwise variant
-        if (dn_knob("DN_CONV_SMALL_PF", 1) && a.cout > 32 && wgs(64, 64) < dn_knob("DN_CONV_SMALL_WGS", 512)) return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
+        if (1 && a.cout > 32 && wgs(64, 64) < 512) return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
     }
     if constexpr (!CONV) {
         // a 1x1 layer with few workgroups and a long K (the first extras layer: 480 -> 256 on 10 x 10) is a chain of exposed round trips with the plain
@@ -1003,7 +1003,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
             return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
         }
     }
-    const int t128 = dn_knob("DN_CONV_T128", 300);      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
+    const int t128 = 300;      // min workgroups for the 128x128 tile of the MFMA-bound dense convs (measured on the VGG models)
     if (wgs(128, 128) >= (CONV ? t128 : 1500)) return launch_cfg<128, 128, 2, 2, CONV>(a, s);
     if (wgs(128, 64) >= 1500 || a.cout % 128 > 64 || a.cout % 128 == 0) {
         if (wgs(64, 128) >= 600) return launch_cfg<64, 128, 2, 2, CONV>(a, s);
@@ -1067,17 +1067,17 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         if (arr[i].cout > maxc) maxc = arr[i].cout;
         wg128 += (long)dn_cdiv(arr[i].m, 128) * dn_cdiv(arr[i].cout, 128);
     }
-    if (maxc <= 32 && conv && wg128 < 256 && dn_knob("DN_CONV_SMALL_PF", 1)) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
+    if (maxc <= 32 && conv && wg128 < 256 && 1) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
     if (wg128 >= 1500 && conv) {
         // MFMA-bound dense-conv heads: 64-deep stages as in launch_cfg (half the barriers per MFMA)
-        const int bk64 = dn_knob("DN_CONV_GROUP_BK64", 1);
+        const int bk64 = 1;
         bool all64 = bk64 != 0;
         for (int i = 0; i < count; ++i) all64 &= arr[i].cv_cin % 64 == 0;
         if (all64) return launch_group_cfg<128, 128, 2, 2, true, 64>(arr, count, s);
     }
-    if (wg128 >= 1500 && !conv && dn_knob("DN_PW_GROUP_96", 1)) {
+    if (wg128 >= 1500 && !conv && 1) {
         // 96-wide channel tiles (a wave = 32 pixels x 96 channels) where they pad less: the 546 class channels of the SSDLite heads are
         // 6 x 96 = 576 columns instead of 5 x 128 = 640 -- the head launch is the longest full-chip launch of a forward (batch 64, three
         // forwards in flight: 0.789 -> 0.775 ms; 128 x 192 tiles 0.808, 64 x 192 level)
@@ -1090,13 +1090,13 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     }
     if (wg128 >= 1500) return conv ? launch_group_cfg<128, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
     // the dense heads of the small levels (a few dozen workgroups, 72 - 144 K stages): latency-bound, stages requested 3 ahead
-    if (conv && wg128 < 256 && dn_knob("DN_CONV_SMALL_PF", 1)) return launch_group_cfg<64, 128, 2, 2, true, 32, 3>(arr, count, s);
+    if (conv && wg128 < 256 && 1) return launch_group_cfg<64, 128, 2, 2, true, 32, 3>(arr, count, s);
     return conv ? launch_group_cfg<64, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
 }
 
 // the squeeze-excitation of a projection can be computed in the projection kernel's prologue (SEF variant of the 64 x 64 tile)
 bool pw_se_fold_supported(int cin, int cout, int squeeze, int hw) {
-    return dn_knob("DN_SE_FOLD", 1) != 0 && dn_knob("DN_PW_SHORTK", 1) != 0 && cin > 32 && cin <= 128 && cin % 8 == 0 && squeeze <= 32 && hw >= 64 &&
+    return dn_knob("DN_SE_FOLD", 1) != 0 && 1 != 0 && cin > 32 && cin <= 128 && cin % 8 == 0 && squeeze <= 32 && hw >= 64 &&
            (cin < 256 || cout < 128);
 }
 
@@ -1147,11 +1147,11 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
     a.xq = c.xq;
     DN_REQUIRE(a.m > 0, "conv: empty problem");
-    if (c.k == 1 && c.stride == 1 && c.pad == 0 && !c.out_fp32 && dn_knob("DN_CONV_1X1_AS_PW", 1)) {
+    if (c.k == 1 && c.stride == 1 && c.pad == 0 && !c.out_fp32 && 1) {
         // a 1x1 dense conv IS a pointwise conv: unless it is big enough for the 256 x 256-tile kernel, the pointwise path serves it
         // (register-direct kernel up to cin = 256, 4-stage prefetch ring beyond; the implicit-GEMM body walks it one exposed stage at a time)
         const long wg256 = (long)dn_cdiv(a.m, 256) * dn_cdiv(a.cout, 256);
-        if (!(dn_knob("DN_CONV_BIG", 1) && conv_big_supported(a) && wg256 >= dn_knob("DN_CONV_BIG_MIN", 40))) {
+        if (!(dn_knob("DN_CONV_BIG", 1) && conv_big_supported(a) && wg256 >= 40)) {
             PwArgs b;
             b.x = c.x; b.w = c.w; b.bias = c.bias; b.residual = nullptr; b.se = nullptr; b.out = c.out;
             b.hw = a.hw; b.m = a.m; b.cin = c.cin; b.cout = c.cout; b.act = c.act; b.out_fp32 = 0; b.out_img_stride = 0; b.out_base = 0;

@@ -418,7 +418,6 @@ __global__ __launch_bounds__(256) void pw_dw_direct_kernel(PwDwArgs q, int tiles
     half8 xf[KSF];
 #pragma unroll
     for (int ks = 0; ks < KSF; ++ks) {
-        const int cb = ks * 16 + hh * 8;
         // The launch is bound by the vector-memory pipe (22 wave-wide loads per wave for two MFMAs), and the depthwise weights / bias are the
         // same for every pixel: both 8-channel halves of a tap come through the scalar cache (uniform address, constant address space) and
         // the lane picks its half with selects -- nine vector loads less per lane.
@@ -536,7 +535,7 @@ int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s) {
 
 bool pw_direct_supported(const PwArgs& a) {
     // squeeze-excitation scaled inputs: only where a 32-row tile lies inside one image (the 40 x 40 maps) and the reduction is short
-    if (a.se && !(a.hw % 32 == 0 && a.cin <= 128 && dn_knob("DN_PW_DIRECT_SE", 1))) return false;
+    if (a.se && !(a.hw % 32 == 0 && a.cin <= 128 && 1)) return false;
     return dn_knob("DN_PW_DIRECT", 1) != 0 && a.cv_k == 1 && !a.out_fp32 && !a.sef_part && !a.w_b && a.cin % 8 == 0 && a.cin >= 8 &&
            a.cin <= 256 && a.cout % 8 == 0 && a.cout >= 8 && !(a.act >> 8) && a.out_img_stride == 0 && a.out_base == 0;
 }
@@ -550,10 +549,10 @@ int launch_pw_direct(const PwArgs& a, hipStream_t s) {
     const int ctiles = dn_cdiv(a.cout, 32);
     const int ksf = a.cin >> 4;
     // wide expansions with enough rows: the streaming variant (pw_stream_kernel) -- channel runs sized so that all waves are resident at once
-    if (dn_knob("DN_PW_STREAM", 1) && !a.se && !a.residual && ksf >= 4 && ksf <= 8 && ctiles >= 12 && a.m >= dn_knob("DN_PW_STREAM_MINM", 12800)) {
-        const int px = dn_knob("DN_PW_STREAM_PX", 2) == 2 ? 2 : 1;      // 32-pixel tiles per wave
+    if (dn_knob("DN_PW_STREAM", 1) && !a.se && !a.residual && ksf >= 4 && ksf <= 8 && ctiles >= 12 && a.m >= 12800) {
+        const int px = 2 == 2 ? 2 : 1;      // 32-pixel tiles per wave
         const long ptiles = dn_cdiv(a.m, 32 * px);
-        int runs = (int)std::max(1L, std::min((long)ctiles, (long)dn_knob("DN_PW_STREAM_WAVES", 2800) / ptiles));
+        int runs = (int)std::max(1L, std::min((long)ctiles, (long)2800 / ptiles));
         const int per = dn_cdiv(ctiles, runs);
         runs = dn_cdiv(ctiles, per);
         switch (ksf * 10 + px) {
@@ -569,7 +568,7 @@ int launch_pw_direct(const PwArgs& a, hipStream_t s) {
             case 82: return launch_stream_t<8, 2>(a, runs, per, s);
         }
     }
-    if (ksf <= 8 && a.cout >= dn_knob("DN_PW_DIRECT_TC2", 400)) {
+    if (ksf <= 8 && a.cout >= 400) {
         const int wc_log = ctiles <= 2 ? 0 : ctiles <= 4 ? 1 : 2;
         switch (ksf) {
 #define DN_PWD_CASE2(k) case k: return launch_t<k, 2>(a, wc_log, s);
