@@ -108,6 +108,43 @@ __global__ __launch_bounds__(256) void k(float* out, const uint4* in) {
                     }
                 }
         }
+        if constexpr (MODE == 5) {
+            // v_dot2_f32_f16 as it could really be used (round 5): a register holds two CHANNELS of one pixel, a dot2 needs two TAPS of one channel,
+            // so pixel pairs (0,1) (2,3) (4,5) (6,7) are transposed with v_perm_b32 (2 per register pair: 32 per row step) and every output uses
+            // two pairs + one single tap: even outputs pairs (kx 0,1) (kx 2,3) + tap 4, odd outputs tap 0 + pairs (kx 1,2) (kx 3,4).
+            // 32 v_perm + 64 v_dot2 + 32 v_fma_mix = 128 instructions for the 160 multiply-adds (weights pre-paired: free).
+            unsigned plo[4][4], phi[4][4];       // [pair][register]: (x_i.c_even, x_{i+1}.c_even), (x_i.c_odd, x_{i+1}.c_odd)
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const unsigned a[4] = {xv[2 * pr].x, xv[2 * pr].y, xv[2 * pr].z, xv[2 * pr].w}, b[4] = {xv[2 * pr + 1].x, xv[2 * pr + 1].y, xv[2 * pr + 1].z, xv[2 * pr + 1].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(plo[pr][i]) : "v"(b[i]), "v"(a[i]), "s"(0x05040100u));
+                    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(phi[pr][i]) : "v"(b[i]), "v"(a[i]), "s"(0x07060302u));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int p0 = (t + 1) >> 1;            // first pair of this output: t = 0 -> pairs 0, 1; 1 -> 1, 2; 2 -> 1, 2; 3 -> 2, 3
+                const int single = (t & 1) ? t : t + 4; // the unpaired tap's pixel
+                const unsigned sx[4] = {xv[single].x, xv[single].y, xv[single].z, xv[single].w};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned ww[4] = {wv[2 * q].x, wv[2 * q].y, wv[2 * q].z, wv[2 * q].w}, w2[4] = {wv[2 * q + 1].x, wv[2 * q + 1].y, wv[2 * q + 1].z, wv[2 * q + 1].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc[t][2 * i]) : "v"(plo[p0 + q][i]), "v"(ww[i]));
+                        asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc[t][2 * i + 1]) : "v"(phi[p0 + q][i]), "v"(w2[i]));
+                    }
+                }
+                const unsigned w4[4] = {wv[4].x, wv[4].y, wv[4].z, wv[4].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(acc[t][2 * i]) : "v"(sx[i]), "v"(w4[i]));
+                    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[t][2 * i + 1]) : "v"(sx[i]), "v"(w4[i]));
+                }
+            }
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -146,6 +183,7 @@ int main() {
         if (run<2>("104 v_cvt + 80 v_pk_fma_f32", out, in, w)) return 1;
         if (run<3>("64 v_cvt (x only) + 80 v_pk_fma_f32 (fp32 weights)", out, in, w)) return 1;
         if (run<4>("96 v_dot2_f32_f16 (tap pairs, 3 for 5)", out, in, w)) return 1;
+        if (run<5>("32 v_perm + 64 v_dot2 + 32 v_fma_mix (NHWC registers)", out, in, w)) return 1;
     }
     return 0;
 }
