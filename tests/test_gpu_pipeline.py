@@ -1,6 +1,7 @@
 """GPU tests (-m gpu) of demonet_amd.pipeline.ForwardPipeline: several forwards of one plan in flight must return, per batch,
 exactly what one forward at a time returns (the oracle parity of that single forward is test_gpu_model.py's subject)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -277,3 +278,57 @@ def test_results_do_not_depend_on_stale_lds_or_registers(name, ncls, kw, n, monk
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
     assert int(res["1"][3].sum()) > 0 and torch.isfinite(res["1"][4]).all()
+
+
+def _world2_worker(rank, world, port, ret):
+    """One rank of the C4 data path with REAL kernels: both ranks share cuda:0 (there is one GPU on the test box) and talk over gloo, which
+    moves device tensors through the host -- the collective's transport is not what is under test, everything around it is."""
+    import torch.distributed as dist
+    from demonet_amd.dist import DetectionGatherer, shard_range
+    from demonet_amd.pipeline import ForwardPipeline
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G, steps, depth = 12, 5, 3                           # global batch 12 -> 6 images per rank, five steps, window of two
+    lo, hi = shard_range(G, rank, world)
+    B = hi - lo
+    m = models.load_synthetic(models.ssdlite320_mobilenet_v3_large(num_classes=91), 0).to(dev)
+    D = m.detections_per_img
+    glob = [torch.from_numpy(synth.images(700 + s, G, 320, 320)).to(dev) for s in range(steps)]       # every rank can build the global batch
+    pipe = ForwardPipeline(m, B, depth=depth, chains=1, device=dev, packed=True)
+    gat = DetectionGatherer(B, D, dev, every=2)
+    tickets = []
+    for s in range(steps):
+        t = pipe.submit(glob[s][lo:hi].contiguous())
+        with torch.cuda.stream(pipe.stream_of(t)):
+            tickets.append(gat.submit(src=pipe.packed(t), join=pipe.join))
+    with torch.cuda.stream(pipe.stream_of(t)):
+        gat.flush(join=pipe.join)
+    torch.cuda.synchronize(dev)
+    pipe.close()
+    ok = True
+    for s in (2, 3, 4):                                  # (steps 0, 1 were overwritten by the third window)
+        pk, cn = gat.result(tickets[s])
+        boxes, scores, labels, counts = [x.clone() for x in m.forward_batch(glob[s])]     # the GLOBAL batch in one forward on this rank
+        ok = ok and pk.shape == (G, D, 6) and torch.equal(cn, counts)
+        ok = ok and torch.equal(pk[..., :4], boxes) and torch.equal(pk[..., 4], scores) and torch.equal(pk[..., 5].long(), labels)
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_data_path_with_real_kernels():
+    """BASELINE config C4's data path at world size 2 on the one GPU of the test box: each rank shards the global batch (dist.shard_range),
+    keeps three forwards of its shard in flight (ForwardPipeline), the merge kernel writes the packed payload, the windowed gatherer
+    all-gathers it (util/misc.py:75-115 is the reference's pickled all_gather; engine.py:105 its call site), and what every rank then holds
+    for a step equals ONE forward of the global batch: boxes, scores, labels and counts, bit for bit, in image order."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_world2_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2 and ret[0] and ret[1], dict(ret)
