@@ -254,7 +254,7 @@ def _launch_ranks(n, argv, stub):
     children's status. The parent never initialises the GPU (torch.cuda.device_count() does not on this image) and never exec()s."""
     import socket
     import subprocess
-    if not stub:
+    if not stub and os.environ.get("DN_BENCH_SHARE_GPU") != "1":
         have = torch.cuda.device_count()
         if have < n:
             sys.exit(f"bench.py: --gpus {n} but this node shows {have} GPU(s): refusing to print a {have}-GPU number as an {n}-GPU line")
@@ -328,10 +328,16 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
     distributed = world > 1 or os.environ.get("DN_BENCH_FORCE_DIST") == "1"     # (the latter: 1-GPU smoke test of the RCCL path)
+    share = False
     if stub:
         dev = torch.device("cpu")
         sync = lambda: None
     else:
+        # DN_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): every rank uses cuda:0 and the collectives run over gloo -- the N-rank code path with
+        # real forwards, not a throughput measurement (the line says so in config.parallelism)
+        share = os.environ.get("DN_BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         sync = lambda: torch.cuda.synchronize(dev)
@@ -343,7 +349,10 @@ def main(argv=None):
         if stub:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+            if share:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from demonet_amd import models, synth
     from demonet_amd.dist import DetectionGatherer
@@ -489,7 +498,8 @@ def main(argv=None):
                    "launch": (f"hipGraph replay, {R} forwards in flight (one stream, workspace and output set each; one plan), each forward a single chain of {B} images" if R > 1 else
                               ("eager" if args.eager else "hipGraph replay") + (f", one forward at a time, {model.batch_split(B)} sub-batch chains" + (
                                   " as branches of one graph" if B >= 64 or os.environ.get("DN_CHAIN_GRAPHS") == "0" else " as one graph each on its own stream") if model.batch_split(B) > 1 else ", one forward at a time, one chain")),
-                   "parallelism": f"image-sharded x{world}, RCCL all_gather of detections (windows of {gatherer.K} steps)" if distributed else "single GPU",
+                   "parallelism": (f"image-sharded x{world}, RCCL all_gather of detections (windows of {gatherer.K} steps)" +
+                                   (" -- DN_BENCH_SHARE_GPU: every rank on cuda:0 over gloo, a code-path check, NOT a scaling number" if os.environ.get("DN_BENCH_SHARE_GPU") == "1" else "")) if distributed else "single GPU",
                    "input": "NCHW fp32 in [0,1], device-resident" if args.input == "f32" else "NHWC uint8 (decoder output), device-resident",
                    "mean_detections": float(counts.float().mean().item())},
     }

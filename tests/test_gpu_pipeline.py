@@ -332,3 +332,22 @@ def test_world_size_2_data_path_with_real_kernels():
     ret = mp.Manager().dict()
     mp.spawn(_world2_worker, args=(2, port, ret), nprocs=2, join=True)
     assert len(ret) == 2 and ret[0] and ret[1], dict(ret)
+
+
+def test_bench_two_ranks_on_one_gpu_runs_the_real_n_rank_path():
+    """`python bench.py --gpus 2` with DN_BENCH_SHARE_GPU=1: the process starts two ranks itself (as the driver's N > 1 form would), both on the
+    one GPU of the test box, collectives over gloo: config C4's code path -- sharding of the global batch 256 (128 per rank), three forwards
+    in flight per rank, the windowed gather of the merge kernel's payload, flush inside the timed region, barriers, MAX over ranks -- with REAL
+    forwards. Not a throughput number (the line says so); n_gpus and the communicator's own world size must be 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DN_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "6", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 256
+    assert d["value"] > 0 and d["config"]["mean_detections"] > 0 and "NOT a scaling number" in d["config"]["parallelism"]
