@@ -577,9 +577,9 @@ def main(argv=None):
         # the library reports which kernel each op launched and which op's event segment holds a grouped launch's time
         name = C.create_string_buffer(96)
         owner = C.c_int32()
-        # the post-process launches have event segments of their own (dn_profile_end): softmax + decode (empty when the fused head launch does
-        # it) | tau + cut-off selection | merge | the fallback launch
-        post = [costs[len(g.nodes)]["kernel"], "select_nms_fast_kernel (+tau)", "merge_kernel", "select_nms_kernel (fallback)"]
+        # the post-process launches have event segments of their own (dn_profile_end): softmax + decode (with the fused head launch: only
+        # the small levels, and the cut-off in its last tile per image) | [tau +] cut-off selection | merge | the fallback launch
+        post = [costs[len(g.nodes)]["kernel"], "select_nms_fast_kernel (+tau when it is a launch)", "merge_kernel", "select_nms_kernel (fallback)"]
         agg = {}
         for i, c in enumerate(costs):
             if i < len(g.nodes):
@@ -610,7 +610,7 @@ def main(argv=None):
                 a["launches"] += split
         if args.per_op:
             with open(args.per_op, "w") as f:
-                names = [f"{nd.op}:{nd.conv_key or nd.fc1_key or nd.scale_key}" for nd in g.nodes] + ["softmax_decode", "tau + select_nms_fast", "merge", "fallback select"]
+                names = [f"{nd.op}:{nd.conv_key or nd.fc1_key or nd.scale_key}" for nd in g.nodes] + ["softmax_decode (small levels + cut-off)", "select_nms_fast", "merge", "fallback select"]
                 members = {}
                 for i, c in enumerate(costs):
                     members.setdefault(c["owner"], []).append(i)

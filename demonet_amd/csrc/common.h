@@ -384,6 +384,7 @@ struct PostArgs {
     bool scores_ready = false;
     HistRows hrows;
     int small_first = -1;       // with scores_ready: first anchor still in logit form (the levels below 32 pixels per image); -1 / A: none
+    unsigned* tickets = nullptr; // with small levels: one zeroed counter per image (left at zero) -> the cut-off runs in the last softmax tile of the image, no tau launch
 };
 // where launch_postprocess keeps its arrays inside the workspace it is given (the fused head launch writes the first three itself)
 struct PostBuffers {

@@ -124,6 +124,7 @@ struct dn_plan {
     std::vector<int> se_in_dw;              // per op: DW op -> index of the SE op whose FCs run in its tail (depthwise.hip dw_se_tail), SE op -> -2, else -1
     int n_se_in_dw = 0;                     // such pairs; slot q of the counter block belongs to the q-th
     std::vector<int> se_slot;               // per op (DW op of a pair): q
+    int post_ticket_slot = -1;              // slot of the counter block lent to launch_postprocess (PostArgs::tickets); needs the stem launch that zeroes the block
     std::vector<int> se_fold;               // per op: PW op -> index of the SE op whose FCs run in its prologue (pointwise.hip SEF), SE op -> -2, else -1
     std::vector<char> tail_materialise;     // per op of the run: its output is read outside the run (pyramid feature) -> also to HBM            // optional extra output of the merge kernel (dn_set_packed_output)
     // inverted-residual stages that run as one launch (expdw.hip): at the first op of a group, fused_len = number of ops and
@@ -513,6 +514,9 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             p->n_se_in_dw += COOP_MAX_STEPS;
         }
     }
+    p->post_ticket_slot = -1;
+    for (int i = 0; i < desc->n_ops; ++i)
+        if (p->ops[i].type == DN_OP_STEM) { p->post_ticket_slot = p->n_se_in_dw++; break; }
     // partial-sum rows of every pooled tensor = workgroups per image of its producing depthwise op
     p->pool_blocks.assign(desc->n_tensors, 0);
     for (int i = 0; i < desc->n_ops; ++i) {
@@ -1255,6 +1259,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
         a.ws = ws + L.post_off; a.ws_bytes = L.post_bytes;
         a.xq = xq;
         a.scores_ready = scores_ready; a.hrows = fused_rows; a.small_first = small_first;
+        if (scores_ready && p->post_ticket_slot >= 0) a.tickets = reinterpret_cast<unsigned*>(ws + L.secnt_off) + (size_t)p->post_ticket_slot * n;
         hipEvent_t* pe = record ? &p->events[ev] : nullptr;
         int rc = launch_postprocess(a, s, pe);
         if (rc) return rc;

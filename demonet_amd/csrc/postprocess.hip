@@ -44,6 +44,82 @@ constexpr int HBINS = DN_PP_HBINS;                       // bins kept: the top 2
 // ------------------------------------------------------------------------------------------------------------
 // P1
 // ------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------
+// Cut-off (the body of tau_kernel; since round 5 also run by the LAST softmax tile of an image when the head launch produced the scores of
+// the large levels, TauArgs::tickets): only candidates that can reach the global top-D matter. tau = lower edge of the highest histogram
+// bin whose suffix count reaches `want` (a multiple of D). Greedy NMS restricted to the score >= tau prefix of each class is exact for
+// that prefix; if at least D boxes survive, every box with score < tau ranks below them and cannot appear in the output. Otherwise
+// needFull[n] triggers the full path.
+// ------------------------------------------------------------------------------------------------------------
+struct TauArgs {
+    const unsigned* phist; int tiles, hb0, clamped; unsigned want;
+    unsigned* tauKey; int* needFull; int nimg, xq, nb, Km1; int* order; int* fbcnt; HistRows hr;
+};
+template <bool AGENT>     // AGENT: the extra rows (softmax tiles of THIS launch, other workgroups) are read with agent-scope loads
+__device__ __forceinline__ void tau_body(const TauArgs& t, const int n, unsigned* __restrict__ part) {
+    const int tid = threadIdx.x;
+    const int nb = t.nb, Km1 = t.Km1;
+    const HistRows& hr = t.hr;
+    unsigned s = 0;
+    if (hr.levels == 0) {
+        // thread t owns bin t: sum of the per-workgroup rows of softmax_decode_kernel (fixed order, 16 loads in flight)
+        const unsigned* h = t.phist + ((size_t)n * t.tiles << 8) + tid;
+        for (int t0 = 0; t0 < t.tiles; t0 += 16) {
+            unsigned v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = h[(size_t)min(t0 + u, t.tiles - 1) << 8];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += (t0 + u < t.tiles) ? v[u] : 0u;
+        }
+    } else {
+        // rows of head_fused_kernel's epilogue: per level, the 32-pixel half tiles that touch this image, in slots sbase .. (HistRows). Exactly
+        // the slots counted here were written in this forward; integer sums, so the order does not matter.
+        const unsigned* h = t.phist + (size_t)n * hr.rows_per_image * 256 + tid;
+        for (int l = 0; l < hr.levels; ++l) {
+            const int nl = hr.grouped[l] ? n - (n / t.xq) * t.xq : n;                // image index inside its XCD group's pixel range
+            const int cnt = (((nl + 1) * hr.hw[l] - 1) >> 5) - ((nl * hr.hw[l]) >> 5) + 1;
+            const unsigned* hl = h + (size_t)hr.sbase[l] * 256;
+            for (int t0 = 0; t0 < cnt; t0 += 8) {
+                unsigned v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = hl[(size_t)min(t0 + u, cnt - 1) << 8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (t0 + u < cnt) ? v[u] : 0u;
+            }
+        }
+        for (int q = 0; q < hr.extra_rows; ++q) {
+            const unsigned* e = h + ((size_t)(hr.extra_base + q) << 8);
+            s += AGENT ? __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *e;
+        }
+    }
+    part[tid] = s;
+    __syncthreads();
+    unsigned above = 0;
+    for (int q = tid + 1; q < nb; ++q) above += part[q];
+    // the unique thread where the suffix count (from the top bin down) crosses `want`: tau = lower edge of its bin. Bin 0 of a
+    // clamped table also holds every lower score -> tau 0 (take everything above the score threshold).
+    if (tid < nb && above < t.want && above + s >= t.want) t.tauKey[n] = (t.clamped && tid == 0) ? 0u : (unsigned)(t.hb0 + tid) << HSHIFT;
+    // classes by descending count of passing scores (ties: ascending class): the per-class workgroups of the next launch are
+    // dispatched in this order, the heavy ones first, so the launch does not end on a late-started heavy class. No counts
+    // (the row has no room): identity.
+    if (nb + Km1 <= HBINS) {
+        if (tid >= nb && tid < nb + Km1) {
+            int rank = 0;
+            for (int q = nb; q < nb + Km1; ++q) rank += (part[q] > s || (part[q] == s && q < tid)) ? 1 : 0;
+            t.order[(size_t)n * Km1 + rank] = tid - nb;
+        }
+    } else {
+        for (int c = tid; c < Km1; c += 256) t.order[(size_t)n * Km1 + c] = c;
+    }
+    if (tid == 0) {
+        unsigned total = 0;
+        for (int q = 0; q < nb; ++q) total += part[q];
+        if (total < t.want) t.tauKey[n] = 0u;    // fewer passing scores than wanted: take everything
+        t.needFull[n] = 0;
+        t.fbcnt[n] = 0;                          // ticket of the fused fallback merge (select_nms_kernel)
+    }
+}
+
 // One tile of 64 anchors [a0, a0 + na) of image n: softmax over the classes, scores out class-major, score histogram + per-class counts of the
 // passing scores ADDED to lhist (the caller zeroes and flushes it), boxes decoded. tile: [64][K] floats + rowsum[64] of LDS. Ends with its LDS
 // reads done only after the caller's next barrier.
@@ -123,7 +199,7 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
                                                             float4* __restrict__ boxes, int A, int K, float img_w, float img_h,
                                                             float score_thr, unsigned* __restrict__ phist, int hb0, int nb,
                                                             long long* __restrict__ stamps, int nimg, int tiles, int xq, PostLevels lv,
-                                                            int a_base, int row_stride, int row_base) {
+                                                            int a_base, int row_stride, int row_base, unsigned* __restrict__ tickets, TauArgs tau) {
     // the launch covers the anchors [a_base, a_base + 64 tiles) of every image; a tile's histogram goes to row row_base + tile of the image's row_stride rows
     extern __shared__ float tile[];            // [64][K] then rowsum[64] then hist[HBINS]
     float* rowsum = tile + 64 * K;
@@ -142,7 +218,27 @@ __global__ __launch_bounds__(256) void softmax_decode_kernel(const float* __rest
     PP_STAMP(11);
     // this workgroup's histogram goes to its own row; tau_kernel adds the rows. (Device-scope atomics into one per-image table
     // made a few workgroups per launch wait 15-25 us on the hot bins: the kernel's whole tail.)
-    phist[(((size_t)n * row_stride + row_base + atile) << 8) + threadIdx.x] = (threadIdx.x < nb + (ccb >= 0 ? K - 1 : 0)) ? lhist[threadIdx.x] : 0u;
+    unsigned* const rowp = phist + (((size_t)n * row_stride + row_base + atile) << 8) + threadIdx.x;
+    const unsigned rowv = (threadIdx.x < nb + (ccb >= 0 ? K - 1 : 0)) ? lhist[threadIdx.x] : 0u;
+    if (!tickets) {
+        *rowp = rowv;
+    } else {
+        // The cut-off of the image in the LAST of its softmax tiles to finish (round 5: one dependent launch less behind the head launch): the row
+        // goes out write-through (agent-scope store), every storing thread waits for its acknowledgement, the barrier orders those waits before
+        // thread 0's relaxed ticket, and the workgroup that draws the last ticket reads the other tiles' rows with agent-scope loads -- the
+        // hand-over of depthwise.hip's squeeze-excitation tail, no cache-flushing fence. The head launch's rows come from an EARLIER launch.
+        // Counters: zeroed by the stem launch of every forward, left at zero here.
+        __hip_atomic_store(rowp, rowv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __shared__ int s_last;
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&tickets[n], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(tiles - 1);
+        __syncthreads();
+        if (s_last) {
+            tau_body<true>(tau, n, lhist);          // (lhist: 256 words of LDS nobody needs any more)
+            if (threadIdx.x == 0) tickets[n] = 0u;
+        }
+    }
     PP_STAMP(12);
 }
 
@@ -557,74 +653,12 @@ __global__ __launch_bounds__(256) void select_nms_kernel(const float* __restrict
     select_nms_one<NW, PERM>(scoresT, boxes, A, Km1, score_thr, nms_thr, topk, keptScore, keptAnchor, keptCount, stamps, lv, n, cls);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Cut-off: only candidates that can reach the global top-D matter. tau = lower edge of the highest histogram bin
-// whose suffix count reaches `want` (a multiple of D). Greedy NMS restricted to the score >= tau prefix of each class
-// is exact for that prefix (decisions only depend on higher-scored boxes); if at least D boxes survive, every box
-// with score < tau ranks below them and cannot appear in the output. Otherwise needFull[n] triggers the full path.
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tau_kernel(const unsigned* __restrict__ phist, int tiles, int hb0, int clamped, unsigned want,
-                                                 unsigned* __restrict__ tauKey, int* __restrict__ needFull, int nimg, int xq,
-                                                 int nb, int Km1, int* __restrict__ order, int* __restrict__ fbcnt, HistRows hr) {
+// the cut-off as a launch of its own (one workgroup per image)
+__global__ __launch_bounds__(256) void tau_kernel(TauArgs t) {
     __shared__ unsigned part[256];
-    const int tid = threadIdx.x;
     int n, unused;
-    if (!xcd_image_of(blockIdx.x, 1, xq, nimg, n, unused)) return;
-    unsigned s = 0;
-    if (hr.levels == 0) {
-        // thread t owns bin t: sum of the per-workgroup rows of softmax_decode_kernel (fixed order, 16 loads in flight)
-        const unsigned* h = phist + ((size_t)n * tiles << 8) + tid;
-        for (int t0 = 0; t0 < tiles; t0 += 16) {
-            unsigned v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = h[(size_t)min(t0 + u, tiles - 1) << 8];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s += (t0 + u < tiles) ? v[u] : 0u;
-        }
-    } else {
-        // rows of head_fused_kernel's epilogue: per level, the 32-pixel half tiles that touch this image, in slots sbase .. (HistRows). Exactly
-        // the slots counted here were written in this forward; integer sums, so the order does not matter.
-        const unsigned* h = phist + (size_t)n * hr.rows_per_image * 256 + tid;
-        for (int l = 0; l < hr.levels; ++l) {
-            const int nl = hr.grouped[l] ? n - (n / xq) * xq : n;                    // image index inside its XCD group's pixel range
-            const int cnt = (((nl + 1) * hr.hw[l] - 1) >> 5) - ((nl * hr.hw[l]) >> 5) + 1;
-            const unsigned* hl = h + (size_t)hr.sbase[l] * 256;
-            for (int t0 = 0; t0 < cnt; t0 += 8) {
-                unsigned v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = hl[(size_t)min(t0 + u, cnt - 1) << 8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s += (t0 + u < cnt) ? v[u] : 0u;
-            }
-        }
-        for (int t = 0; t < hr.extra_rows; ++t) s += h[(size_t)(hr.extra_base + t) << 8];
-    }
-    part[tid] = s;
-    __syncthreads();
-    unsigned above = 0;
-    for (int t = tid + 1; t < nb; ++t) above += part[t];
-    // the unique thread where the suffix count (from the top bin down) crosses `want`: tau = lower edge of its bin. Bin 0 of a
-    // clamped table also holds every lower score -> tau 0 (take everything above the score threshold).
-    if (tid < nb && above < want && above + s >= want) tauKey[n] = (clamped && tid == 0) ? 0u : (unsigned)(hb0 + tid) << HSHIFT;
-    // classes by descending count of passing scores (ties: ascending class): the per-class workgroups of the next launch are
-    // dispatched in this order, the heavy ones first, so the launch does not end on a late-started heavy class. No counts
-    // (fused epilogue, or the row has no room): all zero -> identity.
-    if (nb + Km1 <= HBINS) {
-        if (tid >= nb && tid < nb + Km1) {
-            int rank = 0;
-            for (int t = nb; t < nb + Km1; ++t) rank += (part[t] > s || (part[t] == s && t < tid)) ? 1 : 0;
-            order[(size_t)n * Km1 + rank] = tid - nb;
-        }
-    } else {
-        for (int c = tid; c < Km1; c += 256) order[(size_t)n * Km1 + c] = c;
-    }
-    if (tid == 0) {
-        unsigned total = 0;
-        for (int t = 0; t < nb; ++t) total += part[t];
-        if (total < want) tauKey[n] = 0u;        // fewer passing scores than wanted: take everything
-        needFull[n] = 0;
-        fbcnt[n] = 0;                            // ticket of the fused fallback merge (select_nms_kernel)
-    }
+    if (!xcd_image_of(blockIdx.x, 1, t.xq, t.nimg, n, unused)) return;
+    tau_body<false>(t, n, part);
 }
 
 // Fast path of P2: same semantics as select_nms_kernel restricted to keys >= tau. A class with more than topk scores >= tau keeps
@@ -1066,7 +1100,9 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     post_hist_range(a.score_thresh, &hb0, &nb, &clamped);
     const size_t lds1 = (size_t)(64 * a.K + 64) * sizeof(float) + (size_t)HBINS * sizeof(unsigned);
     const int slots = xcd_image_slots(a.xq, a.n);
-    const int hist_rows = tiles;    // per-image rows of the histogram table tau_kernel adds up
+    const TauArgs targs{phist, tiles, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq, nb, (int)(a.K - 1), order, fbcnt, hrows};
+    // the cut-off inside the softmax launch of the small levels (its last tile per image): when that launch exists and the caller gave counters
+    const bool fold_tau = fast && a.scores_ready && small_tiles > 0 && a.tickets != nullptr && (a.lv.n == 1 && a.lv.aloc[0] == 1) && dn_knob("DN_PP_FOLD_TAU", 1) != 0;
     {
         // every anchor (plain path), or the anchors [small_first, A) the fused head launch left in logit form: a few tiles per image, their histogram
         // rows behind the head launch's rows
@@ -1077,18 +1113,16 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
             if (!(a.lv.n == 1 && a.lv.aloc[0] == 1))
                 hipLaunchKernelGGL(softmax_decode_kernel<true>, dim3(t1 * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
                                    scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
-                                   a.n, t1, a.xq, a.lv, abase, rstride, rbase);
+                                   a.n, t1, a.xq, a.lv, abase, rstride, rbase, (unsigned*)nullptr, TauArgs{});
             else
                 hipLaunchKernelGGL(softmax_decode_kernel<false>, dim3(t1 * slots), dim3(256), lds1, s, a.logits, a.reg, a.anchors,
                                    scoresT, boxes, a.A, a.K, a.img_w, a.img_h, a.score_thresh, phist, hb0, nb, const_cast<long long*>(stp),
-                                   a.n, t1, a.xq, a.lv, abase, rstride, rbase);
+                                   a.n, t1, a.xq, a.lv, abase, rstride, rbase, fold_tau ? a.tickets : (unsigned*)nullptr, targs);
         }
     }
     if (ev) (void)hipEventRecord(ev[1], s);
     int rc = DN_OK;
-    if (fast)
-        hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, phist, hist_rows, hb0, clamped, (unsigned)(want_mult * a.dets), tauKey, needFull, a.n, a.xq,
-                           nb, (int)Km1, order, fbcnt, hrows);
+    if (fast && !fold_tau) hipLaunchKernelGGL(tau_kernel, dim3(slots), dim3(256), 0, s, targs);
     if (fast) {
         const int* ord = dn_knob("DN_PP_ORDER", 1) ? order : nullptr;      // heaviest classes first (0: class order)
         if (nw <= 1) rc = launch_p2_fast<1>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);

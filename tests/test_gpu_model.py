@@ -1035,6 +1035,30 @@ def test_softmax_in_the_head_launch_feeds_the_same_cut_off(monkeypatch):
             assert torch.equal(res["0", "0"][q], res[key][q]), (key, q)
 
 
+@pytest.mark.parametrize("n", [64, 33, 5])
+def test_cut_off_in_the_last_softmax_tile_equals_the_cut_off_launch(n, monkeypatch):
+    """Round 5: with the large levels' scores from the head launch, the cut-off (tau, class order, fallback flags) runs in whichever of an image's
+    small-level softmax tiles finishes last (ticket per image, postprocess.hip tau_body) instead of a launch of its own. Integer sums of the
+    same rows: detections bit-identical to the separate launch (DN_PP_FOLD_TAU=0), on the first forward, on graph replays (the tickets must be
+    back at zero), and with no cut-off at all (DN_PP_FAST=0)."""
+    imgs = torch.from_numpy(synth.images(101, n, 320, 320)).cuda()
+    monkeypatch.setenv("DN_HEAD_SOFTMAX_MINN", "1")
+    res = {}
+    for fold, fast in (("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("DN_PP_FOLD_TAU", fold)
+        monkeypatch.setenv("DN_PP_FAST", fast)
+        m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+        res[fold, fast] = [t.clone() for t in m.forward_batch(imgs)]
+        for _ in range(3):
+            again = m.forward_batch(imgs)
+            for q in range(4):
+                assert torch.equal(res[fold, fast][q], again[q]), (fold, fast, q)
+    for key in (("1", "1"), ("1", "0")):
+        for q in range(4):
+            assert torch.equal(res["0", "1"][q], res[key][q]), (key, q)
+    assert int(res["1", "1"][3].sum()) > 0
+
+
 @pytest.mark.parametrize("n", [64, 37, 8, 3, 1])
 def test_cooperative_small_map_stage_matches_the_launch_per_layer_path(n, monkeypatch):
     """Round 5 (coop.hip, DN_COOP=1; off by default -- it measures slower than the launches it replaces except as one chain of 64 images): the 10 x 10 stage of MobileNetV3 -- SE-scaled projection, two 80 -> 480 -> 80 squeeze-excitation
