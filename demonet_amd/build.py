@@ -35,7 +35,7 @@ def build_stamps(verbose=True):
     (per-workgroup phase stamps and the dn_debug_*_stamps / dn_debug_pw_tile exports: tools/probe_*.py, tools/tune_pw.py). Load it with
     DEMONET_HIP_LIB=<path>; the product library carries neither the stamps nor those exports."""
     build(verbose=verbose)
-    stamped = ["headfuse.hip", "expdw.hip", "pointwise.hip", "depthwise.hip", "postprocess.hip", "tail.hip", "coop.hip"]
+    stamped = ["headfuse.hip", "expdw.hip", "pointwise.hip", "depthwise.hip", "postprocess.hip", "tail.hip", "coop.hip", "convbig.hip"]
     objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s not in stamped]
     for src in stamped:
         obj = os.path.join(LIBDIR, src.replace(".hip", "_stamps.o"))

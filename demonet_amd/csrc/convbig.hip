@@ -23,6 +23,24 @@
 
 #include "common.h"
 
+#ifdef DN_DEV_STAMPS
+static long long* g_patch_stamps = nullptr;     // dev build only (tools/probe_patch.py): per-workgroup phase stamps [workgroup][8]
+static size_t g_patch_stamps_used = 0;          // every launch takes its own [workgroups][8] region behind the previous one's
+extern "C" __attribute__((visibility("default"))) void dn_debug_patch_stamps(void* dev_ptr) { g_patch_stamps = (long long*)dev_ptr; g_patch_stamps_used = 0; }
+static long long* patch_stamps_take(size_t workgroups) {
+    if (!g_patch_stamps) return nullptr;
+    long long* p = g_patch_stamps + g_patch_stamps_used;
+    g_patch_stamps_used += workgroups * 8;
+    return p;
+}
+#define CP_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define CP_STAMP_IF(c, k) do { if (c) CP_STAMP(k); } while (0)
+#else
+#define CP_STAMP_IF(c, k) do { } while (0)
+static long long* patch_stamps_take(size_t) { return nullptr; }
+#define CP_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BP = 256, BC = 256;
@@ -604,22 +622,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 namespace {
 
+// Result of a 16 x 16 block (conv_patch_kernel, conv_patch_resident_kernel) -> LDS [256 pixels][64 + 8] halfs: bias, activation, fp16. The bias comes
+// in registers and the activation is ONE uniform branch around all 64 values of the lane (round 5: per 4-value chunk the old form read its bias
+// from LDS, waited, and walked the activation switch -- sixteen dependent LDS round trips per block, 1.6 us of a 7 us block, tools/probe_patch.py).
+template <typename F>
+__device__ __forceinline__ void patch_emit_t(const floatx16 (&acc)[2][2], const float4 (&bq)[2][4], half_t* ot, int wave, int r, int hh, F actf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int prow = (4 * wave + 2 * j) * 16 + r;           // pixel index inside the block
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = bq[i][g];
+                half4 hv;
+                hv[0] = (half_t)actf(acc[i][j][4 * g + 0] + bv.x); hv[1] = (half_t)actf(acc[i][j][4 * g + 1] + bv.y);
+                hv[2] = (half_t)actf(acc[i][j][4 * g + 2] + bv.z); hv[3] = (half_t)actf(acc[i][j][4 * g + 3] + bv.w);
+                *reinterpret_cast<half4*>(&ot[prow * 72 + i * 32 + 8 * g + 4 * hh]) = hv;
+            }
+    }
+}
+__device__ __forceinline__ void patch_emit(const floatx16 (&acc)[2][2], const float4 (&bq)[2][4], half_t* ot, int wave, int r, int hh, int act) {
+    if (act == DN_ACT_RELU) patch_emit_t(acc, bq, ot, wave, r, hh, [](float v) { return dn_relu(v); });
+    else if (act == DN_ACT_NONE) patch_emit_t(acc, bq, ot, wave, r, hh, [](float v) { return v; });
+    else patch_emit_t(acc, bq, ot, wave, r, hh, [act](float v) { return dn_act(v, act); });
+}
+
 // ---- 64 input channels at full resolution (VGG conv1_2, conv2_1: 300^2 .. 512^2 maps) -----------------------------------------------
 // The flattened run of conv_halo_kernel needs 2 W + 2 halo rows -- too many for W >= 300 -- and with cin = 64 the whole K range of a
 // pixel is 128 B. Here a workgroup owns a 16 x 16 block of output pixels x 64 output channels: the 18 x 18 input patch (all 64
 // channels, 41 KB) is staged ONCE, zero-filled outside the image, so no tap needs a mask; the nine taps are nine row shifts of the
-// fragment reads inside the patch; only the weights stream (one 8-KB tap per stage, double-buffered). 58 KB of LDS and 64 accumulator
-// registers per workgroup: two workgroups per CU cover each other's barriers. Staging by LDS-DMA with the 128-B-row swizzle.
+// fragment reads inside the patch; only the weights stream: 18 stages per slice of (one tap, 32 input channels) = 4 KB, three buffers,
+// requested two stages ahead with a counted wait. 53760 B of LDS and 144 registers per lane: THREE workgroups per CU (round 5; 58 KB
+// and two before -- a workgroup lives 12.9 us for 1.9 us of matrix work: 2.5 us waiting for its patch, 2 + 0.9 us writing its result, and
+// the tap phases of two workgroups overlap only 58 % of the time, tools/probe_patch.py). Staging by LDS-DMA with the row swizzles.
 constexpr int PT = 16, PP = PT + 2;             // output block edge, patch edge
-constexpr int PATCH_ROWS = 328;                 // 18 * 18 = 324 pixels, rounded up to 8-row DMA pieces
+constexpr int PATCH_ROWS = PP * PP;             // 324 pixels (the last 8-row DMA piece moves 4 rows)
 constexpr int PATCH_HALFS = PATCH_ROWS * 64;
-constexpr int WTAP_HALFS = 64 * 64;             // one tap of 64 output channels
+constexpr int WST_HALFS = 64 * 32;              // one weight stage: 64 output channels x 32 input channels of one tap
+constexpr int WST_BUFS = 3;                     // stages in LDS: the one being read and the two after it (requested two stages ahead; 9 deep with two
+                                                // workgroups per CU measured slower: the bound is the L2 -> LDS traffic itself, not its latency)
+constexpr int PATCH_LDS = (PATCH_HALFS + WST_BUFS * WST_HALFS) * 2;            // 53760 B = 42 allocation granules of 1280 B: THREE workgroups per CU
+                                                                                // (measured, tools/lds_occ.hip: 53760 -> 3 resident, 54016 -> 2)
 
-__global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_patch_kernel(PwArgs a, long long* __restrict__ stamps) {      // (three waves per SIMD: at most 168 registers)
     extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];
-    float* bsh = reinterpret_cast<float*>(lds_raw);             // [64]
-    half_t* patch = lds_raw + 128;                              // [PATCH_ROWS][64], swizzled 16-B chunks
-    half_t* wbuf = patch + PATCH_HALFS;                         // [2][64][64]
+    half_t* patch = lds_raw;                                    // [PATCH_ROWS][64], swizzled 16-B chunks
+    half_t* wbuf = patch + PATCH_HALFS;                         // [WST_BUFS][64][32], swizzled 16-B chunks
+    const float* bsh = nullptr;                                 // [64] bias: no room of its own -- parked in the weight buffer the last stage leaves free
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int H = a.cv_h, W = a.cv_w, NC = a.cout;
@@ -631,7 +681,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
     const char* zeros = reinterpret_cast<const char*>(a.zeros);
     const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)n0 * 9 * CIN * 2;
 
-    // DMA geometry: an instruction moves 8 rows of 128 B; lane -> row lane >> 3, position lane & 7, source chunk = position ^ ((row >> 1) & 7)
+    // Swizzles (round 5, after SQ_LDS_BANK_CONFLICT showed 49 % of this kernel's LDS cycles were conflicts): ds_read_b128 serves the lane groups
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) from 64 banks = sixteen 16-B slots (MI355X_MICROARCH.md, LDS). A B fragment's group is 8 pixels
+    // of one patch row and 8 of the next (columns {0-3, 12-15} | {4-11} or the other way round, shifted by kx): slot = 8 (column & 1) + position,
+    // so the position is the chunk XOR (COLUMN >> 1) & 7 -- by column, not by pixel index, whose rows are 18 apart and collided.
+    // patch DMA: an instruction moves 8 rows of 128 B; lane -> row lane >> 3, position lane & 7, source chunk = position ^ ((column >> 1) & 7)
     const int lrow = lane >> 3, lpos = lane & 7;
     // patch pieces: 41 per workgroup, wave w takes pieces w, w + 4, ...
     auto issue_patch = [&](int slice) {
@@ -642,24 +696,27 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
             const int q = pc * 8 + lrow;
             const int py = q / PP, px = q - py * PP;
             const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-            const bool ok = q < PP * PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const int chunk = lpos ^ ((q >> 1) & 7);
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int chunk = lpos ^ ((px >> 1) & 7);
             const char* p = ok ? xbase + ((size_t)iy * W + ix) * CIN * 2 + slice * 128 + chunk * 16 : zeros;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(patch + pc * 8 * 64), 16, 0, 0);
+            if (q < PATCH_ROWS) __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(patch + pc * 8 * 64), 16, 0, 0);     // (the last piece: 4 rows)
         }
     };
-    auto issue_w = [&](int slice, int tap, int b) {              // 64 rows: 8 pieces, two per wave
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = (wave * 2 + u) * 8 + lrow;
-            const int chunk = lpos ^ ((row >> 1) & 7);
-            const char* p = wbase + (((size_t)row * 9 + tap) * CIN + slice * 64) * 2 + chunk * 16;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(wbuf + b * WTAP_HALFS + (wave * 2 + u) * 8 * 64), 16, 0, 0);
-        }
+    // weight stage st = (slice, tap, K half): 64 rows of 64 B = four instructions of 16 rows, ONE per wave (so every wave's vmcnt counts stages);
+    // lane -> row lane >> 2, position lane & 3, source chunk = position ^ ((row >> 2) & 3) (64-B rows: slot = 4 (row & 3) + position, and the rows
+    // of a read group with equal row & 3 are {0, 12, 20, 24} / {4, 8, 16, 28} + ..)
+    const int wrow = wave * 16 + (lane >> 2), wchunk = (lane & 3) ^ ((wrow >> 2) & 3);
+    const char* wlane = wbase + (size_t)wrow * 9 * CIN * 2 + wchunk * 16;
+    auto issue_w = [&](int st, int b) {
+        const int sl = st / 18, rem = st - sl * 18;
+        const int tap = rem >> 1, kh = rem & 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)(wlane + ((size_t)tap * CIN + sl * 64 + kh * 32) * 2), (lptr_t)(wbuf + b * WST_HALFS + wave * 16 * 32), 16, 0, 0);
     };
+    CP_STAMP(0);
     issue_patch(0);
-    issue_w(0, 0, 0);
-    if (tid < 64) bsh[tid] = a.bias[n0 + tid];
+#pragma unroll
+    for (int q = 0; q + 1 < WST_BUFS; ++q) issue_w(q, q);
+    const float bias_r = tid < 64 ? a.bias[n0 + tid] : 0.f;
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -672,60 +729,70 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
     int q0[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) q0[j] = (4 * wave + 2 * j + (r >> 4)) * PP + (r & 15);       // patch pixel of tap (0, 0)
-    const int wsw = (r >> 1) & 7;
+    const int wsw = (r >> 2) & 3;
+    const int xcol = r & 15;                                     // patch column of tap kx = 0
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int sl = 0; sl < NS; ++sl) {
-        for (int tap = 0; tap < 9; ++tap) {
-            const int b = (sl * 9 + tap) & 1;
-            if (tap + 1 < 9) issue_w(sl, tap + 1, b ^ 1);
-            else if (sl + 1 < NS) issue_w(sl + 1, 0, b ^ 1);
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const half_t* wb = wbuf + b * WTAP_HALFS;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                half8 xf[2], wf[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int q = q0[j] + ky * PP + kx;
-                    xf[j] = *reinterpret_cast<const half8*>(patch + q * 64 + (((2 * ks + hh) ^ ((q >> 1) & 7)) * 8));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + (i * 32 + r) * 64 + (((2 * ks + hh) ^ wsw) * 8));
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-            }
-            if (tap == 8 && sl + 1 < NS) {
-                // everyone is done with this slice's patch only after the barrier: restage it behind one
-                __syncthreads();
-                issue_patch(sl + 1);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+    CP_STAMP(1);
+    // 18 stages of 8 MFMAs per slice. A stage's weights were requested two stages ahead; the buffer requested now was read in the stage before
+    // this one, which every wave left through the barrier in front of this stage.
+    const int T = NS * 18;
+    int b = 0;                                                   // buffer of stage st
+    for (int st = 0; st < T; ++st) {
+        const int b2 = b >= 1 ? b - 1 : WST_BUFS - 1;            // buffer of stage st - 1 = of stage st + WST_BUFS - 1
+        if (st + WST_BUFS - 1 < T) issue_w(st + WST_BUFS - 1, b2);
+        if (st + 1 == T) {                                       // (the buffer of stage T - 2: read by nobody any more, published by this stage's barrier)
+            float* bw = reinterpret_cast<float*>(wbuf + b2 * WST_HALFS);
+            if (tid < 64) bw[tid] = bias_r;
+            bsh = bw;
         }
+        const int rem = st % 18;
+        const int tap = rem >> 1, kh = rem & 1;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const half_t* wb = wbuf + b * WST_HALFS;
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) {
+            const int ks = kh * 2 + ksl;
+            half8 xf[2], wf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = q0[j] + ky * PP + kx;
+                xf[j] = *reinterpret_cast<const half8*>(patch + q * 64 + (((2 * ks + hh) ^ (((xcol + kx) >> 1) & 7)) * 8));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const half8*>(wb + (i * 32 + r) * 32 + (((2 * ksl + hh) ^ wsw) * 8));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        if (rem == 17 && st + 1 < T) {
+            // everyone is done with this slice's patch only after the barrier: restage it behind one
+            __syncthreads();
+            issue_patch(st / 18 + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (st + WST_BUFS - 1 < T) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WST_BUFS - 2) : "memory");    // stage st + 1 has landed (this wave's part), the later ones may be in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        b = b + 1 < WST_BUFS ? b + 1 : 0;
     }
+    CP_STAMP(2);
     // epilogue: block -> LDS [256 pixels][64 + 8] halfs over the patch, then 16-B chunks: a block row is 2 KB contiguous in NHWC
     half_t* ot = patch;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int prow = (4 * wave + 2 * j) * PT + r;           // pixel index inside the block
+    {
+        float4 bq[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = i * 32 + 8 * g + 4 * hh;
-                const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
-                half4 hv;
-                float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
-                dn_act_n<float[4], 4>(t4, a.act);
-                hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
-                *reinterpret_cast<half4*>(&ot[prow * 72 + cl]) = hv;
-            }
+            for (int g = 0; g < 4; ++g) bq[i][g] = *reinterpret_cast<const float4*>(&bsh[i * 32 + 8 * g + 4 * hh]);
+        patch_emit(acc, bq, ot, wave, r, hh, a.act);
     }
     __syncthreads();
+    CP_STAMP(3);
     if (a.pool_out) {
         // fused MaxPool2d(kernel 2, stride 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the 16 x 16 block pools to 8 x 8,
         // block origins are multiples of 16 and H, W are even, so every window lies inside one block. The conv output itself
@@ -753,6 +820,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
                 *reinterpret_cast<half8*>(pout + ((size_t)oy * WP + ox) * NC + n0 + ch * 8) = mx;
             }
         }
+        CP_STAMP(4);
         return;
     }
     half_t* outp = reinterpret_cast<half_t*>(a.out) + (size_t)img * H * W * NC;
@@ -764,6 +832,260 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(PwArgs a) {
         if (oy < H && ox < W)
             *reinterpret_cast<uint4*>(outp + ((size_t)oy * W + ox) * NC + n0 + ch * 8) = *reinterpret_cast<const uint4*>(&ot[px * 72 + ch * 8]);
     }
+    CP_STAMP(4);
+}
+
+// ---- the same block with 64 input channels, weights RESIDENT (round 5; VGG conv1_2 and conv2_1) ---------------------------------------------
+// What bounded conv_patch_kernel was never the matrix pipe (0.31) nor the LDS array (30 % busy, SQ_LDS_IDX_ACTIVE) but everything around the
+// multiplication: every 16 x 16 block streamed its nine taps (72 KB) next to its 41 KB patch -- 3.7 GB of L2 -> LDS traffic for conv1_2 of ssd512 --
+// behind one barrier per tap, waited for its patch, and wrote its result through LDS: a workgroup lived 12.9 us for 1.9 us of matrix work
+// (tools/probe_patch.py). With cin = 64 the nine taps of 64 output channels are 72 KB: ONE workgroup per CU keeps them in LDS for its whole life
+// and walks over blocks (persistent, 256 workgroups). Per block and wave: 36 steps of four MFMAs with no barrier and no wait on memory, and
+// riding in the same instruction stream (a) the LDS-DMA requests of the NEXT block's patch into the other patch buffer (one piece per step:
+// ~60 cycles of issue under 96 cycles of MFMA), (b) the PREVIOUS block's result straight from its accumulator copy to memory -- bias, ReLU, fp16,
+// the 2 x 2 max-pool across lanes (v_permlane16_swap for the row pair, a quad DPP for the column pair) and 8-byte stores whose out-of-image lanes
+// carry an out-of-range buffer offset -- no LDS staging, no branch, one barrier per block. The fragments of step s + 1 are requested behind the
+// FIRST MFMA of step s (sched_group_barrier; the order the compiler picks on its own leaves a read 32 cycles of cover: 3.8 vs 2.5 us per block).
+// Blocks are dealt out so that the 32 workgroups of an XCD work on 32 consecutive blocks (neighbours share their halo in that XCD's L2).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// maximum of two packed fp16 pairs that are known to be ordinary numbers (the results of a ReLU): the instruction itself -- through
+// __builtin_elementwise_max every operand is canonicalised first (three v_pk_max_f16 for one)
+__device__ __forceinline__ unsigned pk_max_f16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int RW_HALFS = 9 * 64 * 64;           // resident weights [tap][64 rows][64], rows swizzled by (row >> 1) & 7
+constexpr int RP_HALFS = 328 * 64;              // a patch buffer: 41 whole DMA pieces of 8 rows (rows 324.. are never read)
+constexpr int RES_LDS = (RW_HALFS + 2 * RP_HALFS) * 2;             // 157696 B
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv_patch_resident_kernel(PwArgs a, int tiles_x, int tiles_per_image, int ntiles, long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) half_t lds_raw[];
+    half_t* wres = lds_raw;
+    half_t* pbuf = wres + RW_HALFS;                             // [2][328][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int H = a.cv_h, W = a.cv_w, NC = a.cout;
+    const int n0 = blockIdx.y * 64;
+    // blocks of this workgroup: XCD x = blockIdx.x & 7 owns [x N / 8, (x + 1) N / 8), its workgroup `slot` of `per` takes every per-th of them
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int lo = (int)((long)xcd * ntiles / 8), hi = (int)((long)(xcd + 1) * ntiles / 8);
+    const int first = lo + slot;
+    if (first >= hi) return;
+    const int nmine = (hi - first + per - 1) / per;
+    const char* zeros = reinterpret_cast<const char*>(a.zeros);
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)n0 * 9 * 64 * 2;
+    const int lrow = lane >> 3, lpos = lane & 7;
+    struct Blk { const char* xbase; int ty1, tx1, img, ty0, tx0; };
+    auto blk = [&](int t) {
+        const int img = t / tiles_per_image, tt = t - img * tiles_per_image;
+        const int by = tt / tiles_x, bx = tt - by * tiles_x;
+        return Blk{reinterpret_cast<const char*>(a.x) + (size_t)img * H * W * 128, by * PT - 1, bx * PT - 1, img, by * PT, bx * PT};
+    };
+    // patch piece i of this wave = rows 8 (wave + 4 i) .. of the patch; the lane's pixel (row, column) inside the patch is recomputed per request
+    // (a few VALU operations in an MFMA gap; 22 registers otherwise)
+    auto issue_piece = [&](const Blk& B, half_t* patch, int i) {
+        const int q = min((wave + 4 * i) * 8 + lrow, PATCH_ROWS - 1);
+        const int py = (q * 3641) >> 16;                            // q / 18 for q < 324
+        const int px = q - py * PP;
+        const int iy = B.ty1 + py, ix = B.tx1 + px;
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const int chunk = lpos ^ ((px >> 1) & 7);                  // (the column swizzle: see conv_patch_kernel)
+        const char* p = ok ? B.xbase + (size_t)(unsigned)((iy * W + ix) * 128 + chunk * 16) : zeros;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(patch + (wave + 4 * i) * 8 * 64), 16, 0, 0);
+    };
+    CP_STAMP(0);
+    // the weights, once: 72 pieces of 8 rows x 128 B
+#pragma unroll 1
+    for (int pc = wave; pc < 72; pc += 4) {
+        const int tap = pc >> 3, row = (pc & 7) * 8 + lrow;
+        const int chunk = lpos ^ ((row >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (((size_t)row * 9 + tap) * 64) * 2 + chunk * 16), (lptr_t)(wres + (size_t)pc * 8 * 64), 16, 0, 0);
+    }
+    {
+        const Blk B0 = blk(first);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) issue_piece(B0, pbuf, i);
+        if (wave == 0) issue_piece(B0, pbuf, 10);
+    }
+    float4 bq[2][4];                                             // this lane's bias values, for the workgroup's whole life
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[i][g] = *reinterpret_cast<const float4*>(a.bias + n0 + i * 32 + 8 * g + 4 * hh);
+    // wave w: block rows 4 w .. 4 w + 3; pixel tile j = rows 4 w + 2 j, + 1; lane -> (row r >> 4, column r & 15)
+    int xoff[2];                                                 // byte offset of the lane's patch pixel of tap (0, 0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xoff[j] = ((4 * wave + 2 * j + (r >> 4)) * PP + (r & 15)) * 128;
+    const int xcol = r & 15;
+    int xsw[3];                                                  // chunk swizzle of the lane's column under tap column kx
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) xsw[kx] = ((xcol + kx) >> 1) & 7;
+    const int woff = r * 128, wsw = (r >> 1) & 7;
+    // the output as a buffer: a store whose offset lies beyond it is dropped (lanes outside the image, and the block "before the first")
+    const int HO = POOL ? H >> 1 : H, WO = POOL ? W >> 1 : W;
+    const unsigned out_bytes = (unsigned)(a.m / a.hw) * (unsigned)HO * (unsigned)WO * (unsigned)NC * 2u;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(POOL ? (void*)a.pool_out : a.out, 0, (int)out_bytes, 0x00020000);
+    const int vsel = (r & 1) + 2 * (r >> 4);                     // POOL: which of the four channel groups g this lane of a 2 x 2 window stores
+    unsigned vmask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        vmask[q] = vsel == q ? 0xFFFFFFFFu : 0u;
+        asm volatile("" : "+v"(vmask[q]));                       // (opaque: keeps the AND / OR form below)
+    }
+
+    // Result of one block from its accumulators to memory (see the header), cut into 20 units that ride in the gaps of 20 MFMA steps of the next
+    // block: unit (c, g), c = 2 j + i < 4, g < 4: bias, ReLU, fp16 of four channels and (POOL) their 2 x 2 maximum; unit (c, 4): (POOL) the store.
+    // `live` false: every offset out of range.
+    unsigned pk[4][4][2];
+    auto emit_unit = [&](const floatx16 (&acc)[2][2], const Blk& B, bool live, auto cc, auto gc) {
+        constexpr int c = decltype(cc)::value, g = decltype(gc)::value;
+        constexpr int j = c >> 1, i = c & 1;
+        if constexpr (g < 4) {
+            const float4 bv = bq[i][g];
+            half2_t h0, h1;
+            h0[0] = (half_t)dn_relu(acc[i][j][4 * g + 0] + bv.x); h0[1] = (half_t)dn_relu(acc[i][j][4 * g + 1] + bv.y);
+            h1[0] = (half_t)dn_relu(acc[i][j][4 * g + 2] + bv.z); h1[1] = (half_t)dn_relu(acc[i][j][4 * g + 3] + bv.w);
+            pk[c][g][0] = __builtin_bit_cast(unsigned, h0); pk[c][g][1] = __builtin_bit_cast(unsigned, h1);
+            if constexpr (POOL) {
+                // MaxPool2d(2, 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the window = lanes {2 c, 2 c + 1} x {row 0, row 1 of the
+                // tile's row pair} = lanes l, l ^ 1, l ^ 16, l ^ 17 of the 32-lane half
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(pk[c][g][e], pk[c][g][e], false, false);   // {own rows 0 0 2 2, other rows 1 1 3 3}
+                    const unsigned mu = pk_max_f16(sw[0], sw[1]);
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true);       // quad_perm [1, 0, 3, 2]
+                    pk[c][g][e] = pk_max_f16(mu, nb);
+                }
+            } else {
+                const int oy = B.ty0 + 4 * wave + 2 * j + (r >> 4), ox = B.tx0 + xcol;
+                const bool ok = live && oy < HO && ox < WO;
+                const unsigned off = ok ? (unsigned)(((B.img * HO + oy) * WO + ox) * NC + n0 + i * 32 + 8 * g + 4 * hh) * 2u : 0xFFFFFFF0u;
+                u32x2 v; v[0] = pk[c][g][0]; v[1] = pk[c][g][1];
+                __builtin_amdgcn_raw_buffer_store_b64(v, ors, off, 0, 0);
+            }
+        } else if constexpr (POOL) {
+            // the four lanes of a window hold the same maxima: lane `vsel` stores channel group g = vsel
+            // (masks, not selects: the compiler turns a select chain over pk[c][0..3] into an indexed load from a scratch copy)
+            unsigned o0 = pk[c][0][0] & vmask[0], o1 = pk[c][0][1] & vmask[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) { o0 |= pk[c][q][0] & vmask[q]; o1 |= pk[c][q][1] & vmask[q]; }
+            const int oy = (B.ty0 >> 1) + 2 * wave + j, ox = (B.tx0 >> 1) + (xcol >> 1);
+            const bool ok = live && oy < HO && ox < WO;
+            const unsigned off = ok ? (unsigned)(((B.img * HO + oy) * WO + ox) * NC + n0 + i * 32 + 8 * vsel + 4 * hh) * 2u : 0xFFFFFFF0u;
+            u32x2 v; v[0] = o0; v[1] = o1;
+            __builtin_amdgcn_raw_buffer_store_b64(v, ors, off, 0, 0);
+        }
+    };
+
+    floatx16 prev[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) prev[i][j][e] = 0.f;
+    Blk Bprev = blk(first);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CP_STAMP(1);
+
+    for (int k = 0; k < nmine; ++k) {
+        const int t = first + k * per;
+        const Blk Bcur = blk(t);
+        const Blk Bnext = blk(k + 1 < nmine ? t + per : t);     // (no next block: this one again, into the buffer nobody reads)
+        const char* pb = reinterpret_cast<const char*>(pbuf + (k & 1) * RP_HALFS);
+        half_t* pnext = pbuf + ((k + 1) & 1) * RP_HALFS;
+        const char* wb = reinterpret_cast<const char*>(wres);
+        CP_STAMP_IF(k == 2, 3);
+        if (wave == 0) issue_piece(Bnext, pnext, 10);            // the 41st piece (the other 40: one per wave in each of the first ten steps)
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        half8 xf[2][2], wf[2][2];
+        auto frags = [&](int st, int bf) {
+            const int tap = st >> 2, ks = st & 3;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                xf[bf][j] = *reinterpret_cast<const half8*>(pb + xoff[j] + (ky * PP + kx) * 128 + (((2 * ks + hh) ^ xsw[kx]) * 16));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[bf][i] = *reinterpret_cast<const half8*>(wb + (tap * 64 + i * 32) * 128 + woff + (((2 * ks + hh) ^ wsw) * 16));
+        };
+        const bool live = k > 0;
+        frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<36>([&](auto stc) {
+            constexpr int st = decltype(stc)::value;
+            constexpr int bf = st & 1;
+            if constexpr (st + 1 < 36) frags(st + 1, bf ^ 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[bf][i], xf[bf][j], acc[i][j], 0, 0, 0);
+            if constexpr (st + 1 < 36) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA,
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // the four LDS reads of the next step (into the other register set),
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);          // the other three MFMAs
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the step's gap: issued while its last three MFMAs run (96 cycles)
+            if constexpr (st < 10) issue_piece(Bnext, pnext, st);
+            else if constexpr (st < 30) emit_unit(prev, Bprev, live, std::integral_constant<int, (st - 10) / 5>{}, std::integral_constant<int, (st - 10) % 5>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        CP_STAMP_IF(k == 2, 4);
+        // the next block's patch and the stores issued above: landed; everyone is done reading this block's patch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CP_STAMP_IF(k == 2, 5);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) prev[i][j] = acc[i][j];
+        Bprev = Bcur;
+    }
+    static_for<20>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        emit_unit(prev, Bprev, true, std::integral_constant<int, u / 5>{}, std::integral_constant<int, u % 5>{});
+    });
+    CP_STAMP(2);
+}
+
+bool patch_resident_shape(const PwArgs& a) {
+    const long out_bytes = (long)(a.m / a.hw) * (a.pool_out ? (a.cv_h >> 1) * (a.cv_w >> 1) : a.cv_h * a.cv_w) * a.cout * 2;
+    return a.cv_cin == 64 && a.act == DN_ACT_RELU && out_bytes < 0xFFFFFFF0L && (long)a.cv_h * a.cv_w * 128 < (1L << 31) && dn_knob("DN_PATCH_RESIDENT", 1) != 0;
+}
+
+int launch_patch_resident(const PwArgs& a, hipStream_t s) {
+    const int tiles_x = dn_cdiv(a.cv_w, PT), tiles = tiles_x * dn_cdiv(a.cv_h, PT);
+    const long ntiles = (long)tiles * (a.m / a.hw);
+    DN_REQUIRE(ntiles < (1L << 30), "conv_patch_resident_kernel: %ld blocks", ntiles);
+    const int groups = a.cout / 64;
+    int g = (256 / groups) & ~7;                                  // one workgroup per CU in all (256 CUs), a multiple of the 8 XCDs per channel group
+    if (g < 8) g = 8;
+    long long* st = patch_stamps_take((size_t)g * groups);
+    if (a.pool_out) {
+        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_patch_resident_kernel<true>), 160 * 1024));
+        dn_note_kernel("conv_patch_resident_kernel<pool>");
+        hipLaunchKernelGGL(conv_patch_resident_kernel<true>, dim3(g, groups), dim3(256), RES_LDS, s, a, tiles_x, tiles, (int)ntiles, st);
+    } else {
+        DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_patch_resident_kernel<false>), 160 * 1024));
+        dn_note_kernel("conv_patch_resident_kernel");
+        hipLaunchKernelGGL(conv_patch_resident_kernel<false>, dim3(g, groups), dim3(256), RES_LDS, s, a, tiles_x, tiles, (int)ntiles, st);
+    }
+    return DN_OK;
 }
 
 int patch_max_cin() { return 128; }
@@ -775,11 +1097,12 @@ bool patch_shape(const PwArgs& a) {
 }
 
 int launch_patch(const PwArgs& a, hipStream_t s) {
-    const size_t lds = 512 + (size_t)(PATCH_HALFS + 2 * WTAP_HALFS) * sizeof(half_t);
+    if (patch_resident_shape(a)) return launch_patch_resident(a, s);
+    const size_t lds = PATCH_LDS;
     DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(conv_patch_kernel)));
     dn_note_kernel("conv_patch_kernel");
     const int tiles = dn_cdiv(a.cv_w, PT) * dn_cdiv(a.cv_h, PT);
-    hipLaunchKernelGGL(conv_patch_kernel, dim3(tiles, a.cout / 64, a.m / a.hw), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(conv_patch_kernel, dim3(tiles, a.cout / 64, a.m / a.hw), dim3(256), lds, s, a, patch_stamps_take((size_t)tiles * (a.cout / 64) * (a.m / a.hw)));
     return DN_OK;
 }
 }  // namespace
