@@ -130,6 +130,35 @@ __device__ __forceinline__ void dn_act_n(V& v, int act) {
     }
 }
 
+// Epilogue of an MFMA tile: sink(i, j, g, act(acc[i][j][4 g ..] + bias)) for every 4-channel chunk the lane holds (channel tile i of TC, pixel
+// tile j of TP; registers 4 g .. 4 g + 3 = channels 32 (wc TC + i) + 8 g + 4 hh ..). Per channel tile the lane's 16 bias values are read from LDS
+// in ONE batch, and the activation is ONE uniform branch around the whole tile (round 5: the per-chunk form -- read the bias, wait, walk the
+// activation switch -- made 4 TC TP dependent LDS round trips per tile; same arithmetic, bit-identical results).
+template <int TP, int TC, typename ACC, typename SINK>
+__device__ __forceinline__ void dn_tile_emit(const ACC& acc, const float* bsh, int wc, int hh, int act, SINK&& sink) {
+    auto run = [&](auto actf) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            float4 bq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(&bsh[(wc * TC + i) * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v;
+                    v.x = actf(acc[i][j][4 * g + 0] + bq[g].x); v.y = actf(acc[i][j][4 * g + 1] + bq[g].y);
+                    v.z = actf(acc[i][j][4 * g + 2] + bq[g].z); v.w = actf(acc[i][j][4 * g + 3] + bq[g].w);
+                    sink(i, j, g, v);
+                }
+        }
+    };
+    if (act == DN_ACT_RELU) run([](float v) { return dn_relu(v); });
+    else if (act == DN_ACT_RELU6) run([](float v) { return dn_relu6(v); });
+    else if (act == DN_ACT_HSWISH) run([](float v) { return v * dn_relu6(v + 3.f) * (1.f / 6.f); });
+    else run([](float v) { return v; });
+}
+
 // launchers implemented by the per-kernel translation units (used by plan.hip and by the single-op C entry points)
 struct PwArgs {
     // implicit-GEMM geometry (dense kxk conv); pointwise uses k=1: x rows are then simply [m][cin]

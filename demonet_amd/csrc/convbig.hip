@@ -56,23 +56,34 @@ __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[TC][TP], const PwA
     const int r = lane & 31, hh = lane >> 5;
     const int M = a.m, NC = a.cout;
     half_t* ot = lds;
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const int prow = (wp * TP + j) * 32 + r;
+    // per channel tile: the lane's 16 bias values first (ONE wait for four LDS reads), and one uniform branch on the activation around everything:
+    // per 4-value chunk the round-4 form read its bias, waited, and walked the activation switch -- 16 TC dependent LDS round trips per tile
+    // (tools/probe_patch.py)
+    auto emit = [&](auto actf) {
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
+            float4 bq[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
-                const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
-                half4 hv;
-                float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
-                dn_act_n<float[4], 4>(t4, a.act);
-                hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
-                *reinterpret_cast<half4*>(&ot[prow * ORW + cl]) = hv;
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(&bsh[(wc * TC + i) * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int prow = (wp * TP + j) * 32 + r;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                    const float4 bv = bq[g];
+                    half4 hv;
+                    hv[0] = (half_t)actf(acc[i][j][4 * g + 0] + bv.x); hv[1] = (half_t)actf(acc[i][j][4 * g + 1] + bv.y);
+                    hv[2] = (half_t)actf(acc[i][j][4 * g + 2] + bv.z); hv[3] = (half_t)actf(acc[i][j][4 * g + 3] + bv.w);
+                    *reinterpret_cast<half4*>(&ot[prow * ORW + cl]) = hv;
+                }
             }
         }
-    }
+    };
+    const int act = a.act;
+    if (act == DN_ACT_RELU) emit([](float v) { return dn_relu(v); });
+    else if (act == DN_ACT_NONE) emit([](float v) { return v; });
+    else emit([act](float v) { return dn_act(v, act); });
     __syncthreads();
     if constexpr (TP == 4 && TC == 4) if (a.pool_out) {        // (compiled into the 256 x 256 tile only: in the 512 x 128 one it spilled the main loop)
         // fused MaxPool2d(2, 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the tile is BPt / W whole image rows starting at an even row
@@ -125,23 +136,31 @@ __device__ __forceinline__ void conv_epilogue_fp32(floatx16 (&acc)[TC][TP], cons
     const bool pair2 = a.cout_b > 0 && pair_aligned(a.out_b, a.cout_b, a.out_b_base, a.out_b_img_stride);
     for (int half = 0; half < 2; ++half) {
         if (wp == half) {
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const int prow = j * 32 + r;
+            // (bias per channel tile in one batch, one activation branch: see conv_epilogue)
+            auto emit = [&](auto actf) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
+                    float4 bq[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
-                        const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
-                        float4 v;
-                        float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
-                        dn_act_n<float[4], 4>(t4, a.act);
-                        v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
-                        *reinterpret_cast<float4*>(&ot[prow * FROW + cl]) = v;
+                    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(&bsh[(wc * TC + i) * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        const int prow = j * 32 + r;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
+                            const float4 bv = bq[g];
+                            float4 v;
+                            v.x = actf(acc[i][j][4 * g + 0] + bv.x); v.y = actf(acc[i][j][4 * g + 1] + bv.y);
+                            v.z = actf(acc[i][j][4 * g + 2] + bv.z); v.w = actf(acc[i][j][4 * g + 3] + bv.w);
+                            *reinterpret_cast<float4*>(&ot[prow * FROW + cl]) = v;
+                        }
                     }
                 }
-            }
+            };
+            const int act = a.act;
+            if (act == DN_ACT_NONE) emit([](float v) { return v; });
+            else emit([act](float v) { return dn_act(v, act); });
         }
         __syncthreads();
         constexpr int PPR = BCt / 2;

@@ -454,23 +454,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             // in this chunk layout) in fp32 and rounds ONCE -- act(conv + bias) + x as mobilenetv3.py:97-99 computes it
             constexpr int FROW = BC + 4;
             float* otf = reinterpret_cast<float*>(lds_dyn);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const int prow = (wp * TP + j) * 32 + r;
-#pragma unroll
-                for (int i = 0; i < TC; ++i) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
-                        const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
-                        float4 v;
-                        float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
-                        dn_act_n<float[4], 4>(t4, a.act);
-                        v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
-                        *reinterpret_cast<float4*>(&otf[prow * FROW + cl]) = v;
-                    }
-                }
-            }
+            dn_tile_emit<TP, TC>(acc, bsh, wc, hh, a.act, [&](int i, int j, int g, const float4& v) {
+                *reinterpret_cast<float4*>(&otf[((wp * TP + j) * 32 + r) * FROW + (wc * TC + i) * 32 + 8 * g + 4 * hh]) = v;
+            });
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < NCH; ++u) {
@@ -493,23 +479,11 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
             return;
         }
         half_t* ot = lds_dyn;
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int prow = (wp * TP + j) * 32 + r;
-#pragma unroll
-            for (int i = 0; i < TC; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
-                    const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
-                    half4 hv;
-                    float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
-                    dn_act_n<float[4], 4>(t4, a.act);
-                    hv[0] = (half_t)t4[0]; hv[1] = (half_t)t4[1]; hv[2] = (half_t)t4[2]; hv[3] = (half_t)t4[3];
-                    *reinterpret_cast<half4*>(&ot[prow * OROW + cl]) = hv;
-                }
-            }
-        }
+        dn_tile_emit<TP, TC>(acc, bsh, wc, hh, a.act, [&](int i, int j, int g, const float4& v) {
+            half4 hv;
+            hv[0] = (half_t)v.x; hv[1] = (half_t)v.y; hv[2] = (half_t)v.z; hv[3] = (half_t)v.w;
+            *reinterpret_cast<half4*>(&ot[((wp * TP + j) * 32 + r) * OROW + (wc * TC + i) * 32 + 8 * g + 4 * hh]) = hv;
+        });
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
@@ -528,23 +502,9 @@ __device__ __forceinline__ void pw_body(PwArgs a, const int m0, const int mend, 
         // tile in LDS ([BP][BC+4] floats over the K-loop buffers) and write row-contiguous float2 runs instead.
         constexpr int FROW = BC + 4;
         float* ot = reinterpret_cast<float*>(lds_dyn);
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int prow = (wp * TP + j) * 32 + r;
-#pragma unroll
-            for (int i = 0; i < TC; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = (wc * TC + i) * 32 + 8 * g + 4 * hh;
-                    const float4 bv = *reinterpret_cast<const float4*>(&bsh[cl]);
-                    float4 v;
-                    float t4[4] = {acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w};
-                    dn_act_n<float[4], 4>(t4, a.act);
-                    v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
-                    *reinterpret_cast<float4*>(&ot[prow * FROW + cl]) = v;
-                }
-            }
-        }
+        dn_tile_emit<TP, TC>(acc, bsh, wc, hh, a.act, [&](int i, int j, int g, const float4& v) {
+            *reinterpret_cast<float4*>(&ot[((wp * TP + j) * 32 + r) * FROW + (wc * TC + i) * 32 + 8 * g + 4 * hh]) = v;
+        });
         __syncthreads();
         float* outp = reinterpret_cast<float*>(a.out);
         const bool pair_ok = ((NC | (int)(a.out_base & 1) | (int)(a.out_img_stride & 1)) & 1) == 0 &&
