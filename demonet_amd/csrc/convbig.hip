@@ -959,47 +959,82 @@ __global__ __launch_bounds__(256) void conv_patch_resident_kernel(PwArgs a, int 
         asm volatile("" : "+v"(vmask[q]));                       // (opaque: keeps the AND / OR form below)
     }
 
-    // Result of one block from its accumulators to memory (see the header), cut into 20 units that ride in the gaps of 20 MFMA steps of the next
-    // block: unit (c, g), c = 2 j + i < 4, g < 4: bias, ReLU, fp16 of four channels and (POOL) their 2 x 2 maximum; unit (c, 4): (POOL) the store.
-    // `live` false: every offset out of range.
+    // Result of one block from its accumulators to memory (see the header), cut into 20 units that ride in 20 MFMA steps of the next block: unit
+    // (c, g), c = 2 j + i < 4, g < 4: bias, ReLU, fp16 of four channels and (POOL) their 2 x 2 maximum, (!POOL) their store; unit (c, 4): (POOL) the
+    // store. Every unit -- like a patch request -- comes in four PARTS, one behind each MFMA of its step: the wave issues in order, so what shall run
+    // under an MFMA has to stand between it and the next one. `live` false: every offset out of range.
     unsigned pk[4][4][2];
-    auto emit_unit = [&](const floatx16 (&acc)[2][2], const Blk& B, bool live, auto cc, auto gc) {
-        constexpr int c = decltype(cc)::value, g = decltype(gc)::value;
+    struct Rider { float t[4]; unsigned u[2]; unsigned off; int iy, ix, px; const char* p; };
+    auto emit_part = [&](Rider& R, const floatx16 (&acc)[2][2], const Blk& B, bool live, auto cc, auto gc, auto pc) {
+        constexpr int c = decltype(cc)::value, g = decltype(gc)::value, part = decltype(pc)::value;
         constexpr int j = c >> 1, i = c & 1;
         if constexpr (g < 4) {
-            const float4 bv = bq[i][g];
-            half2_t h0, h1;
-            h0[0] = (half_t)dn_relu(acc[i][j][4 * g + 0] + bv.x); h0[1] = (half_t)dn_relu(acc[i][j][4 * g + 1] + bv.y);
-            h1[0] = (half_t)dn_relu(acc[i][j][4 * g + 2] + bv.z); h1[1] = (half_t)dn_relu(acc[i][j][4 * g + 3] + bv.w);
-            pk[c][g][0] = __builtin_bit_cast(unsigned, h0); pk[c][g][1] = __builtin_bit_cast(unsigned, h1);
-            if constexpr (POOL) {
-                // MaxPool2d(2, 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the window = lanes {2 c, 2 c + 1} x {row 0, row 1 of the
-                // tile's row pair} = lanes l, l ^ 1, l ^ 16, l ^ 17 of the 32-lane half
+            if constexpr (part == 0) {
+                const float4 bv = bq[i][g];
+                R.t[0] = dn_relu(acc[i][j][4 * g + 0] + bv.x); R.t[1] = dn_relu(acc[i][j][4 * g + 1] + bv.y);
+                R.t[2] = dn_relu(acc[i][j][4 * g + 2] + bv.z); R.t[3] = dn_relu(acc[i][j][4 * g + 3] + bv.w);
+            } else if constexpr (part == 1) {
+                half2_t h0, h1;
+                h0[0] = (half_t)R.t[0]; h0[1] = (half_t)R.t[1]; h1[0] = (half_t)R.t[2]; h1[1] = (half_t)R.t[3];
+                pk[c][g][0] = __builtin_bit_cast(unsigned, h0); pk[c][g][1] = __builtin_bit_cast(unsigned, h1);
+                if constexpr (POOL) {
+                    // MaxPool2d(2, 2) (ssd_vgg16.py:34-37 via torchvision vgg16 features): the window = lanes {2 c, 2 c + 1} x {row 0, row 1 of the
+                    // tile's row pair} = lanes l, l ^ 1, l ^ 16, l ^ 17 of the 32-lane half
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(pk[c][g][e], pk[c][g][e], false, false);   // {own rows 0 0 2 2, other rows 1 1 3 3}
-                    const unsigned mu = pk_max_f16(sw[0], sw[1]);
-                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)mu, 0xB1, 0xF, 0xF, true);       // quad_perm [1, 0, 3, 2]
-                    pk[c][g][e] = pk_max_f16(mu, nb);
+                    for (int e = 0; e < 2; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(pk[c][g][e], pk[c][g][e], false, false);   // {own rows 0 0 2 2, other rows 1 1 3 3}
+                        R.u[e] = pk_max_f16(sw[0], sw[1]);
+                    }
+                } else {
+                    const int oy = B.ty0 + 4 * wave + 2 * j + (r >> 4), ox = B.tx0 + xcol;
+                    const bool ok = live && oy < HO && ox < WO;
+                    R.off = ok ? (unsigned)(((B.img * HO + oy) * WO + ox) * NC + n0 + i * 32 + 8 * g + 4 * hh) * 2u : 0xFFFFFFF0u;
                 }
-            } else {
-                const int oy = B.ty0 + 4 * wave + 2 * j + (r >> 4), ox = B.tx0 + xcol;
-                const bool ok = live && oy < HO && ox < WO;
-                const unsigned off = ok ? (unsigned)(((B.img * HO + oy) * WO + ox) * NC + n0 + i * 32 + 8 * g + 4 * hh) * 2u : 0xFFFFFFF0u;
+            } else if constexpr (part == 2) {
+                if constexpr (POOL) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)R.u[e], 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                        pk[c][g][e] = pk_max_f16(R.u[e], nb);
+                    }
+                }
+            } else if constexpr (!POOL) {
                 u32x2 v; v[0] = pk[c][g][0]; v[1] = pk[c][g][1];
-                __builtin_amdgcn_raw_buffer_store_b64(v, ors, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v, ors, R.off, 0, 0);
             }
         } else if constexpr (POOL) {
-            // the four lanes of a window hold the same maxima: lane `vsel` stores channel group g = vsel
-            // (masks, not selects: the compiler turns a select chain over pk[c][0..3] into an indexed load from a scratch copy)
-            unsigned o0 = pk[c][0][0] & vmask[0], o1 = pk[c][0][1] & vmask[0];
+            if constexpr (part == 0) {
+                // the four lanes of a window hold the same maxima: lane `vsel` stores channel group g = vsel
+                // (masks, not selects: the compiler turns a select chain over pk[c][0..3] into an indexed load from a scratch copy)
+                R.u[0] = pk[c][0][0] & vmask[0]; R.u[1] = pk[c][0][1] & vmask[0];
 #pragma unroll
-            for (int q = 1; q < 4; ++q) { o0 |= pk[c][q][0] & vmask[q]; o1 |= pk[c][q][1] & vmask[q]; }
-            const int oy = (B.ty0 >> 1) + 2 * wave + j, ox = (B.tx0 >> 1) + (xcol >> 1);
-            const bool ok = live && oy < HO && ox < WO;
-            const unsigned off = ok ? (unsigned)(((B.img * HO + oy) * WO + ox) * NC + n0 + i * 32 + 8 * vsel + 4 * hh) * 2u : 0xFFFFFFF0u;
-            u32x2 v; v[0] = o0; v[1] = o1;
-            __builtin_amdgcn_raw_buffer_store_b64(v, ors, off, 0, 0);
+                for (int q = 1; q < 4; ++q) { R.u[0] |= pk[c][q][0] & vmask[q]; R.u[1] |= pk[c][q][1] & vmask[q]; }
+            } else if constexpr (part == 1) {
+                const int oy = (B.ty0 >> 1) + 2 * wave + j, ox = (B.tx0 >> 1) + (xcol >> 1);
+                const bool ok = live && oy < HO && ox < WO;
+                R.off = ok ? (unsigned)(((B.img * HO + oy) * WO + ox) * NC + n0 + i * 32 + 8 * vsel + 4 * hh) * 2u : 0xFFFFFFF0u;
+            } else if constexpr (part == 3) {
+                u32x2 v; v[0] = R.u[0]; v[1] = R.u[1];
+                __builtin_amdgcn_raw_buffer_store_b64(v, ors, R.off, 0, 0);
+            }
+        }
+    };
+    // a request of the next patch in the same four parts
+    auto piece_part = [&](Rider& R, const Blk& B, half_t* patch, int i, auto pc) {
+        constexpr int part = decltype(pc)::value;
+        if constexpr (part == 0) {
+            const int q = min((wave + 4 * i) * 8 + lrow, PATCH_ROWS - 1);
+            const int py = (q * 3641) >> 16;                            // q / 18 for q < 324
+            R.px = q - py * PP;
+            R.iy = B.ty1 + py; R.ix = B.tx1 + R.px;
+        } else if constexpr (part == 1) {
+            const bool ok = (unsigned)R.iy < (unsigned)H && (unsigned)R.ix < (unsigned)W;
+            const int chunk = lpos ^ ((R.px >> 1) & 7);
+            R.off = ok ? (unsigned)((R.iy * W + R.ix) * 128 + chunk * 16) : 0xFFFFFFFFu;
+        } else if constexpr (part == 2) {
+            R.p = R.off != 0xFFFFFFFFu ? B.xbase + (size_t)R.off : zeros;
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)R.p, (lptr_t)(patch + (wave + 4 * i) * 8 * 64), 16, 0, 0);
         }
     };
 
@@ -1048,20 +1083,28 @@ __global__ __launch_bounds__(256) void conv_patch_resident_kernel(PwArgs a, int 
         static_for<36>([&](auto stc) {
             constexpr int st = decltype(stc)::value;
             constexpr int bf = st & 1;
-            if constexpr (st + 1 < 36) frags(st + 1, bf ^ 1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[bf][i], xf[bf][j], acc[i][j], 0, 0, 0);
-            if constexpr (st + 1 < 36) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA,
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // the four LDS reads of the next step (into the other register set),
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);          // the other three MFMAs
-            }
+            Rider R;
+            // the step's rider: one request of the next patch, or one unit of the previous block's result, a part behind each MFMA
+            auto rider = [&](auto pc) {
+                if constexpr (st < 10) piece_part(R, Bnext, pnext, st, pc);
+                else if constexpr (st < 30) emit_part(R, prev, Bprev, live, std::integral_constant<int, (st - 10) / 5>{}, std::integral_constant<int, (st - 10) % 5>{}, pc);
+            };
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[bf][0], xf[bf][0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // the step's gap: issued while its last three MFMAs run (96 cycles)
-            if constexpr (st < 10) issue_piece(Bnext, pnext, st);
-            else if constexpr (st < 30) emit_unit(prev, Bprev, live, std::integral_constant<int, (st - 10) / 5>{}, std::integral_constant<int, (st - 10) % 5>{});
+            if constexpr (st + 1 < 36) frags(st + 1, bf ^ 1);            // 128 cycles of MFMA in front of their use
+            rider(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[bf][0], xf[bf][1], acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rider(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[bf][1], xf[bf][0], acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rider(std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[bf][1], xf[bf][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rider(std::integral_constant<int, 3>{});
             __builtin_amdgcn_sched_barrier(0);
         });
         CP_STAMP_IF(k == 2, 4);
@@ -1077,7 +1120,8 @@ __global__ __launch_bounds__(256) void conv_patch_resident_kernel(PwArgs a, int 
     }
     static_for<20>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        emit_unit(prev, Bprev, true, std::integral_constant<int, u / 5>{}, std::integral_constant<int, u % 5>{});
+        Rider R;
+        static_for<4>([&](auto pc) { emit_part(R, prev, Bprev, true, std::integral_constant<int, u / 5>{}, std::integral_constant<int, u % 5>{}, pc); });
     });
     CP_STAMP(2);
 }
