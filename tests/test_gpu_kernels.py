@@ -208,6 +208,10 @@ DENSE_CASES = [
     (5, 9, 9, 64, 64, 3, 1, 1, 1, 1, True),          # tiles spanning several small images
     (9, 19, 19, 128, 512, 3, 1, 1, 1, 1, True),      # 13 pixel tiles x 2 channel tiles: XCD-grouped tile order (8 + remainder 5), two K iterations
     (16, 16, 16, 192, 256, 3, 1, 1, 1, 1, True),     # 16 pixel tiles, three K iterations (run buffers refilled twice)
+    (3, 40, 56, 64, 128, 3, 1, 1, 1, 1, True),       # weights-resident patch kernel (round 5): 3 images x 12 blocks x 2 channel groups, ragged rows (40 = 2.5 blocks)
+    (2, 20, 272, 128, 64, 3, 1, 1, 1, 1, True),      # the same with 128 input channels (two slices per block, 32-channel groups): conv2_2 of ssd512-like, W > 159
+    (1, 12, 256, 128, 128, 3, 1, 1, 1, 1, True),     # four 32-channel groups
+    (1, 33, 47, 64, 64, 3, 1, 1, 1, 0, True),        # no activation: the streamed patch kernel (the resident one is ReLU-only)
 ]
 
 
