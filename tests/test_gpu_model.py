@@ -195,6 +195,25 @@ def test_max_pool_in_the_conv_epilogue_is_bit_identical(name, n, size, monkeypat
         assert torch.equal(res["unfused"][1], res[key][1]), key
 
 
+@pytest.mark.parametrize("name,n,size", [("ssd300_vgg16", 5, 300), ("ssd512_vgg16", 3, 512), ("ssd300_vgg16", 33, 300)])
+def test_weights_resident_patch_kernel_is_bit_identical_to_the_streamed_one(name, n, size, monkeypatch):
+    """Round 5 (DN_PATCH_RESIDENT, default 1): conv1_2 (+ pool1) and conv2_1 of the VGG models (64 input channels, ssd_vgg16.py:33-37 via torchvision
+    vgg16 features[2:7]) run on conv_patch_resident_kernel -- one persistent workgroup per CU with the nine taps resident in LDS, the next block's
+    patch requests and the previous block's bias + ReLU + 2 x 2 max-pool (across lanes) + stores riding in the MFMA steps -- instead of the streamed
+    conv_patch_kernel. Same products, same accumulation order (tap, then 16-channel step), one rounding: the head outputs are equal bit for bit;
+    300 x 300 has ragged blocks on both edges (19 x 19 blocks of 16), 33 images run as two chains."""
+    imgs = torch.from_numpy(synth.images(59, n, size, size)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_PATCH_RESIDENT", flag)
+        m = _model(name, num_classes=91)
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        again = m.forward_heads(imgs)
+        assert torch.equal(res[flag][0], again[0]) and torch.equal(res[flag][1], again[1])
+    assert torch.equal(res["0"][0], res["1"][0]), (res["0"][0] - res["1"][0]).abs().max().item()
+    assert torch.equal(res["0"][1], res["1"][1])
+
+
 def test_model_heads_match_golden(golden_dir):
     z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
     m = _model("ssdlite320_mobilenet_v3_large", z)
