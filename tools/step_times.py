@@ -11,14 +11,21 @@ B, R = 64, 3
 m = models.load_synthetic(models.ssdlite320_mobilenet_v3_large(num_classes=91), 0).cuda()
 pipe = ForwardPipeline(m, B, depth=R, chains=1, device=torch.device("cuda:0"))
 batches = [torch.from_numpy(synth.images(3002 + j, B, 320, 320)).cuda() for j in range(R)]
+slot_streams = {}
 for k in range(W):
-    pipe.submit(batches[k % R], persistent_input=True)
+    t = pipe.submit(batches[k % R], persistent_input=True)
+    slot_streams[k % R] = pipe.stream_of(t)
 torch.cuda.synchronize()
+STAG = float(os.environ.get("STAGGER_MS", "0"))          # experiment: shift the second / third slot's stream by one / two thirds of a forward once
 ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
 evs = []
 t0 = time.perf_counter()
 sub = []
 for k in range(K):
+    if STAG > 0 and 1 <= k < R:
+        # the slot's stream is only known after a submit: use the stream of the slot's warm-up forward (slots rotate, k % R)
+        with torch.cuda.stream(slot_streams[k % R]):
+            torch.cuda._sleep(int(STAG * k * 2.1e6))       # ~2.1 GHz shader clock: cycles per ms
     t = pipe.submit(batches[k % R], persistent_input=True)
     sub.append(time.perf_counter() - t0)
     e = torch.cuda.Event(enable_timing=True)
