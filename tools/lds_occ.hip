@@ -1,5 +1,5 @@
 // dev: how many workgroups of 256 threads REALLY share a CU for a given dynamic LDS size on gfx950? Every workgroup bumps a per-CU counter (XCC_ID, HW_ID),
-// spins ~30 us, records the maximum it saw, and leaves.   hipcc --offload-arch=gfx950 tools/lds_occ.hip -o tools/_lds_occ
+// spins ~30 us, records the maximum it saw, and leaves.   hipcc --offload-arch=gfx950 tools/lds_occ.hip -o tools/_lds_occ   (git-ignored; run it on the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
