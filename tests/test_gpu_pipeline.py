@@ -256,7 +256,7 @@ def test_stress_forwards_in_flight_are_bit_identical_to_serial(se_small, monkeyp
 
 
 @pytest.mark.parametrize("name,ncls,kw,n", [("ssdlite320_mobilenet_v3_large", 91, {}, 5), ("ssdlite320_mobilenet_v3_large", 91, {}, 37),
-                                           ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 9), ("ssd300_vgg16", 21, {}, 2)])
+                                           ("ssd_lite_mobilenet_v2", 21, {"image_size": 300}, 9), ("ssd300_vgg16", 21, {}, 2), ("ssd512_vgg16", 21, {}, 1)])
 def test_results_do_not_depend_on_stale_lds_or_registers(name, ncls, kw, n, monkeypatch):
     """DN_POISON=1 (round 4, correctness tooling -- dense.hip poison_kernel, plan.hip): a launch that leaves NaN patterns in every LDS byte and every
     vector register (VGPR and AGPR) of the chip runs in front of every launch of the forward (plain launches, no graph). A kernel that reads LDS or a
