@@ -20,12 +20,23 @@ CSRC = os.path.join(ROOT, "demonet_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+_ASM_CACHE = {}
+# the flags demonet_amd/build.py compiles each file with (the hazard scan must see the code that ships)
+_BUILD_EXTRA = {"pwdirect.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"), "pointwise.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"),
+                "tail.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"), "postprocess.hip": ("-ffp-contract=off",)}
+
+
+def _asm_cmd(src, out, extra=()):
+    return [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-gpu-rdc", "--cuda-device-only", "-S", *extra, os.path.join(CSRC, src), "-o", out]
+
+
 def _asm(src, tmp_path, extra=()):
-    out = os.path.join(str(tmp_path), src.replace(".hip", ".s"))
-    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-gpu-rdc", "--cuda-device-only", "-S", *extra,
-           os.path.join(CSRC, src), "-o", out]
-    subprocess.check_call(cmd)
-    return open(out).read()
+    key = (src, tuple(extra))
+    if key not in _ASM_CACHE:
+        out = os.path.join(str(tmp_path), src.replace(".hip", ".s"))
+        subprocess.check_call(_asm_cmd(src, out, extra))
+        _ASM_CACHE[key] = open(out).read()
+    return _ASM_CACHE[key]
 
 
 def _kernels(text):
@@ -191,3 +202,29 @@ def test_run_staged_conv_dma_is_hidden_from_the_compiler_and_m0_is_only_touched_
         assert dma >= 40, (name, dma)                                   # prologue + 9 unrolled stages
         assert len(waits) >= 11 and waits[-1] == 0, (name, waits)       # prologue, 9 stage waits, the drain in front of the epilogue
         assert any(w > 0 for w in waits[1:-1]), (name, waits)           # counted: stages that request run pieces leave them in flight
+
+
+def test_no_instruction_reads_a_matrix_result_before_it_is_written(tmp_path):
+    """gfx950 does not interlock a matrix instruction's result write against a later vector / memory instruction that reads those registers:
+    software keeps passes + 4 wait states between them. hipcc does that for the instructions it generates, but not for `asm` statements --
+    until round 6 ReLU was an inline-asm v_max_f32 that could land 4 wait states behind the MFMA whose accumulator it read
+    (tools/mfma_hazard_scan.py). Every translation unit that uses the matrix cores is scanned as it is built."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mfma_hazard_scan import scan
+    srcs = ["pointwise.hip", "pwdirect.hip", "tail.hip", "expdw.hip", "headfuse.hip", "convbig.hip"]
+    procs = []
+    for src in srcs:
+        key = (src, tuple(_BUILD_EXTRA.get(src, ())))
+        if key in _ASM_CACHE:
+            continue
+        out = os.path.join(str(tmp_path), "hz_" + src.replace(".hip", ".s"))
+        procs.append((key, out, subprocess.Popen(_asm_cmd(src, out, key[1]))))
+    for key, out, p in procs:
+        assert p.wait() == 0, key
+        _ASM_CACHE[key] = open(out).read()
+    for src in srcs:
+        text = _ASM_CACHE[(src, tuple(_BUILD_EXTRA.get(src, ())))]
+        assert "v_mfma" in text, src
+        bad = scan(text)
+        assert not bad, f"{src}: {len(bad)} reads of a matrix result inside its hazard window, first: {bad[0]}"
