@@ -50,7 +50,17 @@ def _family(name):
 POINTWISE_FAMILIES = ("pw_direct_kernel", "pw_stream_kernel", "pw_kernel", "pw_xs_kernel", "pw_group_kernel")     # stand-alone 1x1 launches (north_star's ">= 90 % of roofline" path; the fused head launch, whose GEMM is a 1x1 behind a depthwise, is reported as its own family)
 
 
-def op_costs(graph, n):
+def softmax_levels(graph, kernel_names):
+    """Pyramid levels whose softmax / decode / histogram run in the epilogue of the fused head launch (headfuse.hip, HeadFuseLevel::sm):
+    told by what the library LAUNCHED -- dn_profile_op_info names that launch `head_fused_kernel<..,softmax>` -- not by re-reading a knob
+    (round 5 read DN_HEAD_SOFTMAX with the wrong default and priced a full softmax launch that no longer exists). The epilogue takes the
+    levels with at least 32 pixels per image; the rest leave as fp32 logits and get the small softmax_decode launch."""
+    if not any(k.startswith("head_fused_kernel") and "softmax" in k for k in kernel_names):
+        return ()
+    return tuple(l for l, f in enumerate(graph.features) if graph.t(f).h * graph.t(f).w >= 32)
+
+
+def op_costs(graph, n, sm_levels=()):
     """Algorithmic bytes / flops per op for a batch of n (fp16 tensors, fp32 bias; fused op = external bytes)."""
     out = []
     for nd in graph.nodes:
@@ -96,24 +106,37 @@ def op_costs(graph, n):
         out.append(c)
     A, K = graph.num_anchors(), graph.num_classes
     topk, D = graph.post["topk_candidates"], graph.post["detections_per_img"]
-    if graph.name.startswith(("ssdlite", "ssd_lite")) and os.environ.get("DN_HEAD_SOFTMAX", "0") != "0":
-        # the class heads' epilogue computes the softmax (scores written instead of logits): only the box decode is left of this launch
-        out.append(dict(kernel="decode_boxes_kernel", bytes=float(n * A * 48), flops=float(20 * n * A)))
-    else:
-        out.append(dict(kernel="softmax_decode_kernel", bytes=float(n * A * (4 * K + 16 + 4 * (K - 1) + 16)), flops=float(5 * n * A * K)))
+    # softmax + decode launch: fp32 logits and regressions in, class-major scores and boxes out, one 1 KB histogram row per 64-anchor tile --
+    # only for the anchors of the levels the fused head launch did NOT finish itself (sm_levels): with the epilogue on, 7 % of them
+    a_done = sum(graph.t(graph.features[l]).h * graph.t(graph.features[l]).w * graph.anchors_per_loc[l] for l in sm_levels)
+    a_left = A - a_done
+    out.append(dict(kernel="softmax_decode_kernel", bytes=float(n * (a_left * (4 * K + 16 + 4 * (K - 1) + 16) + (a_left + 63) // 64 * 1024)), flops=float(5 * n * a_left * K)))
     out.append(dict(kernel="select_nms_kernel", bytes=float(n * (K - 1) * (4 * A + 24 * topk)), flops=float(25 * n * (K - 1) * topk * topk / 2)))
     out.append(dict(kernel="merge_kernel", bytes=float(n * ((K - 1) * topk * 8 + D * 40)), flops=0.0))
     out.append(dict(kernel="select_nms_kernel", bytes=float(4 * n), flops=0.0))      # the fallback launch behind the cut-off pass: reads the per-image flags (and redoes flagged images: usually none)
     return out
 
 
-def fused_external_bytes(g, costs, mem, head):
+def fused_external_bytes(g, costs, mem, head, sm_levels=()):
     """External (HBM) algorithmic bytes of ONE fused launch covering ops `mem` ("a fused kernel is credited with the external
     bytes of the fused group")."""
     if head:
-        # every level's two depthwise ops read the SAME feature map (once), their outputs never exist; the two 1x1 heads write the fp32 rows
-        return (sum(costs[i]["b_in"] for i in mem if g.nodes[i].op == "dw") / 2 + sum(costs[i]["b_out"] for i in mem if g.nodes[i].op == "pw") +
-                sum(costs[i]["b_w"] for i in mem))
+        # every level's two depthwise ops read the SAME feature map (once), their outputs never exist; the two 1x1 heads write fp32 rows:
+        # logits [K] + regressions [4] per anchor -- or, for the levels whose post-process runs in the epilogue (sm_levels), scores [K - 1]
+        # + decoded boxes [4] per anchor and one 1 KB histogram row per 32-pixel half tile and image (the logits never reach memory)
+        K = g.num_classes
+        ext = sum(costs[i]["b_in"] for i in mem if g.nodes[i].op == "dw") / 2 + sum(costs[i]["b_w"] for i in mem)
+        for i in mem:
+            nd = g.nodes[i]
+            if nd.op != "pw":
+                continue
+            if nd.level in sm_levels and nd.head == 1:
+                hw = g.t(nd.out).h * g.t(nd.out).w
+                n = costs[i]["b_out"] / (4.0 * hw * nd.cout)
+                ext += costs[i]["b_out"] * (K - 1) / K + n * ((hw + 30) // 32 + 1) * 1024
+            else:
+                ext += costs[i]["b_out"]
+        return ext
     # the block's input once, its output once, every member's weights -- and a residual only when it is NOT the block's own input (an
     # inverted-residual block adds its input: those rows are already counted in first["b_in"]; round 4 counted them twice and
     # over-credited the fused-block family by 21 %)
@@ -280,6 +303,39 @@ def _launch_ranks(n, argv, stub):
     return json.loads(line)
 
 
+def time_config(model_name, batch, image_size, steps, warmup, dev, inflight=3):
+    """One more single-GPU BASELINE config timed in this process with the loop of the headline (ForwardPipeline, `inflight` forwards in
+    flight, device-resident synthetic batches, barrier-free N = 1 window: synchronize | K steps | synchronize). Used for BASELINE
+    configs[2] (C3: ssd_lite_mobilenet_v2 at 300 x 300, batch 128) and configs[4] (C5: ssd512_vgg16, batch 32) behind the C2 sections."""
+    from demonet_amd import models, synth
+    from demonet_amd.pipeline import ForwardPipeline
+    ncls = 21 if model_name == "ssd_lite_mobilenet_v2" else 91
+    fkw = {"image_size": image_size} if (image_size and model_name == "ssd_lite_mobilenet_v2") else {}
+    m = models.load_synthetic(getattr(models, model_name)(num_classes=ncls, **fkw), 0).to(dev)
+    W, H = m.graph.size
+    pipe = ForwardPipeline(m, batch, depth=inflight, chains=1, device=dev)
+    batches = [torch.from_numpy(synth.images(5002 + j, batch, H, W)).to(dev) for j in range(inflight)]
+    k = 0
+    for _ in range(max(warmup, 2 * inflight)):
+        pipe.submit(batches[k % inflight], persistent_input=True)
+        k += 1
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t = pipe.submit(batches[k % inflight], persistent_input=True)
+        k += 1
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    counts = pipe.result(t)[3]
+    out = {"value": round(batch * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": max(warmup, 2 * inflight),
+           "forwards_in_flight": inflight, "mean_detections": float(counts.float().mean().item()),
+           "workload": f"{model_name} fp16, batch {batch}, {H}x{W} synthetic images, K={ncls}, synthetic weights seed 0, detections incl. NMS"}
+    pipe.close()
+    del pipe, m, batches
+    torch.cuda.empty_cache()
+    return out
+
+
 def _on(stream):
     import contextlib
     return contextlib.nullcontext() if stream is None else torch.cuda.stream(stream)
@@ -309,6 +365,7 @@ def main(argv=None):
                     "images up). The PMC passes of tools/round_profile.sh use --eager --chains 1: the kernels at the launch size of the timed region")
     ap.add_argument("--no-latency", action="store_true", help="skip the per-step latency percentiles / D2H-inclusive step time (extra passes after the timed region)")
     ap.add_argument("--per-op", default="", help="write a per-op table (time, GB/s, TFLOP/s) to this file")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C5 legs (BASELINE configs[2] and [4]) that the default single-GPU run times behind the C2 sections")
     args = ap.parse_args(argv)
     stub = args.stub_cpu
 
@@ -572,13 +629,18 @@ def main(argv=None):
             model.forward_batch(images, persistent_input=True)
         buf = (C.c_float * nseg)()
         runs = _lib.check(L.dn_profile_end(h, buf, nseg))
-        costs = op_costs(g, B)
         split = _lib.check(L.dn_batch_split(h, B))     # every kernel runs once per sub-batch branch
         # the library reports which kernel each op launched and which op's event segment holds a grouped launch's time
         name = C.create_string_buffer(96)
         owner = C.c_int32()
         # the post-process launches have event segments of their own (dn_profile_end): softmax + decode (with the fused head launch: only
         # the small levels, and the cut-off in its last tile per image) | [tau +] cut-off selection | merge | the fallback launch
+        launched = []
+        for i in range(len(g.nodes)):
+            _lib.check(L.dn_profile_op_info(h, i, name, 96, C.byref(owner)))
+            launched.append(name.value.decode())
+        sm_levels = softmax_levels(g, launched)
+        costs = op_costs(g, B, sm_levels)
         post = [costs[len(g.nodes)]["kernel"], "select_nms_fast_kernel (+tau when it is a launch)", "merge_kernel", "select_nms_kernel (fallback)"]
         agg = {}
         for i, c in enumerate(costs):
@@ -593,7 +655,7 @@ def main(argv=None):
             if c["kernel"].startswith(("expdw_kernel", "expdw_one_kernel", "pw_dw_direct_kernel", "head_fused_kernel", "coop_kernel")):
                 fused.setdefault(c["owner"], []).append(i)
         for mem in fused.values():
-            ext = fused_external_bytes(g, costs, mem, costs[mem[0]]["kernel"].startswith("head_fused_kernel"))
+            ext = fused_external_bytes(g, costs, mem, costs[mem[0]]["kernel"].startswith("head_fused_kernel"), sm_levels)
             for i in mem:
                 costs[i]["bytes"] = ext / len(mem)
         owners = {}
@@ -746,6 +808,14 @@ def main(argv=None):
                                  "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "launches": v["launches"],
                                  "share": round(v["ms"] / total_ms, 3)}
                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not distributed and not args.no_configs and args.model == DEFAULT_MODEL and B == DEFAULT_BATCH and args.weights == "calibrated":
+        # the other single-GPU BASELINE configs, same loop, same process (bounded: K steps each): C3 = configs[2], C5 = configs[4]
+        model = None
+        torch.cuda.empty_cache()
+        result["configs"] = {"C2": {"value": result["value"], "unit": "images/sec", "ms_per_step": result["ms_per_step"], "steps": args.steps, "warmup": args.warmup,
+                                    "forwards_in_flight": R, "workload": result["config"]["workload"]},
+                             "C3": time_config("ssd_lite_mobilenet_v2", 128, 300, args.steps, args.warmup, dev),
+                             "C5": time_config("ssd512_vgg16", 32, 0, args.steps, args.warmup, dev)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, g, 1002)
     if distributed:

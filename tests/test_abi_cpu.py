@@ -249,3 +249,30 @@ def test_bench_fused_block_bytes_count_the_residual_once():
     assert bench.fused_external_bytes(g, costs, mem, False) == want
     # a projection whose residual comes from elsewhere (not this launch's input) still pays for it
     assert bench.fused_external_bytes(g, costs, [i + 2], False) == 2 * m * 72 + 2 * m * 24 + (2 * 72 * 24 + 4 * 24) + 2 * m * 24
+
+
+def test_bench_prices_the_post_process_by_what_the_library_launched():
+    """Round-5 slip: bench.py read DN_HEAD_SOFTMAX with the wrong default and booked a whole-anchor softmax launch (156 MB in 21 us = "7.2 TB/s")
+    for a launch that only touches the levels the fused head launch did not finish. The levels are now derived from the launched kernel's
+    name, the small launch is priced with its own anchors, and the head launch with scores + boxes + histogram rows instead of logits."""
+    import bench
+    from demonet_amd import spec
+    g = spec.GRAPHS["ssdlite320_mobilenet_v3_large"]()
+    n, K, A = 64, g.num_classes, g.num_anchors()
+    assert bench.softmax_levels(g, ["pw_direct_kernel<1,1>", "head_fused_kernel<5>"]) == ()
+    sm = bench.softmax_levels(g, ["head_fused_kernel<5,softmax>"])
+    assert sm == (0, 1)                                   # 20 x 20 and 10 x 10: >= 32 pixels per image
+    full = bench.op_costs(g, n)[len(g.nodes)]
+    part = bench.op_costs(g, n, sm)[len(g.nodes)]
+    assert full["kernel"] == part["kernel"] == "softmax_decode_kernel"
+    assert full["bytes"] == n * (A * (4 * K + 16 + 4 * (K - 1) + 16) + (A + 63) // 64 * 1024)
+    left = A - (400 + 100) * 6
+    assert left == 234 and part["bytes"] == n * (left * (4 * K + 16 + 4 * (K - 1) + 16) + 4 * 1024)
+    assert part["bytes"] < 0.09 * full["bytes"]
+    costs = bench.op_costs(g, n, sm)
+    mem = [i for i, nd in enumerate(g.nodes) if nd.head]
+    mem += [i for i, nd in enumerate(g.nodes) if nd.op == "dw" and any(g.nodes[j].inp == nd.out for j in mem)]
+    plain = bench.fused_external_bytes(g, costs, sorted(mem), True)
+    with_sm = bench.fused_external_bytes(g, costs, sorted(mem), True, sm)
+    logits_large = 4.0 * n * (400 + 100) * 6 * K
+    assert abs((plain - with_sm) - (logits_large / K - n * (14 + 5) * 1024)) < 1.0
