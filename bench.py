@@ -652,7 +652,7 @@ def main(argv=None):
         # fused inverted-residual launches: the intermediate activations never reach HBM -> external bytes only
         fused = {}
         for i, c in enumerate(costs):
-            if c["kernel"].startswith(("expdw_kernel", "expdw_one_kernel", "pw_dw_direct_kernel", "head_fused_kernel", "coop_kernel")):
+            if c["kernel"].startswith(("expdw_kernel", "expdw_one_kernel", "pw_dw_direct_kernel", "head_fused_kernel")):
                 fused.setdefault(c["owner"], []).append(i)
         for mem in fused.values():
             ext = fused_external_bytes(g, costs, mem, costs[mem[0]]["kernel"].startswith("head_fused_kernel"), sm_levels)

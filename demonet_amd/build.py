@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdemonet_hip.so")
-SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "pwdirect.hip", "loss.hip", "headfuse.hip", "coop.hip"]
+SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postprocess.hip", "expdw.hip", "tail.hip", "convbig.hip", "pwdirect.hip", "loss.hip", "headfuse.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, not AGPRs -- the small-tile kernels otherwise spend a v_accvgpr_read per
 # accumulator value on the way to their epilogues (not for convbig.hip: its 256 x 256 tiles need the AGPR half of the file)
 VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
@@ -35,7 +35,7 @@ def build_stamps(verbose=True):
     (per-workgroup phase stamps and the dn_debug_*_stamps / dn_debug_pw_tile exports: tools/probe_*.py, tools/tune_pw.py). Load it with
     DEMONET_HIP_LIB=<path>; the product library carries neither the stamps nor those exports."""
     build(verbose=verbose)
-    stamped = ["headfuse.hip", "expdw.hip", "pointwise.hip", "depthwise.hip", "postprocess.hip", "tail.hip", "coop.hip", "convbig.hip"]
+    stamped = ["headfuse.hip", "expdw.hip", "pointwise.hip", "depthwise.hip", "postprocess.hip", "tail.hip", "convbig.hip"]
     objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s not in stamped]
     for src in stamped:
         obj = os.path.join(LIBDIR, src.replace(".hip", "_stamps.o"))

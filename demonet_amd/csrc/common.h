@@ -327,32 +327,6 @@ struct TailArgs {
 int launch_tail(const TailArgs& a, int n, hipStream_t s);
 bool tail_op_supported(const dn_op_desc& o, int hin, int win, int hout, int wout);
 
-// The small-map squeeze-excitation stage of the MobileNetV3 backbone as ONE launch of per-image workgroup GROUPS (coop.hip): a projection from
-// a depthwise output in memory (with its SE scale), up to COOP_MAX_BLOCKS inverted-residual SE blocks, a final expansion written to memory.
-constexpr int COOP_G = 4;              // workgroups per image (slices of the expanded channels)
-constexpr int COOP_MAX_BLOCKS = 2;
-constexpr int COOP_MAX_STEPS = 2 * COOP_MAX_BLOCKS + 1;      // group barriers per image
-struct CoopPw { const half_t* wfrag; const float* bias; int cin, cout, act; };       // 1x1 conv: fragment-major weights (dn_op_desc::w2_off), folded bias
-struct CoopBlock {
-    CoopPw ex, pj;                                          // expand cin -> cexp (act), project cexp -> cout (+ residual)
-    const half_t* wd; const float* bd; int k, pad, act_dw;  // depthwise [k * k][cexp], stride 1
-    const half_t* w1t; const float* b1; const half_t* w2t; const float* b2; int sq;     // squeeze-excitation: fc1 transposed [cexp][sq], fc2 transposed [sq][cexp]
-    float inv_pixels; int has_res;
-};
-struct CoopArgs {
-    int n, H, W, xq;
-    const half_t* d0; const float* s0; CoopPw p0;           // leading projection: d0 [n][M][p0.cin] fp16, s0 [n][p0.cin] SE scale
-    int nblocks; CoopBlock blk[COOP_MAX_BLOCKS];
-    CoopPw last; half_t* out_last;                          // final expansion -> out_last [n][M][last.cout]
-    int cx, cmax, sqmax, slice_max;                         // block width (p0.cout), max expanded width / squeeze width / channel slice (multiple of 32)
-    float* scratch; size_t scratch_per_image;               // per image: [cmax] means + [COOP_G][M][cx] fp32 partial projections (floats)
-    unsigned* counters; int counter_stride;                 // counters[step * counter_stride + image], zero before the launch
-    long long* stamps;                                      // dev build only (tools/probe_coop.py)
-};
-bool coop_supported(const CoopArgs& a);
-size_t coop_lds_bytes(const CoopArgs& a);
-int launch_coop(const CoopArgs& a, hipStream_t s);
-
 // expand 1x1 + depthwise kxk in one launch (expdw.hip)
 struct ExpDwArgs {
     const half_t* x; half_t* out; float* pool;     // pool (optional): [n][tiles][cexp] fp32 per-tile channel sums

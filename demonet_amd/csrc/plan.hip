@@ -75,7 +75,6 @@ struct Layout {
     size_t arena = 0;
     int chain_n = 0;
     size_t secnt_off = 0;       // [n_se_in_dw][n] unsigned: last-workgroup counters of the squeeze-excitation tails
-    size_t coop_off = 0, coop_per_image = 0;      // exchange scratch of the cooperative stage (coop.hip): bytes per image
 };
 
 struct GraphKey {
@@ -118,9 +117,6 @@ struct dn_plan {
     std::vector<int> head_dw, head_cls, head_reg;
     // run of tiny backbone layers [tail_first, tail_end) executed by one per-image workgroup (tail.hip); -1: none
     int tail_first = -1, tail_end = -1;
-    // run [coop_first, coop_first + coop_len) = SE-scaled projection, coop_blocks squeeze-excitation blocks, final expansion on one small map: ONE
-    // launch of per-image workgroup groups (coop.hip); its group-barrier counters are slots coop_slot0 .. of the SE counter block. -1: none
-    int coop_first = -1, coop_len = 0, coop_blocks = 0, coop_slot0 = 0;
     std::vector<int> se_in_dw;              // per op: DW op -> index of the SE op whose FCs run in its tail (depthwise.hip dw_se_tail), SE op -> -2, else -1
     int n_se_in_dw = 0;                     // such pairs; slot q of the counter block belongs to the q-th
     std::vector<int> se_slot;               // per op (DW op of a pair): q
@@ -206,7 +202,6 @@ static const Layout& get_layout(dn_plan* p, int n) {
                     break;
                 }
                 if (i == p->tail_first) len = p->tail_end - p->tail_first;
-                else if (i == p->coop_first) len = p->coop_len;
                 else if (p->fused_len[i] > 0) len = p->fused_len[i];
                 for (int q = 0; q < len; ++q) when[i + q] = tstep;
                 if (len > 1) {
@@ -280,16 +275,6 @@ static const Layout& get_layout(dn_plan* p, int n) {
     off += align256((size_t)n * 2 * 4);
     L.secnt_off = off;
     off += align256((size_t)n * p->n_se_in_dw * 4 + 4);
-    if (p->coop_first >= 0) {
-        // exchange scratch of the cooperative stage per image: [cmax] channel means + [COOP_G][M][cx] fp32 partial projections
-        const dn_op_desc& o0 = p->ops[p->coop_first];
-        const dn_tensor_desc& t0 = p->tensors[o0.out];
-        int cmax = 0;
-        for (int q = 0; q < p->coop_len; ++q) cmax = std::max(cmax, std::max(p->ops[p->coop_first + q].cin, p->ops[p->coop_first + q].cout));
-        L.coop_per_image = align256(((size_t)cmax + (size_t)COOP_G * t0.h * t0.w * o0.cout) * 4);
-        L.coop_off = off;
-        off += align256((size_t)n * L.coop_per_image);
-    }
     L.post_off = off;
     {
         const int S = batch_split(p, n);          // one private post-process scratch slice per sub-batch branch
@@ -462,56 +447,6 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
             p->se_in_dw[j] = i;
             p->se_in_dw[i] = -2;
             p->se_slot[j] = p->n_se_in_dw++;
-        }
-    }
-    // Cooperative small-map stage (coop.hip, DN_COOP, default 0 = off: measured -- 101 us against 128 us for the ten launches as ONE chain of 64
-    // images, but slower than them at 32 images per chain and with forwards in flight, where small launches overlap for free and this one takes
-    // a workgroup slot on every compute unit for 100 us; every exchange through memory costs what a dependent launch costs): [PW with SE scale, no residual] -> { PW expand, DW k x k stride 1 with pool, SE,
-    // PW project with that SE (+ residual = the block's input) } x 1..2 -> PW expand, all on one map of 33 .. 128 pixels, nothing inside read
-    // from outside the run except the final expansion's output. (MobileNetV3: the 10 x 10 stage, mobilenetv3.py:198-214 rows 13 - 15.)
-    p->coop_first = -1;
-    if (dn_knob("DN_COOP", 0) != 0 && p->ops[0].type == DN_OP_STEM) {
-        auto plain_op = [&](int q) {
-            bool in_group = p->fused_len[q] > 0;
-            for (int b = 1; b <= 3 && q - b >= 0; ++b) in_group |= p->fused_len[q - b] > b;
-            return !in_group && p->se_fold[q] == -1 && p->se_in_dw[q] == -1 && !p->ops[q].head;
-        };
-        for (int i = 1; i + 5 < desc->n_ops && p->coop_first < 0; ++i) {
-            const dn_op_desc& o0 = p->ops[i];
-            if (o0.type != DN_OP_PW || o0.se < 0 || o0.residual >= 0 || !plain_op(i) || o0.act != DN_ACT_NONE || o0.w2_off < 0) continue;
-            const dn_tensor_desc& t0 = p->tensors[o0.out];
-            const int M = t0.h * t0.w, cx = o0.cout;
-            if (M <= 32 || M > 128 || p->tensors[o0.in].kind != DN_T_ACT || p->tensors[o0.in].h != t0.h || p->tensors[o0.in].w != t0.w) continue;
-            int j = i + 1, nb = 0, x = o0.out;
-            bool ok = true;
-            while (ok && nb < COOP_MAX_BLOCKS && j + 4 < desc->n_ops) {
-                const dn_op_desc &ex = p->ops[j], &dw = p->ops[j + 1], &se = p->ops[j + 2], &pj = p->ops[j + 3];
-                const bool blk = ex.type == DN_OP_PW && ex.in == x && ex.se < 0 && ex.residual < 0 && ex.w2_off >= 0 && ex.cin == cx && ex.cout % 32 == 0 &&
-                                 dw.type == DN_OP_DW && dw.in == ex.out && dw.pool >= 0 && dw.stride == 1 && dw.dil == 1 && (dw.k == 3 || dw.k == 5) &&
-                                 dw.pad == (dw.k - 1) / 2 && dw.cin == ex.cout && se.type == DN_OP_SE && se.in == dw.pool && se.cin == ex.cout && se.squeeze % 2 == 0 &&
-                                 se.squeeze <= 128 && pj.type == DN_OP_PW && pj.in == dw.out && pj.se == se.out && (pj.residual == x || pj.residual < 0) &&
-                                 pj.cout == cx && pj.act == DN_ACT_NONE && pj.w2_off >= 0 && pj.cin == ex.cout && plain_op(j) && plain_op(j + 1) &&
-                                 plain_op(j + 2) && plain_op(j + 3) && p->tensors[dw.out].h == t0.h && p->tensors[dw.out].w == t0.w;
-                if (!blk) break;
-                x = pj.out; j += 4; ++nb;
-            }
-            if (nb < 1) continue;
-            const dn_op_desc& lo = p->ops[j];
-            if (!(lo.type == DN_OP_PW && lo.in == x && lo.se < 0 && lo.residual < 0 && lo.w2_off >= 0 && lo.cin == cx && lo.cout % 32 == 0 && plain_op(j))) continue;
-            if (cx % 16 != 0 || o0.cin % 32 != 0 || o0.cin / 32 < COOP_G || lo.cout / 32 < COOP_G) continue;
-            // nothing produced inside the run (except the last output) may be read outside it
-            std::set<int> inner;
-            for (int q = i; q < j; ++q) { inner.insert(p->ops[q].out); if (p->ops[q].pool >= 0) inner.insert(p->ops[q].pool); }
-            for (int l = 0; l < desc->n_levels; ++l) ok = ok && !inner.count(desc->level_tensor[l]);
-            for (int u = 0; u < desc->n_ops && ok; ++u) {
-                if (u >= i && u <= j) continue;
-                const dn_op_desc& ou = p->ops[u];
-                ok = !(inner.count(ou.in) || inner.count(ou.residual) || inner.count(ou.se));
-            }
-            if (!ok) continue;
-            p->coop_first = i; p->coop_len = j + 1 - i; p->coop_blocks = nb;
-            p->coop_slot0 = p->n_se_in_dw;
-            p->n_se_in_dw += COOP_MAX_STEPS;
         }
     }
     p->post_ticket_slot = -1;
@@ -722,8 +657,6 @@ static const Layout& get_sub_layout(dn_plan* p, int n, int S, int k) {
     V.reg_off = L.reg_off + (size_t)n0 * p->d.num_anchors * 16;
     V.scale_off = L.scale_off + (size_t)n0 * 8;
     V.secnt_off = L.secnt_off + (size_t)n0 * p->n_se_in_dw * 4;
-    V.coop_off = L.coop_off + (size_t)n0 * L.coop_per_image;
-    V.coop_per_image = L.coop_per_image;
     const size_t slice = L.post_bytes / (size_t)S;
     V.post_off = L.post_off + (size_t)k * slice;
     V.post_bytes = slice;
@@ -1086,41 +1019,6 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
             for (size_t q = seg + 1; q < p->ops.size(); ++q)
                 if (record) (void)hipEventRecord(p->events[ev++], s);
             break;
-        }
-        if ((int)i == p->coop_first) {
-            CoopArgs ca{};
-            auto cpw = [&](const dn_op_desc& q) { return CoopPw{reinterpret_cast<const half_t*>(W + q.w2_off), reinterpret_cast<const float*>(W + q.b_off), q.cin, q.cout, q.act}; };
-            const dn_op_desc& o0 = p->ops[i];
-            ca.n = n; ca.H = to.h; ca.W = to.w; ca.xq = xq;
-            ca.d0 = reinterpret_cast<const half_t*>(tptr(o0.in)); ca.s0 = reinterpret_cast<const float*>(tptr(o0.se)); ca.p0 = cpw(o0);
-            ca.cx = o0.cout; ca.nblocks = p->coop_blocks;
-            ca.cmax = 0; ca.sqmax = 2;
-            int tiles_max = dn_cdiv(o0.cin / 32, COOP_G);
-            for (int b = 0; b < p->coop_blocks; ++b) {
-                const dn_op_desc &ex = p->ops[i + 1 + 4 * b], &dw = p->ops[i + 2 + 4 * b], &se = p->ops[i + 3 + 4 * b], &pj = p->ops[i + 4 + 4 * b];
-                CoopBlock& B = ca.blk[b];
-                B.ex = cpw(ex); B.pj = cpw(pj);
-                B.wd = reinterpret_cast<const half_t*>(W + dw.w_off); B.bd = reinterpret_cast<const float*>(W + dw.b_off); B.k = dw.k; B.pad = dw.pad; B.act_dw = dw.act;
-                B.w1t = reinterpret_cast<const half_t*>(W + se.w_off); B.b1 = reinterpret_cast<const float*>(W + se.b_off);
-                B.w2t = reinterpret_cast<const half_t*>(W + se.w2_off); B.b2 = reinterpret_cast<const float*>(W + se.b2_off); B.sq = se.squeeze;
-                B.inv_pixels = 1.0f / (float)se.pool_pixels; B.has_res = pj.residual >= 0 ? 1 : 0;
-                ca.cmax = std::max(ca.cmax, ex.cout); ca.sqmax = std::max(ca.sqmax, se.squeeze);
-                tiles_max = std::max(tiles_max, dn_cdiv(ex.cout / 32, COOP_G));
-            }
-            const dn_op_desc& lo = p->ops[i + p->coop_len - 1];
-            ca.last = cpw(lo);
-            ca.out_last = reinterpret_cast<half_t*>(tptr(lo.out));
-            tiles_max = std::max(tiles_max, dn_cdiv(lo.cout / 32, COOP_G));
-            ca.slice_max = 32 * tiles_max;
-            ca.scratch = reinterpret_cast<float*>(ws + L.coop_off); ca.scratch_per_image = L.coop_per_image / 4;
-            ca.counters = reinterpret_cast<unsigned*>(ws + L.secnt_off) + (size_t)p->coop_slot0 * n; ca.counter_stride = n;
-            rc = launch_coop(ca, s);
-            if (rc != DN_OK) return rc;
-            for (int q = 0; q < p->coop_len; ++q) note(i + q, i);
-            for (int q = 1; q < p->coop_len; ++q)
-                if (record) (void)hipEventRecord(p->events[ev++], s);
-            i += p->coop_len - 1;
-            continue;
         }
         if ((int)i == p->tail_first) {
             TailArgs ta{};

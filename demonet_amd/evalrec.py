@@ -7,6 +7,11 @@ reference's evaluators consume, and score them, without pycocotools.
   confidence descending, +1 pixel box arithmetic, a ground truth can be claimed once, "difficult" boxes are ignored) and
   `voc_ap` (:29-58), both the 11-point VOC07 metric and the area under the precision envelope.
 
+`voc_ap` and the overlap / TP-FP loop of `voc_class_pr` are the canonical PASCAL VOC devkit routine (VOCdevkit `VOCevaldet.m`, as ported to
+Python in py-faster-rcnn's `voc_eval.py`), which the reference itself carries in demonet/data/voc_eval.py: to be a drop-in they have to
+produce that routine's numbers bit for bit (tests/golden/voc_eval.npz holds vectors from the reference's own functions), so the arithmetic
+-- the precision envelope, the `+ 1` pixel box sizes, "a ground truth is claimed once" -- is restated step for step, not redesigned.
+
 Host-side numpy; inputs are what `SSD.forward_batch` returns (copied to the host once per batch).
 """
 from typing import Dict, List, Sequence, Tuple
@@ -30,7 +35,7 @@ def coco_detection_records(boxes, scores, labels, counts, image_ids: Sequence[in
 
 
 def voc_ap(rec: np.ndarray, prec: np.ndarray, use_07_metric: bool = False) -> float:
-    """voc_eval.py:29-58."""
+    """voc_eval.py:29-58 -- the PASCAL VOC devkit's AP (11-point VOC07 metric, or the area under the monotone precision envelope)."""
     rec, prec = np.asarray(rec, dtype=np.float64), np.asarray(prec, dtype=np.float64)
     if use_07_metric:
         ap = 0.0

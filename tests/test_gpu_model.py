@@ -1078,31 +1078,6 @@ def test_cut_off_in_the_last_softmax_tile_equals_the_cut_off_launch(n, monkeypat
     assert int(res["1", "1"][3].sum()) > 0
 
 
-@pytest.mark.parametrize("n", [64, 37, 8, 3, 1])
-def test_cooperative_small_map_stage_matches_the_launch_per_layer_path(n, monkeypatch):
-    """Round 5 (coop.hip, DN_COOP=1; off by default -- it measures slower than the launches it replaces except as one chain of 64 images): the 10 x 10 stage of MobileNetV3 -- SE-scaled projection, two 80 -> 480 -> 80 squeeze-excitation
-    blocks, the expansion that is pyramid feature 1 (mobilenetv3.py:198-214 rows 13 - 15, :61-99, :22-37) -- is ONE launch of four-workgroup groups
-    per image that exchange channel means and K-slice partial sums through memory. Same rounding points as the ten launches it replaces
-    (fp16 activations, fp32 accumulation, fp16 SE product), sums in another order: feature 1 agrees to fp16 rounding of a few values, the
-    logits within the golden tolerance, and the launch is deterministic (two runs, eager and graph replay: bit-identical)."""
-    imgs = torch.from_numpy(synth.images(97, n, 320, 320)).cuda()
-    res, feat = {}, {}
-    monkeypatch.setenv("DN_WS_REUSE", "0")                  # (feature 1 is read back below: one contiguous block per tensor)
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DN_COOP", flag)
-        m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
-        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
-        feat[flag] = m.tensor(imgs.shape, m.graph.features[1]).float()
-        again = m.forward_heads(imgs)
-        assert torch.equal(res[flag][0], again[0]) and torch.equal(res[flag][1], again[1])
-    d = (feat["1"] - feat["0"]).abs()
-    scale = feat["0"].abs().clamp_min(1.0)
-    assert float((d / scale).max()) < 3e-2 and float(d.mean()) < 2e-3, (float((d / scale).max()), float(d.mean()))
-    for q in (0, 1):
-        tol = LOGIT_ATOL + LOGIT_RTOL * res["0"][q].abs()
-        assert bool(((res["1"][q] - res["0"][q]).abs() <= tol).all()), q
-
-
 def test_c2_full_batch_against_the_cpu_path():
     """BASELINE config C2 at its full size with default knobs, tied to the CPU path directly (generalized_ssd.py:271-349): until round 6 every
     test that ran the V3 model at 64 images compared the HIP path with itself, and the 64-image launch forms -- softmax / decode in the fused

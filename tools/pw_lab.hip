@@ -206,9 +206,12 @@ __global__ __launch_bounds__(256) void k_base(Args a, int tiles, int tiles_per_r
 // store-only patterns: the grid and per-wave instruction counts of k_base<.., 2>; every wave writes its 64 rows x run of channel tiles.
 //   PAT 0: 32 rows x 32 B per instruction (round 5)   PAT 1: 16 rows x 64 B   PAT 2: 8 rows x 128 B   PAT 3: linear 1 KB per instruction
 template <int PAT>
-__global__ __launch_bounds__(256) void k_store(half_t* out, int m, int NC, int tiles, int tiles_per_run, unsigned v) {
+__global__ __launch_bounds__(256) void k_store(half_t* out, int m, int NC, int tiles, int tiles_per_run, unsigned v, long long* stamps) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    struct Stamp { long long* p; long long t0; __device__ ~Stamp() { const long long t2 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long t3 = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0) { p[0] = t0; p[1] = t0; p[2] = t2; p[3] = t3; } } }
+        st{stamps + ((size_t)blockIdx.x * 4 + wave) * 4, (long long)__builtin_amdgcn_s_memrealtime()};
     const int flat = blockIdx.x;
     const int by = flat / tiles;
     const int m0 = (flat - by * tiles) * 256 + wave * 64;
@@ -406,7 +409,7 @@ template <int KS1, int RT, int PXU, int ACT, int FLAGS>
 __global__ __launch_bounds__(256) void k_pws(Args a, int runs, int n_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KSF = KS1 - 1;
-    long long t0 = 0, t1 = 0, t2 = 0;
+    long long t0 = 0, t1 = 0, t2 = 0, ta = 0, tb = 0, tc = 0, ca = 0, cc = 0;
     if (FLAGS & 1) t0 = __builtin_amdgcn_s_memrealtime();
     const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -465,7 +468,9 @@ __global__ __launch_bounds__(256) void k_pws(Args a, int runs, int n_units) {
                 xf[j][ks] = *reinterpret_cast<const half8*>(lds + o);
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((FLAGS & 1) && ta == 0) { ta = __builtin_amdgcn_s_memrealtime(); ca = __builtin_amdgcn_s_memtime(); }
         if (u + Q < n_units) dma_x(u + Q);
+        if ((FLAGS & 1) && tb == 0) tb = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int j = 0; j < PXU; ++j) xf[j][KSF] = data ? xf[j][KSF] : (bcol ? ones : zero8);
         const int row0 = (u * PXU) * 32;
@@ -504,6 +509,7 @@ __global__ __launch_bounds__(256) void k_pws(Args a, int runs, int n_units) {
                 __builtin_amdgcn_raw_buffer_store_b128(hi4, ors, (okc && rr + 16 < a.m) ? off + 32u * (unsigned)NC : 0x80000000u, 0, 0);
             }
         }
+        if ((FLAGS & 1) && tc == 0) { tc = __builtin_amdgcn_s_memrealtime(); cc = __builtin_amdgcn_s_memtime(); }
         // the next unit's x tile must have landed; with FLAGS & 4 this unit's 2 RT PXU stores (always issued: buffer stores) stay in flight
         if (FLAGS & 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RT * PXU) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -511,7 +517,8 @@ __global__ __launch_bounds__(256) void k_pws(Args a, int runs, int n_units) {
     }
     if (FLAGS & 1) {
         const long long t3 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) { long long* sp = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 4; sp[0] = t0; sp[1] = t1; sp[2] = t2; sp[3] = t3; }
+        if (lane == 0) { long long* sp = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 4; sp[0] = t0; sp[1] = t1; sp[2] = t2; sp[3] = t3;
+            long long* sq = a.stamps + (1 << 19) + ((size_t)blockIdx.x * 4 + wave) * 4; sq[0] = ta - t1; sq[1] = tb - ta; sq[2] = tc - tb; sq[3] = (cc - ca) * 1000 / max(tc - ta, 1LL); }
     }
 }
 
@@ -604,7 +611,7 @@ int main(int argc, char** argv) {
     long long* dstamps; const size_t nst = (size_t)1 << 20;
     CK(hipMalloc(&dstamps, nst * 8)); CK(hipMemset(dstamps, 0, nst * 8));
     Args a{dx, dw, dwfb, db, nullptr, M, K, N, act, dstamps};
-    auto stamp_report = [&](int nwaves) {
+    auto stamp_report = [&](int nwaves, bool h2 = false) {
         std::vector<long long> h((size_t)nwaves * 4);
         CK(hipMemcpy(h.data(), dstamps, h.size() * 8, hipMemcpyDeviceToHost));
         std::vector<double> v[4]; long long base = -1;
@@ -613,6 +620,14 @@ int main(int argc, char** argv) {
         const char* nm[4] = {"wave start", "operands ready", "first unit done", "wave done"};
         for (int k = 0; k < 4; ++k) { std::sort(v[k].begin(), v[k].end()); const size_t n = v[k].size(); if (!n) continue;
             printf("      %-18s min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us   (%zu waves)\n", nm[k], v[k][0], v[k][n / 10], v[k][n / 2], v[k][n * 9 / 10], v[k][n - 1], n); }
+        if (h2) {
+            std::vector<long long> g((size_t)nwaves * 4);
+            CK(hipMemcpy(g.data(), dstamps + (1 << 19), g.size() * 8, hipMemcpyDeviceToHost));
+            const char* nm2[4] = {"x fragments read", "next DMA issued", "unit issued", "MHz*10 in unit"};
+            for (int k = 0; k < 4; ++k) { std::vector<double> q; for (int w = 0; w < nwaves; ++w) if (h[w * 4]) q.push_back(g[w * 4 + k] * (k < 3 ? 0.01 : 1.0));
+                std::sort(q.begin(), q.end()); const size_t n = q.size(); if (!n) continue;
+                printf("      first unit: %-18s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f\n", nm2[k], q[0], q[n / 10], q[n / 2], q[n * 9 / 10], q[n - 1]); }
+        }
         CK(hipMemset(dstamps, 0, nst * 8));
     };
     // CPU check of the reference on a few rows
@@ -645,10 +660,10 @@ int main(int argc, char** argv) {
     if (have_ref) cpu_check();
     {
         int per; const int runs = runs_for(2, 2800, per); const int tiles = (M + 255) / 256;
-        bench("store only, 32 rows x 32 B / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<0>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u); }, false);
-        bench("store only, 16 rows x 64 B / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<1>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u); }, false);
-        bench("store only, 8 rows x 128 B / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<2>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u); }, false);
-        bench("store only, linear 1 KB / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<3>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u); }, false);
+        bench("store only, 32 rows x 32 B / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<0>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u, dstamps); }, false); stamp_report(tiles * runs * 4);
+        bench("store only, 16 rows x 64 B / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<1>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u, dstamps); }, false); stamp_report(tiles * runs * 4);
+        bench("store only, 8 rows x 128 B / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<2>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u, dstamps); }, false); stamp_report(tiles * runs * 4);
+        bench("store only, linear 1 KB / instr", [&](half_t* o) { hipLaunchKernelGGL((k_store<3>), dim3(tiles * runs), dim3(256), 0, s, o, M, N, tiles, per, 1u, dstamps); }, false); stamp_report(tiles * runs * 4);
     }
 #define LDSW(KS1v, PXv, STv, cap, nm) if (KSF + 1 == KS1v) { int per; const int runs = runs_for(PXv, cap, per); const int tiles = (M + 128 * PXv - 1) / (128 * PXv); \
         const int ldsb = per * KS1v * 1024; CK(hipFuncSetAttribute((const void*)k_ldsw<KS1v, PXv, STv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
@@ -677,9 +692,9 @@ int main(int argc, char** argv) {
         bench(nm2, [&](half_t* o) { Args b = a; b.out = o; hipLaunchKernelGGL((k_pws<KS1v, RTv, PXUv, ACTv, FL | 2>), dim3(nwg), dim3(256), ldsb, s, b, runs, n_units); }, false); \
         snprintf(nm2, sizeof nm2, "%s RT=%d PXU=%d wg=%d stamps", nm, RTv, PXUv, nwg); \
         bench(nm2, [&](half_t* o) { Args b = a; b.out = o; hipLaunchKernelGGL((k_pws<KS1v, RTv, PXUv, ACTv, FL | 1>), dim3(nwg), dim3(256), ldsb, s, b, runs, n_units); }, false); \
-        stamp_report(nwg * 4); }
-#define PWS(KS1v, RTv, PXUv, ACTv) PWS1(KS1v, RTv, PXUv, ACTv, 2, 0, "pws wait0") PWS1(KS1v, RTv, PXUv, ACTv, 2, 4, "pws counted") PWS1(KS1v, RTv, PXUv, ACTv, 2, 12, "pws counted wdirect") \
-        PWS1(KS1v, RTv, PXUv, ACTv, 3, 4, "pws counted") PWS1(KS1v, RTv, PXUv, ACTv, 3, 12, "pws counted wdirect") PWS1(KS1v, RTv, PXUv, ACTv, 4, 4, "pws counted")
+        stamp_report(nwg * 4, true); }
+#define PWS(KS1v, RTv, PXUv, ACTv) PWS1(KS1v, RTv, PXUv, ACTv, 2, 4, "pws counted") PWS1(KS1v, RTv, PXUv, ACTv, 3, 4, "pws counted")
+    PWS(8, 3, 1, 0) PWS(8, 3, 2, 3)
     PWS(8, 3, 1, 3) PWS(6, 3, 1, 3) PWS(6, 5, 1, 3) PWS(3, 4, 1, 3) PWS(3, 4, 2, 3) PWS(2, 3, 2, 1) PWS(2, 3, 1, 1) PWS(2, 3, 4, 1)
     return 0;
 }
