@@ -47,7 +47,7 @@ def _family(name):
     return "expdw_kernel" if fam == "expdw_one_kernel" else fam
 
 
-POINTWISE_FAMILIES = ("pw_direct_kernel", "pw_stream_kernel", "pw_kernel", "pw_xs_kernel", "pw_group_kernel")     # stand-alone 1x1 launches (north_star's ">= 90 % of roofline" path; the fused head launch, whose GEMM is a 1x1 behind a depthwise, is reported as its own family)
+POINTWISE_FAMILIES = ("pw_direct_kernel", "pw_stream_kernel", "pw_wstat_kernel", "pw_kernel", "pw_xs_kernel", "pw_group_kernel")     # stand-alone 1x1 launches (north_star's ">= 90 % of roofline" path; the fused head launch, whose GEMM is a 1x1 behind a depthwise, is reported as its own family)
 
 
 def softmax_levels(graph, kernel_names):

@@ -500,6 +500,184 @@ __global__ __launch_bounds__(256) void pw_dw_direct_kernel(PwDwArgs q, int tiles
     }
 }
 
+
+// Weight-stationary variant for the EXPANSIONS (round 6): cin <= 128, no squeeze-excitation scale, no residual -- 24 -> 72 on the 80 x 80 map,
+// 40 -> 120, 80 -> 480, 112 -> 672 (mobilenetv3.py:76 expand ConvBNActivation) and the V2 expansions that run as launches of their own.
+// What the lab (tools/pw_lab.hip, ablations + in-kernel stamps, LAB_NOTEBOOK R6) found about pw_stream_kernel on 112 -> 672 (17.2 us by rocprofv3):
+// 6.5 us remain with every memory operation removed, the weight requests cost 4.5, the stores 5.1, the x requests 3.2 -- and they ADD, because (a) a
+// wave's fragment loads are 32-byte pieces of 32 different rows per instruction (32 tag lookups each; with 8 - 12 waves per CU the lines leave L1
+// between the K steps that use them: 13 M L1 accesses for a 40 MB layer), (b) loads and stores retire in order, so the wait for the next weight
+// tile is also a wait for the previous tile's stores, (c) one round of workgroups runs load | compute | store in lockstep over the chip.
+// Here
+//   * a wave keeps the A fragments of its RUN of RT channel tiles in registers for its whole life (staged once per workgroup through LDS from
+//     the fragment-major copy: 1 KB contiguous per LDS-DMA instruction; the bias joins as the (hi, lo) columns of the last K step);
+//   * it walks over 32-row pixel tiles: a tile of x is 64 cin CONTIGUOUS bytes, fetched by LDS-DMA as whole cache lines into the wave's own LDS
+//     buffer and read back as B fragments with ds_read_b128 -- the next tile's DMA is in flight during the matrix + epilogue work of this one;
+//   * no vector-memory load is waited for inside a tile, and the wait at the end of a tile is COUNTED: this tile's stores (buffer stores with an
+//     out-of-range offset for masked lanes, so their number is fixed) stay in flight behind it;
+//   * the tile leaves as 64-byte pieces (v_permlane32_swap + v_permlane16_swap: four lanes per pixel row and store instruction).
+// Arithmetic per output = pw_direct_kernel's (same K order, bias in the reduction, one rounding): bit-identical to it (test_pointwise_wstat_*).
+__device__ __forceinline__ void pw_glds16(const void* gsrc, unsigned dst) {
+    // LDS-DMA behind the compiler's back (headfuse.hip: as a builtin every later ds_read would wait for vmcnt(0)); M0 saved and restored
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+template <int KS1, int RT>
+__global__ __launch_bounds__(256) void pw_wstat_kernel(PwArgs a, int runs, int wg_per_group) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pws_lds[];
+    constexpr int KSF = KS1 - 1;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = a.cin, NC = a.cout;
+    const int ksw = (K + 15) >> 4;                       // K steps of the fragment-major copy (a tail step holds zeros in its upper half)
+    // XCD grouping as everywhere (pw_tile_rows): the workgroups with equal (flat index % 8) own the rows of one group of a.xq images
+    int r0, mend, w;
+    if (a.xq > 0) {
+        const int g = blockIdx.x & 7;
+        w = blockIdx.x >> 3;
+        r0 = g * a.xq * a.hw;
+        mend = min(a.m, r0 + a.xq * a.hw);
+    } else {
+        w = blockIdx.x; r0 = 0; mend = a.m;
+    }
+    const int run = w % runs, wgq = w / runs;
+    const int Q = (wg_per_group / runs) * 4;             // pixel tiles between two tiles of one wave
+    const int n_units = mend > r0 ? (mend - r0 + 31) >> 5 : 0;
+    const int ctiles = (NC + 31) >> 5;
+    const int ct0 = run * RT;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)pws_lds;
+    const unsigned xoff = (unsigned)(RT * ksw * 1024 + wave * ksw * 1024);          // this wave's x buffer: ksw pieces of 1 KB >= 64 K bytes
+    auto dma_x = [&](int u) {
+        const long row0 = (long)r0 + (long)u * 32;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.x + row0 * K);
+        const unsigned lim = (unsigned)min((long)(a.m - row0) * K * 2 - 16, 0x7fffffffL);           // the last 16 bytes of the tensor
+#pragma unroll 1
+        for (int p = 0; p < ksw; ++p) pw_glds16(src + min((unsigned)(p * 1024 + lane * 16), lim), lds0 + xoff + p * 1024);
+    };
+    int u = wgq * 4 + wave;
+    if (u < n_units) dma_x(u);
+    {
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wfrag) + (size_t)ct0 * ksw * 1024 + lane * 16;
+        const int pieces = max(min(RT, ctiles - ct0), 0) * ksw;
+#pragma unroll 1
+        for (int p = wave; p < pieces; p += 4) pw_glds16(wsrc + (size_t)p * 1024, lds0 + p * 1024);
+    }
+    float bl[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) bl[t] = a.bias[min((ct0 + t) * 32 + r, NC - 1)];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int kb = KSF * 16 + hh * 8;                    // first column of this lane in the last step: < K data, == K the bias columns, > K nothing
+    const bool data = kb < K, bcol = kb == K;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8 wf[RT][KS1];
+    {
+        const half8* wl = reinterpret_cast<const half8*>(pws_lds) + lane;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int tt = min(t, max(ctiles - ct0 - 1, 0));                          // (a run's tiles beyond the last: a valid tile again, never stored)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) wf[t][ks] = wl[(tt * ksw + min(ks, ksw - 1)) * 64];
+            const half_t hi = (half_t)bl[t];
+            const half8 bw = {hi, (half_t)(bl[t] - (float)hi), 0, 0, 0, 0, 0, 0};
+            wf[t][KSF] = data ? wf[t][KSF] : (bcol ? bw : zero8);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)a.m * (unsigned)NC * 2u), 0x00020000);
+    const half8 ones = {(half_t)1.f, (half_t)1.f, 0, 0, 0, 0, 0, 0};
+    const unsigned xrd = xoff + (unsigned)r * (unsigned)K * 2u;                       // this lane's row in the wave's x buffer
+    const unsigned xlast = (unsigned)min(kb, K - 8) * 2u;
+    const int colq = 8 * ((lane >> 5) + 2 * ((lane >> 4) & 1));
+    const int act = a.act;
+    for (; u < n_units; u += Q) {
+        half8 xf[KS1];
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) xf[ks] = *reinterpret_cast<const half8*>(pws_lds + xrd + (ks < KSF ? (unsigned)(ks * 32 + hh * 16) : xlast));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (u + Q < n_units) dma_x(u + Q);
+        xf[KSF] = data ? xf[KSF] : (bcol ? ones : zero8);
+        const int rr = r0 + u * 32 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            floatx16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[t][ks], xf[ks], acc, 0, 0, 0);
+            act16(acc, act);
+            uint2v p[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[4 * g + e];
+                p[g] = __builtin_bit_cast(uint2v, hv);
+            }
+            // permlane32: lane r <- channels 0..7 / 16..23, lane r + 32 <- 8..15 / 24..31 of pixel r (pw_direct_kernel); permlane16 on top: rows 0..15 of
+            // the tile end up in one register set with FOUR lanes per row (64 contiguous bytes per row and store instruction), rows 16..31 in the other
+            const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[1][0], false, false);
+            const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[1][1], false, false);
+            const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[2][0], p[3][0], false, false);
+            const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[2][1], p[3][1], false, false);
+            const uint2v q0 = __builtin_amdgcn_permlane16_swap(s0[0], s2[0], false, false);
+            const uint2v q1 = __builtin_amdgcn_permlane16_swap(s1[0], s3[0], false, false);
+            const uint2v q2 = __builtin_amdgcn_permlane16_swap(s0[1], s2[1], false, false);
+            const uint2v q3 = __builtin_amdgcn_permlane16_swap(s1[1], s3[1], false, false);
+            const u32x4 lo4 = {q0[0], q1[0], q2[0], q3[0]}, hi4 = {q0[1], q1[1], q2[1], q3[1]};
+            const int col = (ct0 + t) * 32 + colq;
+            const unsigned off = ((unsigned)rr * (unsigned)NC + (unsigned)col) * 2u;
+            const bool okc = col < NC;
+            __builtin_amdgcn_raw_buffer_store_b128(lo4, ors, (okc && rr < mend) ? off : 0x80000000u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(hi4, ors, (okc && rr + 16 < mend) ? off + 32u * (unsigned)NC : 0x80000000u, 0, 0);
+        }
+        // the next tile of x must have landed; this tile's 2 RT stores stay in flight (always issued: masked lanes carry an out-of-range offset)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * RT) : "memory");
+    }
+}
+
+template <int KS1, int RT>
+int launch_wstat_t(const PwArgs& a, hipStream_t s) {
+    const int ctiles = dn_cdiv(a.cout, 32), runs = dn_cdiv(ctiles, RT);
+    const int groups = a.xq > 0 ? 8 : 1;
+    const long rows = a.xq > 0 ? (long)a.xq * a.hw : a.m;
+    const int units = dn_cdiv(rows, 32);
+    // two workgroups per compute unit (188 registers at KS1 RT = 24: two waves per SIMD), fewer when there are not that many pixel tiles
+    int wpg = std::min(512 / groups, dn_cdiv(units, 4) * runs);
+    wpg = std::max(runs, wpg / runs * runs);
+    const int ksw = dn_cdiv(a.cin, 16);
+    const int lds = (RT + 4) * ksw * 1024;
+    dn_note_kernel("pw_wstat_kernel<%d,%d>", KS1, RT);
+    hipLaunchKernelGGL((pw_wstat_kernel<KS1, RT>), dim3((unsigned)(groups * wpg)), dim3(256), lds, s, a, runs, wpg);
+    return DN_OK;
+}
+
+static bool pw_wstat_supported_(const PwArgs& a) {
+    return dn_knob("DN_PW_WSTAT", 1) != 0 && a.wfrag && !a.se && !a.residual && a.cin >= 16 && a.cin <= 128 && a.cin % 8 == 0 && a.m >= 3200 &&
+           (long)a.m * a.cout * 2 < 0x7fffffffL && a.cout >= 64;
+}
+
+static int launch_pw_wstat_(const PwArgs& a, hipStream_t s) {
+    const int ks1 = a.cin / 16 + 1, ctiles = dn_cdiv(a.cout, 32);
+    // tiles per run: as many as 96 registers of A fragments allow, least padding of the last run first
+    int rt = 2, waste = 1 << 30;
+    for (int c = 4; c >= 2; --c) {
+        if (ks1 * c > 24) continue;
+        const int w = dn_cdiv(ctiles, c) * c - ctiles;
+        if (w < waste) { waste = w; rt = c; }
+    }
+    switch (ks1 * 10 + rt) {
+#define DN_PWS_CASE(k, t) case k * 10 + t: return launch_wstat_t<k, t>(a, s);
+        DN_PWS_CASE(2, 2) DN_PWS_CASE(2, 3) DN_PWS_CASE(2, 4) DN_PWS_CASE(3, 2) DN_PWS_CASE(3, 3) DN_PWS_CASE(3, 4) DN_PWS_CASE(4, 2) DN_PWS_CASE(4, 3) DN_PWS_CASE(4, 4)
+        DN_PWS_CASE(5, 2) DN_PWS_CASE(5, 3) DN_PWS_CASE(5, 4) DN_PWS_CASE(6, 2) DN_PWS_CASE(6, 3) DN_PWS_CASE(6, 4) DN_PWS_CASE(7, 2) DN_PWS_CASE(7, 3)
+        DN_PWS_CASE(8, 2) DN_PWS_CASE(8, 3) DN_PWS_CASE(9, 2)
+#undef DN_PWS_CASE
+    }
+    return DN_E_UNSUPPORTED;
+}
+
 template <int KSF, int TC>
 int launch_t(const PwArgs& a, int wc_log, hipStream_t s) {
     const int BP = 32 * (4 >> wc_log), BC = (32 * TC) << wc_log;
@@ -546,6 +724,8 @@ int launch_pw_direct(const PwArgs& a, hipStream_t s) {
     // registers overlap their single memory round trip better. Wide expansions (cout >= DN_PW_DIRECT_TC2, short reductions) take two
     // tiles per wave: every wave re-reads its x rows once per channel tile, and at 21 tiles (112 -> 672) that is most of the traffic
     // (measured: threshold 400 -> batch 64 1.115 -> 1.107 ms, batch 32 0.79 -> 0.77 ms; 200 and 600 in between).
+    // the expansions (short reduction, wide output, no scale, no residual): weight-stationary waves over LDS-DMA'd pixel tiles (round 6)
+    if (pw_wstat_supported_(a)) return launch_pw_wstat_(a, s);
     const int ctiles = dn_cdiv(a.cout, 32);
     const int ksf = a.cin >> 4;
     // wide expansions with enough rows: the streaming variant (pw_stream_kernel) -- channel runs sized so that all waves are resident at once

@@ -120,6 +120,39 @@ def test_pointwise_streaming_bit_identical_to_direct(m, cin, cout, hw, act, monk
 
 
 
+
+@pytest.mark.parametrize("m,cin,cout,hw,act", [
+    (25600, 112, 672, 400, 3), (64 * 100, 80, 480, 100, 3), (13 * 1600, 40, 120, 1600, 1), (9 * 6400, 24, 72, 6400, 1),     # the V3 expansions
+    (25600 + 37, 112, 672, 25637, 3),                       # one "image": plain mapping, ragged last tile
+    (13 * 400, 80, 480, 400, 3),                            # XCD groups of 2 images, the last group short, 25 tiles per image pair
+    (8 * 5625, 16, 96, 5625, 2), (19 * 361, 64, 384, 361, 2), (40 * 100, 96, 576, 100, 2), (3300, 128, 264, 3300, 0),    # V2-like: odd maps, K = 128, cout % 32 == 8
+    (7 * 1444, 32, 192, 1444, 2), (9 * 400, 48, 72, 400, 1),
+])
+def test_pointwise_wstat_bit_identical_to_direct(m, cin, cout, hw, act, monkeypatch):
+    """pw_wstat_kernel (round 6: weight-stationary waves, x tiles by LDS-DMA, counted waits, 64-byte store pieces) computes every output with
+    pw_direct_kernel's arithmetic -- same K order, bias in the reduction, one rounding -- so the two agree bit for bit; pw_direct_kernel is
+    the path test_pointwise_conv holds against the fp32 reference. Also against that reference directly."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(m + cin)
+    x = torch.randn(m, cin, generator=g).half()
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).half()
+    b = torch.randn(cout, generator=g)
+    ref = _act(x.float() @ w.float().t() + b, act).half().float()
+    xd, bd, wd = x.cuda(), b.cuda(), w.cuda()
+    wfd = torch.from_numpy(fragment_major(w.numpy())).cuda()
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_PW_WSTAT", flag)
+        out = torch.full((m + 64, cout), -777.0, dtype=torch.half, device="cuda")     # 64 guard rows behind the tensor
+        L.check(lib.dn_pointwise_conv(_ptr(xd), _ptr(wd), _ptr(wfd), _ptr(bd), _ptr(None), _ptr(None), _ptr(out), m, cin, cout, hw, act, 0, 0,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dn_pointwise_conv")
+        torch.cuda.synchronize()
+        assert bool((out[m:] == -777.0).all())
+        outs.append(out[:m])
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().max()) > 0
+    torch.testing.assert_close(outs[1].cpu().float(), ref, rtol=4e-3, atol=4e-3)
+
+
 @pytest.mark.parametrize("m,cin,cout,hw,se,res", [(19200, 480, 112, 400, True, False), (25600 + 37, 672, 112, 25637, False, False),
                                                   (9 * 400, 672, 112, 400, True, True), (6400, 480, 256, 100, False, False),
                                                   (13 * 100 + 0, 960, 160, 100, True, False)])

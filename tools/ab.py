@@ -10,7 +10,7 @@ for setting in args:
     env = dict(os.environ)
     for kv in filter(None, setting.split(",")):
         k, v = kv.split("="); env[k] = v
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "200", "--warmup", "20"] + extra, env=env, capture_output=True, text=True)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-configs", "--steps", "200", "--warmup", "20"] + extra, env=env, capture_output=True, text=True)
     try:
         d = json.loads(p.stdout.strip().splitlines()[-1])
     except Exception:
