@@ -97,6 +97,9 @@ struct dn_plan {
     size_t weight_bytes = 0;
     float* anchors_dev = nullptr;
     std::map<int, Layout> layouts;
+    // workspaces whose last forward was dn_forward (not dn_forward_heads): their head arrays may be incomplete -- from DN_HEAD_SOFTMAX_MINN images
+    // per chain up the fused head launch writes scores / boxes instead of the large levels' logits -- so dn_head_outputs refuses them
+    std::map<const void*, bool> heads_partial;
     bool graph_mode = true;
     std::map<GraphKey, hipGraphExec_t> graphs;
     hipStream_t capture_stream = nullptr;   // capture never happens on the caller's stream (may be the null stream)
@@ -1240,6 +1243,7 @@ static int forward_impl(dn_plan* p, const float* images, int n, int h, int w, fl
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    p->heads_partial[workspace] = !heads_only;
     if (p->profiling) {
         const int S = batch_split(p, n);
         const size_t stride = p->ops.size() + 6;
@@ -1355,6 +1359,11 @@ extern "C" int dn_forward_heads(dn_plan* plan, const float* images_dev, int n, i
 
 extern "C" int dn_head_outputs(const dn_plan* p, void* workspace, int n, float** logits, float** reg) {
     DN_REQUIRE(p && workspace && n > 0, "dn_head_outputs: bad argument");
+    {
+        const auto it = p->heads_partial.find(workspace);
+        DN_REQUIRE(it == p->heads_partial.end() || !it->second, "dn_head_outputs: the last forward on this workspace was dn_forward, which may compute softmax / box "
+                   "decode inside the head launch and never writes the large levels' logits: run dn_forward_heads first");
+    }
     const Layout& L = get_layout(const_cast<dn_plan*>(p), n);
     if (logits) *logits = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + L.logits_off);
     if (reg) *reg = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + L.reg_off);

@@ -107,7 +107,7 @@ DN_API int dn_forward_u8(dn_plan* plan, const uint8_t* images_dev, int n, int h,
 /* Backbone + heads only (no post-process). The head outputs live inside the workspace; query them with
  * dn_head_outputs:  cls_logits [n][A][K] fp32, bbox_regression [n][A][4] fp32 (generalized_ssd.py:60-74). Valid after
  * dn_forward_heads only: dn_forward may compute softmax / box decode inside the head launch and then never writes the logits
- * of the large pyramid levels. */
+ * of the large pyramid levels -- dn_head_outputs returns DN_E_INVALID for a workspace whose last forward was dn_forward. */
 DN_API int dn_forward_heads(dn_plan* plan, const float* images_dev, int n, int h, int w,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
 DN_API int dn_head_outputs(const dn_plan* plan, void* workspace_dev, int n, float** cls_logits_dev, float** bbox_regression_dev);

@@ -1118,3 +1118,21 @@ def test_c2_full_batch_against_the_cpu_path():
             share = ((iou > 0.9) & (d["labels"][:, None] == labels[i, :c][None, :])).any(1).mean()
             print(f"{form}: image {i}: {share * 100:.1f}% of the CPU path's detections reproduced")
             assert share >= HIT_MIN, (form, i, share)
+
+
+def test_head_outputs_are_refused_after_a_full_forward():
+    """dn_head_outputs is valid behind dn_forward_heads only (include/demonet_hip.h): dn_forward may finish the large levels inside the head
+    launch and never write their logits. Round-5 advice: the call must say so instead of handing out pointers to stale rows."""
+    from demonet_amd import _lib
+    m = _model("ssdlite320_mobilenet_v3_large", num_classes=91)
+    imgs = torch.from_numpy(synth.images(5, 40, 320, 320)).cuda()
+    logits, _ = m.forward_heads(imgs)                       # dn_forward_heads + dn_head_outputs: fine
+    assert bool(torch.isfinite(logits).all())
+    m.forward_batch(imgs)
+    torch.cuda.synchronize()
+    b = m._buffers_for(40, 320, 320, imgs.device)
+    pl, pr = C.c_void_p(), C.c_void_p()
+    rc = _lib.lib().dn_head_outputs(C.c_void_p(m._handle), C.c_void_p(b["ws"].data_ptr()), 40, C.byref(pl), C.byref(pr))
+    assert rc < 0 and b"dn_forward_heads" in _lib.lib().dn_last_error()
+    logits2, _ = m.forward_heads(imgs)                      # ... and valid again behind the next heads-only forward
+    assert torch.equal(logits, logits2)
