@@ -522,6 +522,206 @@ __global__ __launch_bounds__(256) void k_pws(Args a, int runs, int n_units) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// candidate 3 ("kproj"): projections (long K, few channels) -- lab copy of demonet_amd/csrc/pwproj.hip with ablation flags
+struct KArgs { const half_t* x; const half_t* wfrag; const float* bias; const half_t* residual; const float* se; half_t* out; int m, cin, cout, hw, act, xq; long long* stamps; };
+constexpr int KP_KC = 64, KP_IMGS = 3;
+__device__ __forceinline__ void kp_glds16(const void* gsrc, unsigned dst) {
+#ifdef LAB_M0_NOSAVE
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(dst) : "memory");
+#else
+    glds16(gsrc, dst);
+#endif
+}
+template <int N> __device__ __forceinline__ void kp_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// FL: 1 = stamps, 2 = weight pieces from one hot line, 4 = x pieces from one hot line, 8 = no MFMA
+template <int NTL, int D, int FL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_kproj(KArgs a, int wg_per_group) {
+    long long tw = 0, tc = 0, t0 = __builtin_amdgcn_s_memrealtime();
+    extern __shared__ __attribute__((aligned(16))) unsigned char kp_lds[];
+    constexpr int PPW = NTL + 4;                            // DMA instructions per wave and stage: NTL weight pieces + its 4 x pieces
+    constexpr int STAGE = (NTL * 4 + 16) * 1024;            // bytes: [NTL tiles][4 K steps] fragments of 1 KB, then [4 waves][4 pieces] of x
+    static_assert((D - 1) * PPW <= 63, "vmcnt is six bits");
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = a.cin, NC = a.cout;
+    const int KS = K >> 4;                                  // 16-deep K steps (K % 16 == 0)
+    const int nst = (KS + 3) >> 2;                          // stages
+    int r0, mend, w;
+    if (a.xq > 0) {
+        const int g = blockIdx.x & 7;
+        w = blockIdx.x >> 3;
+        r0 = g * a.xq * a.hw;
+        mend = min(a.m, r0 + a.xq * a.hw);
+    } else {
+        w = blockIdx.x; r0 = 0; mend = a.m;
+    }
+    const int wrow0 = r0 + w * 128;                         // the workgroup's first row
+    if (wrow0 >= mend) return;                              // (uniform over the workgroup)
+    const int row0 = wrow0 + wave * 32;                     // the wave's first row
+    const bool live = row0 < mend;                          // a wave without rows still copies its share of the weights
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)kp_lds;
+    float* const tab = reinterpret_cast<float*>(kp_lds + D * STAGE);             // [KP_IMGS][K] squeeze-excitation scales (with a.se), then [32 NTL] bias
+    float* const bsh = tab + (a.se ? KP_IMGS * K : 0);
+
+    // ---- the DMA of one stage: this wave's x rows (4 pieces of 8 rows x 128 B) and NTL of the stage's 4 NTL weight fragments
+    const int xr = min(row0 + (lane >> 3), mend - 1);       // piece p covers rows 8 p .. 8 p + 7 of the wave's tile: this lane's row of piece 0
+    const unsigned char* const xbase = reinterpret_cast<const unsigned char*>(a.x);
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(a.wfrag);
+    const int part = (lane & 7) ^ (lane >> 3);              // the 16-byte part of the row's 128-byte run this lane copies (XOR swizzle by the row)
+    const int ctiles = (NC + 31) >> 5;
+    // share q (0 .. 3) of a stage's DMA: x piece q and the weight pieces q, q + 4, ... of this wave -- issued behind K step q of the stage in
+    // flight, so that an instruction that holds the vector-memory issue path for ~100 cycles sits under that step's matrix instructions
+    auto stage_dma_share = [&](int st, int q) {
+        const unsigned dst = lds0 + (unsigned)((st % D) * STAGE);
+        if (st < nst) {
+            const int k0 = st * KP_KC + part * 8;           // first K column of this lane's part; beyond K (the last stage of K % 64 == 32): a valid dummy
+            const int kc = min(k0, K - 8);
+            const long row = min(xr + 8 * q, mend - 1);
+            kp_glds16((FL & 4) ? (const void*)(wbase + lane * 16) : (const void*)(xbase + (row * K + kc) * 2), dst + (unsigned)(NTL * 4096 + (wave * 4 + q) * 1024));
+#pragma unroll
+            for (int i = q; i < NTL; i += 4) {
+                const int piece = wave * NTL + i;           // (tile, step) = (piece / 4, piece % 4)
+                const int t = min(piece >> 2, ctiles - 1), ks = min(st * 4 + (piece & 3), KS - 1);
+                kp_glds16((FL & 2) ? wbase + lane * 16 : wbase + ((size_t)(t * KS + ks) * 64 + lane) * 16, dst + (unsigned)(piece * 1024));
+            }
+        } else {
+            // behind the last stage: the same number of instructions (the counted wait below relies on it), one hot line, a ring slot nobody reads any more
+            kp_glds16(wbase + lane * 16, dst + (unsigned)(q * 1024));
+#pragma unroll
+            for (int i = q; i < NTL; i += 4) kp_glds16(wbase + lane * 16, dst + (unsigned)((4 + i) * 1024));
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < D - 1; ++st)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_dma_share(st, q);
+
+    // ---- tables: squeeze-excitation scales of the workgroup's images, bias
+    const int img_first = wrow0 / a.hw;
+    const int nimg_all = (a.m + a.hw - 1) / a.hw;
+    if (a.se) {
+        for (int i = threadIdx.x; i < KP_IMGS * K; i += 256) {
+            const int im = i / K, k = i - im * K;
+            tab[i] = a.se[(size_t)min(img_first + im, nimg_all - 1) * K + k];
+        }
+    }
+    for (int i = threadIdx.x; i < 32 * NTL; i += 256) bsh[i] = i < NC ? a.bias[i] : 0.f;
+    // residual rows in the accumulator layout (pw_direct_kernel), requested now
+    const int row = row0 + r;
+    const int rowc = min(row, mend - 1);
+    uint2 rres[NTL][4];
+    const bool has_res = a.residual != nullptr;
+    if (has_res) {
+        const half_t* rp = a.residual + (size_t)rowc * NC;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rres[t][g] = *reinterpret_cast<const uint2*>(rp + min(t * 32 + 8 * g + 4 * hh, NC - 4));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (compiler-visible loads must not sit between the DMA stages and their counted waits)
+    }
+    const float* const srow = tab + (a.se ? (rowc / a.hw - img_first) * K + hh * 8 : 0);
+
+    floatx16 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // this lane's B fragment of K step s of a stage: row r of the wave's tile = piece r / 8, row r % 8 of it; part 2 s + hh, swizzled
+    const unsigned xrd = (unsigned)(NTL * 4096 + wave * 4096 + (r >> 3) * 1024 + (r & 7) * 128);
+    const bool has_se = a.se != nullptr;
+    for (int st = 0; st < nst; ++st) {
+        // stage st has landed (this wave's pieces: all but those of the D - 2 younger stages; the other waves': the barrier)
+        long long ta = (FL & 1) ? __builtin_amdgcn_s_memrealtime() : 0;
+        kp_wait<(D - 2) * PPW>();
+        __syncthreads();
+        long long tb = (FL & 1) ? __builtin_amdgcn_s_memrealtime() : 0;
+        tw += tb - ta;
+        // (the DMA of stage st + D - 1 goes into the slot stage st - 1 was read from: every wave is past it)
+        const unsigned char* sb = kp_lds + (st % D) * STAGE;
+        const int steps = live ? min(4, KS - st * 4) : 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < steps) {
+                half8 bf = *reinterpret_cast<const half8*>(sb + xrd + (unsigned)(((2 * s + hh) ^ (r & 7)) * 16));
+                if (has_se) {
+                    // (half)((float)x * s) in one instruction per value: v_fma_mixlo / mixhi_f16 multiply in fp32 and round once to fp16 -- the
+                    // rounding of every other 1x1 kernel's scale8 (8 instructions per fragment instead of 20: the scaling is this wave's vector work)
+                    const float4 s0 = *reinterpret_cast<const float4*>(srow + st * KP_KC + s * 16);
+                    const float4 s1 = *reinterpret_cast<const float4*>(srow + st * KP_KC + s * 16 + 4);
+                    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                    u32x4 xb = __builtin_bit_cast(u32x4, bf), ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned d = 0;
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "+v"(d) : "v"(xb[e]), "v"(sv[2 * e]));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(xb[e]), "v"(sv[2 * e + 1]));
+                        ob[e] = d;
+                    }
+                    bf = __builtin_bit_cast(half8, ob);
+                }
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    const half8 af = *reinterpret_cast<const half8*>(sb + (unsigned)((t * 4 + s) * 1024 + lane * 16));
+                    if (FL & 8) acc[t][0] += (float)af[0] * (float)bf[0]; else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stage_dma_share(st + D - 1, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (FL & 1) { const long long t1 = __builtin_amdgcn_s_memrealtime(); if (lane == 0) { long long* sp = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 4; sp[0] = t0; sp[1] = t0 + tw; sp[2] = t1; sp[3] = t1; } }
+    if (!live) return;
+    // ---- epilogue
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)a.m * (unsigned)NC * 2u), 0x00020000);
+    const int colq = 8 * ((lane >> 5) + 2 * ((lane >> 4) & 1));
+    const int rr = row0 + (lane & 15);
+    const int act = a.act;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        if (t * 32 >= NC) break;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(&bsh[t * 32 + 8 * g + 4 * hh]);
+            acc[t][4 * g] += b.x; acc[t][4 * g + 1] += b.y; acc[t][4 * g + 2] += b.z; acc[t][4 * g + 3] += b.w;
+        }
+        act16(acc[t], act);
+        if (has_res) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half4 q = __builtin_bit_cast(half4, rres[t][g]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][4 * g + e] += (float)q[e];
+            }
+        }
+        uint2v p[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (half_t)acc[t][4 * g + e];
+            p[g] = __builtin_bit_cast(uint2v, hv);
+        }
+        const uint2v s0 = __builtin_amdgcn_permlane32_swap(p[0][0], p[1][0], false, false);
+        const uint2v s1 = __builtin_amdgcn_permlane32_swap(p[0][1], p[1][1], false, false);
+        const uint2v s2 = __builtin_amdgcn_permlane32_swap(p[2][0], p[3][0], false, false);
+        const uint2v s3 = __builtin_amdgcn_permlane32_swap(p[2][1], p[3][1], false, false);
+        const uint2v q0 = __builtin_amdgcn_permlane16_swap(s0[0], s2[0], false, false);
+        const uint2v q1 = __builtin_amdgcn_permlane16_swap(s1[0], s3[0], false, false);
+        const uint2v q2 = __builtin_amdgcn_permlane16_swap(s0[1], s2[1], false, false);
+        const uint2v q3 = __builtin_amdgcn_permlane16_swap(s1[1], s3[1], false, false);
+        const u32x4 lo4 = {q0[0], q1[0], q2[0], q3[0]}, hi4 = {q0[1], q1[1], q2[1], q3[1]};
+        const int col = t * 32 + colq;
+        const unsigned off = ((unsigned)rr * (unsigned)NC + (unsigned)col) * 2u;
+        const bool okc = col < NC;
+        __builtin_amdgcn_raw_buffer_store_b128(lo4, ors, (okc && rr < mend) ? off : 0x80000000u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi4, ors, (okc && rr + 16 < mend) ? off + 32u * (unsigned)NC : 0x80000000u, 0, 0);
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host
 static std::vector<half_t> pack_frag_bias(const std::vector<half_t>& w, const std::vector<float>& b, int N, int K) {
@@ -611,6 +811,7 @@ int main(int argc, char** argv) {
     long long* dstamps; const size_t nst = (size_t)1 << 20;
     CK(hipMalloc(&dstamps, nst * 8)); CK(hipMemset(dstamps, 0, nst * 8));
     Args a{dx, dw, dwfb, db, nullptr, M, K, N, act, dstamps};
+    auto stamp_report_fwd = 0; (void)stamp_report_fwd;
     auto stamp_report = [&](int nwaves, bool h2 = false) {
         std::vector<long long> h((size_t)nwaves * 4);
         CK(hipMemcpy(h.data(), dstamps, h.size() * 8, hipMemcpyDeviceToHost));
@@ -654,6 +855,25 @@ int main(int argc, char** argv) {
         BASE(KSFv, 2, 2, "base, no stores") BASE(KSFv, 2, 4, "base, no x loads") BASE(KSFv, 2, 3, "base, no weight loads, no stores") \
         BASE(KSFv, 2, 5, "base, no weight loads, no x loads") BASE(KSFv, 2, 7, "base, MFMA + epilogue VALU only") BASE(KSFv, 2, 15, "base, launch + VALU only") \
         BASE(KSFv, 1, 0, "base stream<" #KSFv ",1>")
+
+    if (K >= 256) {
+        // projection lab: fragment-major weights WITHOUT the bias step (plan.py fragment_major), no SE / residual (the ablations are about the streams)
+        const int nt = (N + 31) / 32, KS = K / 16;
+        std::vector<half_t> wf((size_t)nt * KS * 64 * 8, (half_t)0.f);
+        for (int t = 0; t < nt; ++t) for (int ks = 0; ks < KS; ++ks) for (int l = 0; l < 64; ++l) { const int r = l & 31, hh = l >> 5, n = t * 32 + r;
+            if (n < N) for (int e = 0; e < 8; ++e) wf[(((size_t)t * KS + ks) * 64 + l) * 8 + e] = hw[(size_t)n * K + ks * 16 + hh * 8 + e]; }
+        half_t* dwf; CK(hipMalloc(&dwf, wf.size() * 2)); CK(hipMemcpy(dwf, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+        const int hwp = 400;
+#define KPROJ(NTLv, Dv, FLv, nm) if ((N + 31) / 32 <= NTLv && (NTLv == 3 || (N + 31) / 32 > (NTLv == 4 ? 3 : NTLv == 6 ? 4 : 6))) { const int wpg = (M + 127) / 128; \
+        const size_t ldsb = (size_t)Dv * (NTLv * 4 + 16) * 1024 + 32 * NTLv * 4; \
+        CK(hipFuncSetAttribute((const void*)k_kproj<NTLv, Dv, FLv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        bench(nm, [&](half_t* o) { KArgs b{dx, dwf, db, nullptr, nullptr, o, M, K, N, hwp, act, 0, dstamps}; hipLaunchKernelGGL((k_kproj<NTLv, Dv, FLv>), dim3(wpg), dim3(256), ldsb, s, b, wpg); }, false); \
+        if (FLv & 1) stamp_report(wpg * 4); }
+#define KPROJS(NTLv, Dv) KPROJ(NTLv, Dv, 0, "kproj") KPROJ(NTLv, Dv, 1, "kproj stamps (operands ready = time in waits)") KPROJ(NTLv, Dv, 2, "kproj, weights from one hot line") \
+        KPROJ(NTLv, Dv, 4, "kproj, x from one hot line") KPROJ(NTLv, Dv, 6, "kproj, both from one hot line") KPROJ(NTLv, Dv, 8, "kproj, no MFMA") KPROJ(NTLv, Dv, 14, "kproj, launch + DMA issue + LDS only")
+        KPROJS(3, 4) KPROJS(4, 4) KPROJS(6, 3) KPROJS(8, 3)
+        return 0;
+    }
     { int per; const int runs = runs_for(2, 2800, per); const int tiles = (M + 255) / 256;
       bench("null kernel, same grid", [&](half_t* o) { Args b = a; b.out = o; hipLaunchKernelGGL(k_null, dim3(tiles * runs), dim3(256), 0, s, b, tiles, per); }, false); }
     BASES(1) BASES(2) BASES(4) BASES(5) BASES(7)
