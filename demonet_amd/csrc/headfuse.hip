@@ -113,62 +113,66 @@ __device__ __forceinline__ void hf_fma8v(float (&acc)[8], const u32x4& x, const 
     }
 }
 
-// Scores of one histogram window: rows [ra, ra + wr) of the half tile, lying in at most HF_NP images. Wave w takes the classes w, w + 4, ...; per
-// class its lanes hold NB x 64 rows (rows beyond wr masked): NB independent read -> multiply -> store chains per class (the epilogue runs at two waves
-// per SIMD; everything per row -- LDS address, reciprocal of the row sum, byte offset of the score, histogram of its image -- sits in registers and
-// advances by constants). A store instruction writes 64 consecutive anchors of one class (256 contiguous bytes; rows are consecutive canonical
-// anchors). A class belongs to ONE wave, so its counts of passing scores are ballots added up in scalar registers and written once, no atomics.
-// The rows lie in at most two images (levels with >= 32 pixels per image).
-template <int NB>
-__device__ __forceinline__ void hf_scores(const HeadPost& P, const float* __restrict__ lg, const float* __restrict__ rowrcp, const unsigned* __restrict__ rowoff,
-                                          const unsigned* __restrict__ ranc, const unsigned char* __restrict__ rpart, unsigned* __restrict__ lhist,
-                                          const int ra, const int wr, const int w0, const int wq0, const int wave, const int lane, const int Km1, const int ccb) {
-    unsigned eo[NB], ob4[NB], hb[NB];       // (LDS element index, not a pointer: a pointer array loses the LDS address space and turns into flat loads)
-    float rinv[NB];
-    bool ok[NB];
-    unsigned long long q1m[NB];             // lanes whose row lies in the half tile's second image (wave-uniform mask: the per-class counts are scalar work)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        ok[b] = 64 * b + lane < wr;
-        const int row = ra + (ok[b] ? 64 * b + lane : 0);
-        eo[b] = rowoff[row] + 1u + (unsigned)wave;
-        rinv[b] = rowrcp[row];
-        const int q = (int)rpart[row] - wq0;
-        q1m[b] = __ballot(q != 0);
-        hb[b] = (unsigned)q * 256u;
-        ob4[b] = (((unsigned)(w0 + q) * (unsigned)Km1 + (unsigned)wave) * (unsigned)P.A + ranc[row]) * 4u;      // (host: n (K - 1) A < 2^30)
-    }
-    const unsigned step4 = 16u * (unsigned)P.A;             // bytes between class k and class k + 4
+// Softmax rows AND scores in one pass (round 6). Until then a half tile's rows were walked twice: pp_softmax_row replaced the logits in LDS by exp(x - max)
+// (two reads and a write per element), a barrier, then hf_scores read every element again, multiplied, stored (in-kernel stamps: 34 k + 35 k of a
+// workgroup's 150 k cycles). Here the four lanes of a row keep their 23 exponentials in registers: one LDS read per element, the row's maximum and sum
+// through the same two xor-shuffles in the same order (pp_softmax_row's arithmetic, bit for bit), then score = e * (1 / sum) straight to memory -- a store
+// instruction writes four classes x 16 consecutive anchors (64 contiguous bytes each). The per-class counts of passing scores, ballots in hf_scores (a
+// class belonged to one wave there), are LDS atomics here like the histogram bins: passing scores are a few per cent.
+__device__ __forceinline__ void hf_softmax_scores(const HeadPost& P, const float* __restrict__ lg, const unsigned* __restrict__ rowoff, const unsigned* __restrict__ ranc,
+                                                  const unsigned char* __restrict__ rpart, unsigned* __restrict__ lhist, const int nrows, const int img_first,
+                                                  const int te, const int K, const int ccb) {
+#pragma clang fp contract(off)
+    const int Km1 = K - 1, sub = te & 3;
     char* const sbase = reinterpret_cast<char*>(P.scoresT);
-    // software-pipelined: the LDS reads of class k + 4 are issued before the stores / histogram atomics of class k (LDS operations are ordered:
-    // behind the atomics every read would wait for them, and a lone wave per SIMD has nothing else to run)
-    float cur[NB];
+    const unsigned step4 = 4u * (unsigned)P.A;              // bytes between class k and class k + 1
+    for (int rb = 0; rb < nrows; rb += 64) {
+        const int row = rb + (te >> 2);
+        const bool valid = row < nrows;
+        const float* rp = lg + (valid ? rowoff[row] : 0u);
+        float mx = -INFINITY, sm = 0.f;
+        float v[24];                                        // element 8 b + u <-> class k = sub + 32 b + 4 u (pp_softmax_row's batches)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) cur[b] = lg[eo[b]];
-    for (int k1 = wave; k1 < Km1; k1 += 4) {
-        float sc[NB], nxt[NB];
+        for (int b = 0; b < 3; ++b) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            eo[b] += (k1 + 4 < Km1) ? 4u : 0u;             // (the last iteration re-reads its own element)
-            nxt[b] = lg[eo[b]];
-            sc[b] = pp_score(cur[b], rinv[b]);
-        }
-        int c_all = 0, c_1 = 0;
+            for (int u = 0; u < 8; ++u) v[8 * b + u] = rp[min(sub + 32 * b + 4 * u, K - 1)];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (ok[b]) *reinterpret_cast<float*>(sbase + ob4[b]) = sc[b];
-            ob4[b] += step4;
-            const bool pass = ok[b] && sc[b] > P.score_thr;
-            if (pass) atomicAdd(&lhist[hb[b] + (unsigned)pp_hist_bin(sc[b], P.hb0, P.nb)], 1u);
-            const unsigned long long pm = __ballot(pass);
-            c_all += __popcll(pm);
-            c_1 += __popcll(pm & q1m[b]);
-            cur[b] = nxt[b];
+            for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[8 * b + u]);
         }
-        if (ccb >= 0 && lane == 0) {
-            lhist[ccb + k1] = (unsigned)(c_all - c_1);
-            lhist[256 + ccb + k1] = (unsigned)c_1;
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[8 * b + u] = pp_exp_nonpos(v[8 * b + u] - mx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (sub + 32 * b + 4 * u < K) sm += v[8 * b + u];
         }
+        sm += __shfl_xor(sm, 1);
+        sm += __shfl_xor(sm, 2);
+        if (!valid) continue;
+        const float rinv = pp_row_rcp(sm);
+        // (the row's tables are read HERE, behind the exponentials: held across them they cost the one register the 256-register budget does not have)
+        int rw = row;
+        asm volatile("" : "+v"(rw));
+        const unsigned q = rpart[rw];
+        const unsigned hb = q * 256u;
+        const unsigned ob4 = (((unsigned)(img_first + (int)q) * (unsigned)Km1) * (unsigned)P.A + ranc[rw]) * 4u + (unsigned)(sub - 1) * step4;     // class sub - 1 (sub = 0: the background, skipped)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = sub + 32 * b + 4 * u;
+                if (k >= 1 && k < K) {
+                    const float sc = pp_score(v[8 * b + u], rinv);
+                    *reinterpret_cast<float*>(sbase + (unsigned)(ob4 + (unsigned)(8 * b + u) * 4u * step4)) = sc;       // (32-bit sum first: for sub = 0 ob4 is "class -1" modulo 2^32)
+                    if (sc > P.score_thr) {
+                        atomicAdd(&lhist[hb + (unsigned)pp_hist_bin(sc, P.hb0, P.nb)], 1u);
+                        if (ccb >= 0) atomicAdd(&lhist[hb + (unsigned)(ccb + k - 1)], 1u);
+                    }
+                }
+            }
     }
 }
 
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
                     }
                 }
             }
+            for (int t = te; t < HF_NP * 256; t += 256) lhist[t] = 0u;
             // row tables: row = pixel * AL + anchor -- consecutive rows are consecutive canonical anchors
             int bx_px = 0, bx_a = 0, bx_img = 0, bx_anc = 0;
             if (te < nrows) {
@@ -478,26 +483,10 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(HfGroup g) {
                 const float4 an = reinterpret_cast<const float4*>(P.anchors)[bx_anc];
                 P.boxes[(size_t)bx_img * P.A + bx_anc] = pp_decode_box(rg4, an, P.img_w, P.img_h);
             }
-            // (S) softmax rows: four adjacent lanes per row, 64 rows per pass
-            for (int rb = 0; rb < nrows; rb += 64) {
-                const int row = rb + (te >> 2);
-                const bool valid = row < nrows;
-                const float sm = pp_softmax_row(lg + (valid ? rowoff[row] : 0u), K, te & 3, valid);
-                if (valid && (te & 3) == 0) rowsum[row] = pp_row_rcp(sm);      // (the reciprocal: scores are e * (1 / sum), post_math.h)
-            }
+            // (S + P) softmax rows and scores in one pass: four adjacent lanes per row, 64 rows per pass (hf_softmax_scores)
+            hf_softmax_scores(P, lg, rowoff, ranc, rpart, lhist, nrows, img_first, te, K, ccb);
             __syncthreads();
             HF_T(se2);
-            // (P) scores out, class-major, + histogram rows
-            for (int t = te; t < HF_NP * 256; t += 256) lhist[t] = 0u;
-            __syncthreads();
-            {
-                const int nb64 = (nrows + 63) >> 6;
-                if (nb64 == 1) hf_scores<1>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
-                else if (nb64 == 2) hf_scores<2>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
-                else if (nb64 == 3) hf_scores<3>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
-                else hf_scores<4>(P, lg, rowsum, rowoff, ranc, rpart, lhist, 0, nrows, img_first, 0, wave, lane, Km1, ccb);
-            }
-            __syncthreads();
             // the rows of this half tile's (at most two) images: slot = half tiles of the range between the image's first one and this one
 #pragma unroll
             for (int qq = 0; qq < HF_NP; ++qq) {

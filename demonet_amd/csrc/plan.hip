@@ -839,7 +839,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 if (!head_fused_level_supported(f)) continue;
                 // DN_HEAD_FUSE_MINHW: levels with fewer pixels per image stay on the grouped launches. The fused workgroups take 512 residency
                 // slots (2 per CU); at batch 64 levels 0 - 1 are 504 of them, every further workgroup starts a second round of the whole launch
-                if (ti.h * ti.w < 0) continue;
+                if (ti.h * ti.w < dn_knob("DN_HEAD_FUSE_MINHW", 0)) continue;
                 if (nl > 0 && (dn_cdiv(f.nc[0], 32) + 4) / 4 != (dn_cdiv(fl[0].nc[0], 32) + 4) / 4) continue;      // (one instantiation per launch: channel tiles per wave)
                 ++nl;
                 members.push_back(dc); members.push_back(dr); members.push_back(h_cls[q]); members.push_back(qr);
@@ -867,7 +867,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                         const int level = p->ops[members[4 * q + 2]].level;
                         fl[q].aoff = p->level_off[level];
                         fl[q].aloc = fl[q].nc[0] / d.num_classes;
-                        fl[q].sm = fl[q].H * fl[q].W >= 32 ? 1 : 0;
+                        fl[q].sm = fl[q].H * fl[q].W >= std::max(32, dn_knob("DN_HEAD_SM_MINHW", 32)) ? 1 : 0;
                         if (fl[q].sm) {
                             prefix = prefix && nsm == q && (q == 0 ? fl[q].aoff == 0 : fl[q].aoff == fl[q - 1].aoff + fl[q - 1].H * fl[q - 1].W * fl[q - 1].aloc);
                             fl[q].sbase = rows;
