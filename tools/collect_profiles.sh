@@ -6,4 +6,4 @@ for tag in "$@"; do
     [ -f gpurun_out/$tag/$f ] && cp gpurun_out/$tag/$f profiles/${tag}_$f
   done
 done
-ls profiles | grep -c "^r05"
+ls profiles | grep -c "^r06"

@@ -10,7 +10,7 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 for kv in "${ENVS[@]}"; do export "$kv"; done
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$NAME -o p -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/log_$NAME.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$NAME -o p -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline --no-latency --no-configs "$@" > $OUT/log_$NAME.txt 2>&1
 python3 - <<PY
 import csv,re,glob,json
 f=glob.glob('/tmp/ks_$NAME/**/p_kernel_stats.csv',recursive=True)[0]

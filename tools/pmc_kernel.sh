@@ -28,7 +28,7 @@ GROUPS_=(
 i=0
 for g in "${GROUPS_[@]}"; do
   # (every pass under its own timeout: a TA_* group aborted rocprofv3 on this image and its finalization then hung for the whole call)
-  timeout 180 rocprofv3 --pmc $g --kernel-trace --output-format csv -d /tmp/pk_$NAME/$i -o p -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/log_pmc_${NAME}_$i.txt 2>&1
+  timeout 180 rocprofv3 --pmc $g --kernel-trace --output-format csv -d /tmp/pk_$NAME/$i -o p -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency --no-configs "$@" > $OUT/log_pmc_${NAME}_$i.txt 2>&1
   i=$((i+1))
 done
 python3 - "$REGEX" /tmp/pk_$NAME $OUT/pmc_$NAME.txt <<'PY'

@@ -4,7 +4,7 @@ OUT=$1; shift
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf /tmp/rp_lds
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/rp_lds -o lds -- python3 bench.py --steps 2 --warmup 1 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/rp_lds -o lds -- python3 bench.py --steps 2 --warmup 1 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency --no-configs "$@" > $OUT.log 2>&1
 f=$(find /tmp/rp_lds -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY' > $OUT
 import csv, sys, collections, re

@@ -9,17 +9,17 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline "$@" > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline --no-configs "$@" > $OUT/stats.log 2>&1
 cp $(find /tmp/rp_$TAG/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 # the same kernels with ONE forward in flight (single chain): what bench.py's event pass measures; with three forwards in flight a launch
 # shares the chip and its duration in the summary above stretches (3x for the MFMA-bound VGG convs)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats1 -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline --inflight 1 --chains 1 "$@" > $OUT/stats1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG/stats1 -o stats -- python3 bench.py --no-cpu-baseline --no-latency --no-roofline --no-configs --inflight 1 --chains 1 "$@" > $OUT/stats1.log 2>&1
 cp $(find /tmp/rp_$TAG/stats1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_one_forward.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$TAG/pmc/$c -o $c -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rp_$TAG/pmc/$c -o $c -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency --no-configs "$@" > $OUT/pmc_$c.log 2>&1
 done
 PMC_CMD="bench.py --steps 3 --warmup 2 --eager --chains 1 $*" python3 tools/pmc_traffic.py /tmp/rp_$TAG/pmc $OUT/hbm_traffic.json
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/rp_$TAG/sq -o sq -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/rp_$TAG/sq -o sq -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency --no-configs "$@" > $OUT/pmc_sq.log 2>&1
 python3 tools/pmc_mfma.py /tmp/rp_$TAG/sq $OUT/mfma_util.json $OUT/kernel_stats_one_forward.csv
 rm -rf /tmp/rp_$TAG
 # the summaries of this build become the committed ones the bench line quotes

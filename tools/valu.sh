@@ -10,7 +10,7 @@ cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 rm -rf /tmp/valu_$NAME
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/valu_$NAME -o v -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency "$@" > $OUT/valu_$NAME.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/valu_$NAME -o v -- python3 bench.py --steps 3 --warmup 2 --eager --chains 1 --no-cpu-baseline --no-roofline --no-latency --no-configs "$@" > $OUT/valu_$NAME.log 2>&1
 python3 - <<PY
 import csv, glob, re
 acc = {}
