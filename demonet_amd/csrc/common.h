@@ -37,11 +37,13 @@ const char* dn_last_kernel();
 // ReLU / ReLU6 in ONE instruction each. fmaxf / fminf make hipcc quiet a possible signalling NaN first (`v_max_f32 v, v, v`) whenever the operand does
 // not come from an arithmetic instruction it knows -- MFMA results, inline-asm v_fma_mix_f32 sums -- i.e. two instructions per value in epilogues
 // that are bound by vector-instruction issue (round 3: 28 000 such pairs in the expdw object alone). Same values for every non-NaN input.
-// (round 6) ReLU is v_med3_f32(v, 0, +inf), a BUILTIN: until then it was an inline-asm `v_max_f32`, and an asm statement is opaque to hipcc's hazard
+// (round 6) ReLU is v_med3_f32(v, 0, FLT_MAX), a BUILTIN: until then it was an inline-asm `v_max_f32`, and an asm statement is opaque to hipcc's hazard
 // recognizer -- gfx950 has no interlock between a matrix instruction's result write and a vector instruction that reads it (software keeps passes + 4
 // wait states), so wherever the asm landed right behind an MFMA it could read stale accumulators (tools/mfma_hazard_scan.py; tests/test_isa_lint.py).
-// Same value as max(v, 0) for every non-NaN input, -0.0 included (both give +0.0).
-__device__ __forceinline__ float dn_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+// FLT_MAX, not +inf: med3(v, 0, inf) is folded into max(v, 0), and fmaxf on a value hipcc does not know to be canonical costs a second instruction
+// (`v_max_f32 v, v, v` first: the reason the asm existed). Same value as max(v, 0) for every finite input, -0.0 included (both give +0.0); +inf becomes
+// FLT_MAX, which the fp16 stores of every caller round back to +inf.
+__device__ __forceinline__ float dn_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 3.4028234663852886e38f); }
 __device__ __forceinline__ float dn_relu6(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
 
 __device__ __forceinline__ float dn_act(float v, int act) {

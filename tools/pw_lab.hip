@@ -23,7 +23,7 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_HSWISH = 3 };
-__device__ __forceinline__ float dn_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+__device__ __forceinline__ float dn_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 3.4028234663852886e38f); }
 __device__ __forceinline__ float dn_relu6(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
 __device__ __forceinline__ void act16(floatx16& v, int act) {
     if (act == ACT_RELU) {
