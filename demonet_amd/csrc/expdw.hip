@@ -227,6 +227,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
                 for (int ks = 0; ks < KSM; ++ks)
                     if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
+                asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc));      /* matrix result -> activation switch: every branch path gets its 12 wait states (pwdirect.hip act16) */
                 act_n<floatx16, 16>(acc, a.act1);
                 half_t* erow = &Es[(rt * 32 + r) * EW + t * 32 + 4 * hh];
 #pragma unroll
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(KSM <= 6 ? 4
                         for (int ks = 0; ks < KSM; ++ks)
                             if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf2[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast2, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
+                        asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc));
                         float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
                         act_n<float[4], 4>(v4, a.act1);
                         half4 hv;
@@ -578,7 +580,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int ks = 0; ks < KSM; ++ks)
                 if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
-            act_n<floatx16, 16>(acc, a.act1);
+            asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc));      /* matrix result -> activation switch: every branch path gets its 12 wait states (pwdirect.hip act16) */
+                act_n<floatx16, 16>(acc, a.act1);
             half_t* erow = &Es[(rt * 32 + r) * EW + t * 32 + 4 * hh];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -598,7 +601,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 for (int ks = 0; ks < KSM; ++ks)
                     if (ks < KSF) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf2[ks], *reinterpret_cast<const half8*>(xrow + ks * 16), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlast2, *reinterpret_cast<const half8*>(xrow + KSF * 16), acc, 0, 0, 0);
-                float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+                asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc));
+                        float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
                 act_n<float[4], 4>(v4, a.act1);
                 half4 hv;
 #pragma unroll

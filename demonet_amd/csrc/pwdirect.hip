@@ -29,6 +29,10 @@ namespace {
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void act16(floatx16& v, int act) {
+    // `v` comes straight from a matrix instruction and the first thing that happens to it is a scalar branch on `act`: hipcc's hazard recognizer gives the
+    // straight path its 12 wait states but undercounts some of the branch paths (5 - 7: tools/mfma_hazard_scan.py --all). Twelve explicit wait states in
+    // front of the switch cover every path (the matrix instruction runs under them; other waves issue meanwhile).
+    asm volatile("s_nop 7\n\ts_nop 3" : "+v"(v));       // (tied to the accumulator: otherwise hipcc schedules it in front of the last matrix instruction)
     if (act == DN_ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = dn_relu(v[e]);
