@@ -396,8 +396,7 @@ int launch_dw_group(const DwArgs* arr, int count, hipStream_t s) {
     }
     g.start[count] = acc;
     dn_note_kernel("dw_group_kernel<%d,%d,%d>", K, S, TW);
-    if (1) hipLaunchKernelGGL((dw_group_kernel<K, S, TW, 4>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((dw_group_kernel<K, S, TW>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((dw_group_kernel<K, S, TW, 4>), dim3(acc, arr[0].xq > 0 ? arr[0].xq : arr[0].n), dim3(256), 0, s, g);
     return DN_OK;
 }
 

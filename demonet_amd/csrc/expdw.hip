@@ -744,7 +744,7 @@ int launch_k(const ExpDwArgs& a, int tiles_x, int tiles_y, int zsplit, size_t ld
         // the wide variant (a last chunk of 72 channels taken whole) exists for the one shape that uses it: the whole expanded width IS that chunk
         // (24 -> 72 -> 24). As a tail of a longer chunk run (cexp = 136, 200 ... with cin <= 40) it was never dispatched by the model zoo and every
         // such instantiation spilled 36 - 76 B per lane at the 128-register cap: not instantiated any more.
-        if (a.cexp == EW && 1 && dn_knob("DN_EXPDW_ONE", 1)) return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, true>(a, tiles_x, tiles_y, zsplit, lds, s);
+        if (a.cexp == EW && dn_knob("DN_EXPDW_ONE", 1)) return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, true>(a, tiles_x, tiles_y, zsplit, lds, s);
     }
     return launch_kw<K, S, OH, OW, KSM, EXP, PROJ, XW8, false>(a, tiles_x, tiles_y, zsplit, lds, s);
 }
@@ -757,7 +757,7 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     constexpr int DROWS = (OH * OW + 31) / 32 * 32;
     const size_t lds0 = ((size_t)G::ROWS * a.xw + 8 + (exp ? (size_t)G::ROWS * EW : 0) + K * K * EW + (proj ? (size_t)DROWS * EW : 0)) * sizeof(half_t) +
                        (EW + NT / 64 * 64 + (proj ? 256 : 0)) * sizeof(float);
-    const size_t lds = std::min<size_t>(160 * 1024, lds0 + (size_t)0 * 1024);      // dev knob: reserve more (occupancy experiments)
+    const size_t lds = lds0;
     DN_REQUIRE(lds0 <= 160 * 1024, "expand+depthwise: LDS %zu B exceeds 160 KB", lds0);
     // split the 64-channel chunks over grid.y until there are enough workgroups to fill the chip a few times over
     // (not with a project stage: it sums over all chunks inside the workgroup)
@@ -773,7 +773,7 @@ int launch_t(const ExpDwArgs& a0, hipStream_t s) {
     if (proj) {
         // the output tile is staged over the E .. depthwise-output buffers (everything between the X rows and the project bias)
         const size_t avail = ((exp ? (size_t)G::ROWS * EW : 0) + K * K * EW + (size_t)DROWS * EW) * sizeof(half_t) + (EW + NT / 64 * 64) * sizeof(float);
-        a.stage_out = 1 && (size_t)OH * OW * a.cout * sizeof(half_t) <= avail && a.cout % 8 == 0 &&
+        a.stage_out = (size_t)OH * OW * a.cout * sizeof(half_t) <= avail && a.cout % 8 == 0 &&
                       fd_ok((unsigned long long)OH * OW * (a.cout >> 3), (unsigned)(a.cout >> 3));
         a.fd_oc8 = fastdiv((unsigned)(a.cout >> 3));
     }

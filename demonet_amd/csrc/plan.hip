@@ -241,8 +241,6 @@ static const Layout& get_layout(dn_plan* p, int n) {
                 if (born[t] >= 0) born[t] = std::min(born[t], when[i]);
             }
         const int t_end = NO + 2;
-        if (const int slack = 0)        // diagnostics: every block stays reserved `slack` launches beyond its last reader
-            for (size_t t = 0; t < T; ++t) if (dies[t] >= 0) dies[t] += slack;
         for (int l = 0; l < p->d.n_levels; ++l) dies[p->d.level_tensor[l]] = t_end;      // read back by tests / callers after the forward
         struct Blk { size_t off, bytes; int born, dies; };
         std::vector<Blk> placed;
@@ -371,13 +369,8 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
                 p->fused_len[i] = 2; p->fused_kind[i] = 8; i += 1;
                 continue;
             }
-            // the same pair through the LDS-tiled block kernel: correct but measured slower than the two
-            // launches (16 channels leave half of the workgroup idle in the depthwise stage) -- opt-in
-            const bool noexp = 0 != 0;
-            if (noexp && dw_ok(a) && p->tensors[a.in].kind == DN_T_ACT && expdw_supported(a.cin, a.cin, a.k, a.stride) && a.cin <= 32 &&
-                proj_ok(d, a, a.in)) {
-                p->fused_len[i] = 2; p->fused_kind[i] = 2; i += 1;
-            }
+            // (the same pair through the LDS-tiled block kernel was correct but slower than the two launches -- 16 channels leave half of the
+            //  workgroup idle in the depthwise stage -- and is not dispatched)
         }
     }
     // ---- dense 3x3 conv -> MaxPool2d(2, 2) pairs (VGG conv1_2 / conv2_2): one launch, fused_kind 4 (convbig.hip conv_patch_kernel)

@@ -952,7 +952,7 @@ int launch_select(const PwArgs& a, hipStream_t s) {
         // small dense convs (the extras of the VGG models: <= 16 x 16 maps, K = 9 cin up to 4608): a few workgroups walking 70 - 140
         // K stages, each an exposed memory round trip with the plain double buffer (60 - 130 us per layer for < 1 us of MFMA work):
         // request the stages 4 ahead through the register ring of the short-K pointwise variant
-        if (1 && a.cout > 32 && wgs(64, 64) < 512) return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
+        if (a.cout > 32 && wgs(64, 64) < 512) return launch_bk<64, 64, 2, 2, CONV, 32, 4>(a, s, 2);
     }
     if constexpr (!CONV) {
         // a 1x1 layer with few workgroups and a long K (the first extras layer: 480 -> 256 on 10 x 10) is a chain of exposed round trips with the plain
@@ -1027,7 +1027,7 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         if (arr[i].cout > maxc) maxc = arr[i].cout;
         wg128 += (long)dn_cdiv(arr[i].m, 128) * dn_cdiv(arr[i].cout, 128);
     }
-    if (maxc <= 32 && conv && wg128 < 256 && 1) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
+    if (maxc <= 32 && conv && wg128 < 256) return launch_group_cfg<128, 32, 4, 1, true, 32, 3>(arr, count, s);
     if (maxc <= 32) return conv ? launch_group_cfg<128, 32, 4, 1, true>(arr, count, s) : launch_group_cfg<128, 32, 4, 1, false>(arr, count, s);
     if (maxc <= 64) return conv ? launch_group_cfg<64, 64, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 64, 2, 2, false>(arr, count, s);
     if (wg128 >= 1500 && conv) {
@@ -1037,7 +1037,7 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
         for (int i = 0; i < count; ++i) all64 &= arr[i].cv_cin % 64 == 0;
         if (all64) return launch_group_cfg<128, 128, 2, 2, true, 64>(arr, count, s);
     }
-    if (wg128 >= 1500 && !conv && 1) {
+    if (wg128 >= 1500 && !conv) {
         // 96-wide channel tiles (a wave = 32 pixels x 96 channels) where they pad less: the 546 class channels of the SSDLite heads are
         // 6 x 96 = 576 columns instead of 5 x 128 = 640 -- the head launch is the longest full-chip launch of a forward (batch 64, three
         // forwards in flight: 0.789 -> 0.775 ms; 128 x 192 tiles 0.808, 64 x 192 level)
@@ -1050,13 +1050,13 @@ int launch_pointwise_group(const PwArgs* arr, int count, bool conv, hipStream_t 
     }
     if (wg128 >= 1500) return conv ? launch_group_cfg<128, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<128, 128, 2, 2, false>(arr, count, s);
     // the dense heads of the small levels (a few dozen workgroups, 72 - 144 K stages): latency-bound, stages requested 3 ahead
-    if (conv && wg128 < 256 && 1) return launch_group_cfg<64, 128, 2, 2, true, 32, 3>(arr, count, s);
+    if (conv && wg128 < 256) return launch_group_cfg<64, 128, 2, 2, true, 32, 3>(arr, count, s);
     return conv ? launch_group_cfg<64, 128, 2, 2, true>(arr, count, s) : launch_group_cfg<64, 128, 2, 2, false>(arr, count, s);
 }
 
 // the squeeze-excitation of a projection can be computed in the projection kernel's prologue (SEF variant of the 64 x 64 tile)
 bool pw_se_fold_supported(int cin, int cout, int squeeze, int hw) {
-    return dn_knob("DN_SE_FOLD", 1) != 0 && 1 != 0 && cin > 32 && cin <= 128 && cin % 8 == 0 && squeeze <= 32 && hw >= 64 &&
+    return dn_knob("DN_SE_FOLD", 1) != 0 && cin > 32 && cin <= 128 && cin % 8 == 0 && squeeze <= 32 && hw >= 64 &&
            (cin < 256 || cout < 128);
 }
 
@@ -1107,7 +1107,7 @@ int launch_conv(const ConvArgs& c, hipStream_t s) {
     a.cout = c.cout; a.act = c.act; a.out_fp32 = c.out_fp32; a.out_img_stride = c.out_img_stride; a.out_base = c.out_base;
     a.xq = c.xq;
     DN_REQUIRE(a.m > 0, "conv: empty problem");
-    if (c.k == 1 && c.stride == 1 && c.pad == 0 && !c.out_fp32 && 1) {
+    if (c.k == 1 && c.stride == 1 && c.pad == 0 && !c.out_fp32) {
         // a 1x1 dense conv IS a pointwise conv: unless it is big enough for the 256 x 256-tile kernel, the pointwise path serves it
         // (register-direct kernel up to cin = 256, 4-stage prefetch ring beyond; the implicit-GEMM body walks it one exposed stage at a time)
         const long wg256 = (long)dn_cdiv(a.m, 256) * dn_cdiv(a.cout, 256);

@@ -970,7 +970,7 @@ int launch_p2(const PostArgs& a, const float* scoresT, const float4* boxes, floa
     }
     const bool perm = !(a.lv.n == 1 && a.lv.aloc[0] == 1);
     // behind the cut-off pass (needFull given) only flagged images are worked on -- usually none: a small grid whose workgroups walk the images
-    const int islots = (needFull && 8 > 0) ? std::min(a.n, 8) : 0;
+    const int islots = needFull ? std::min(a.n, 8) : 0;
     if (perm) {
         DN_HIP_CHECK(dn_allow_big_lds(reinterpret_cast<const void*>(select_nms_kernel<NW, true>), 160 * 1024 - 64));      // (minus the kernel's static LDS: the ticket flag)
         hipLaunchKernelGGL((select_nms_kernel<NW, true>), dim3((a.K - 1) * (islots > 0 ? islots : xcd_image_slots(a.xq, a.n))), dim3(256), lds, s, scoresT, boxes, a.A, a.K - 1,
@@ -992,8 +992,7 @@ int launch_p2_fast(const PostArgs& a, const float* scoresT, const float4* boxes,
     const dim3 grid((a.K - 1) * xcd_image_slots(a.xq, a.n));
 #define DN_P2F(FT, PERM) hipLaunchKernelGGL((select_nms_fast_kernel<NW, FT, PERM>), grid, dim3(FT), 0, s, scoresT, boxes, a.A, a.K - 1, a.score_thresh, \
                                             a.nms_thresh, a.topk, tauKey, needFull, keptScore, keptAnchor, keptCount, g_pp_stamps, a.n, a.xq, a.lv, order)
-    if (512 == 256) { if (perm) DN_P2F(256, true); else DN_P2F(256, false); }
-    else { if (perm) DN_P2F(512, true); else DN_P2F(512, false); }
+    if (perm) DN_P2F(512, true); else DN_P2F(512, false);
 #undef DN_P2F
     return DN_OK;
 }
@@ -1131,17 +1130,14 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
         else if (nw <= 5) rc = launch_p2_fast<5>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         else rc = launch_p2_fast<8>(a, scoresT, boxes, tauKey, needFull, keptScore, keptAnchor, keptCount, ord, s);
         if (ev) (void)hipEventRecord(ev[2], s);
-        if (1024 == 256)
-            hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 0, a.n, a.xq);
-        else
-            hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 0, a.n, a.xq);
+        hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 0, a.n, a.xq);
     }
     else if (ev) (void)hipEventRecord(ev[2], s);
     if (ev) (void)hipEventRecord(ev[3], s);
     const int* flag = fast ? needFull : nullptr;
     // behind the cut-off pass: ONE launch redoes the flagged images (usually none) with the full kernel and merges each in the workgroup that
     // finishes its last class (DN_PP_FUSE_FALLBACK, default 1; 0: a second merge launch as in rounds 1 - 3)
-    const bool fuse_fb = fast && dn_knob("DN_PP_FUSE_FALLBACK", 1) && 8 > 0;
+    const bool fuse_fb = fast && dn_knob("DN_PP_FUSE_FALLBACK", 1) != 0;
     int* fb = fuse_fb ? fbcnt : nullptr;
     if (nw <= 1) rc = launch_p2<1>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
     else if (nw <= 2) rc = launch_p2<2>(a, scoresT, boxes, keptScore, keptAnchor, keptCount, flag, mg, fb, s);
@@ -1151,7 +1147,7 @@ int launch_postprocess(const PostArgs& a0, hipStream_t s, hipEvent_t* ev) {
     if (rc != DN_OK) return rc;
     if (!fuse_fb) {
         // the merge after the full pass: with the fast path on it only works for flagged images (usually none): 256 threads, scheduled at once
-        if (fast && 256 == 256)
+        if (fast)
             hipLaunchKernelGGL(merge_kernel<256>, dim3(slots), dim3(256), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, 1, a.n, a.xq);
         else
             hipLaunchKernelGGL(merge_kernel<1024>, dim3(slots), dim3(1024), 0, s, keptScore, keptAnchor, keptCount, boxes, a.A, (int)Km1, a.topk, mg, fast ? 1 : 2, a.n, a.xq);

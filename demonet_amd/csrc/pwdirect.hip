@@ -717,7 +717,7 @@ int launch_pw_dw_direct(const PwArgs& a, const DwArgs& d, hipStream_t s) {
 
 bool pw_direct_supported(const PwArgs& a) {
     // squeeze-excitation scaled inputs: only where a 32-row tile lies inside one image (the 40 x 40 maps) and the reduction is short
-    if (a.se && !(a.hw % 32 == 0 && a.cin <= 128 && 1)) return false;
+    if (a.se && !(a.hw % 32 == 0 && a.cin <= 128)) return false;
     return dn_knob("DN_PW_DIRECT", 1) != 0 && a.cv_k == 1 && !a.out_fp32 && !a.sef_part && !a.w_b && a.cin % 8 == 0 && a.cin >= 8 &&
            a.cin <= 256 && a.cout % 8 == 0 && a.cout >= 8 && !(a.act >> 8) && a.out_img_stride == 0 && a.out_base == 0;
 }
@@ -734,17 +734,12 @@ int launch_pw_direct(const PwArgs& a, hipStream_t s) {
     const int ksf = a.cin >> 4;
     // wide expansions with enough rows: the streaming variant (pw_stream_kernel) -- channel runs sized so that all waves are resident at once
     if (dn_knob("DN_PW_STREAM", 1) && !a.se && !a.residual && ksf >= 4 && ksf <= 8 && ctiles >= 12 && a.m >= 12800) {
-        const int px = 2 == 2 ? 2 : 1;      // 32-pixel tiles per wave
+        const int px = 2;                   // 32-pixel tiles per wave
         const long ptiles = dn_cdiv(a.m, 32 * px);
         int runs = (int)std::max(1L, std::min((long)ctiles, (long)2800 / ptiles));
         const int per = dn_cdiv(ctiles, runs);
         runs = dn_cdiv(ctiles, per);
         switch (ksf * 10 + px) {
-            case 41: return launch_stream_t<4, 1>(a, runs, per, s);
-            case 51: return launch_stream_t<5, 1>(a, runs, per, s);
-            case 61: return launch_stream_t<6, 1>(a, runs, per, s);
-            case 71: return launch_stream_t<7, 1>(a, runs, per, s);
-            case 81: return launch_stream_t<8, 1>(a, runs, per, s);
             case 42: return launch_stream_t<4, 2>(a, runs, per, s);
             case 52: return launch_stream_t<5, 2>(a, runs, per, s);
             case 62: return launch_stream_t<6, 2>(a, runs, per, s);
