@@ -17,7 +17,7 @@ SOURCES = ["plan.hip", "pointwise.hip", "depthwise.hip", "dense.hip", "postproce
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs, not AGPRs -- the small-tile kernels otherwise spend a v_accvgpr_read per
 # accumulator value on the way to their epilogues (not for convbig.hip: its 256 x 256 tiles need the AGPR half of the file)
 VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-EXTRA = {"postprocess.hip": ["-ffp-contract=off"], "pwdirect.hip": VGPR_MFMA, "pointwise.hip": VGPR_MFMA, "tail.hip": VGPR_MFMA}
+EXTRA = {"postprocess.hip": ["-ffp-contract=off"], "pwdirect.hip": VGPR_MFMA, "pointwise.hip": VGPR_MFMA, "tail.hip": VGPR_MFMA, "depthwise.hip": VGPR_MFMA}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
           "-fvisibility=hidden", "-fgpu-rdc" if False else "-fno-gpu-rdc"]

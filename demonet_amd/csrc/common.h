@@ -285,6 +285,7 @@ struct StemArgs {
     float mean[3], inv_std[3];
     int xq = 0;             // XCD grouping: images per group (0: plain mapping)
     unsigned* zero_u32 = nullptr; int zero_count = 0;      // optional: words the first workgroup clears (the chain's SE counters)
+    int split_ok = 0;       // weights and bias finite and below the fp16 range: the split-fp16 matrix kernel may run (plan.hip checks the host copy)
 };
 int launch_stem(const StemArgs& a, hipStream_t s);
 

@@ -966,9 +966,333 @@ __global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_
     }
 }
 
+// The same tiles, products and accumulation order as stem_mfma64_kernel (bit-identical output), scheduled as a pipeline inside the wave.
+// The kernel above runs request -> wait -> normalise -> 28 dependent-pair MFMAs -> epilogue -> stores strictly in sequence per tile, and its
+// costs ADD (ablations on the 512 x 512 batch, 16 images per launch: 236 us = vector work 49 + matrix chain ~95 + stores ~55 + taps ~45;
+// matrix pipe 0.35 busy). Here the wave's TPW tiles are straight-line code and every step t is ONE scheduling region that holds
+//   the taps of tile t + 2 (requests),  the MFMA chain of tile t,  bias / ReLU / fp16 / slab / stores of tile t - 1,  the wait for and the
+//   normalisation of tile t + 1
+// so that each memory round trip has a whole chain to complete in and the vector work of three tiles sits between one tile's MFMAs.
+// pad 1, ReLU and output predication by the buffer's range keep the step free of branches; border handling is a 6-bit mask test per tap
+// (borders the tap must not cross & borders the pixel touches); pixel coordinates advance by addition.
+// Requests, stores and waits are `asm volatile`: hipcc sinks a plain load to its first use (behind the chain it is meant to overlap), and
+// asm statements keep their order -- requests(t + 2), stores(t - 1), wait(t + 1) -- so the wait's count is known: loads and stores retire in
+// order, and younger than the taps of tile t + 1 are the stores of t - 2, the requests of t + 2 and the stores of t - 1 (tests/test_isa_lint.py
+// checks the compiled code: nothing touches a requested register before the wait that retires it).
+template <int TPW, int ABL = 0>
+__global__ __launch_bounds__(256) void stem_mfma64p_kernel(StemArgs a, int nblocks) {
+    if (a.zero_u32 && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.zero_count; i += 256) a.zero_u32[i] = 0u;
+    __shared__ __attribute__((aligned(16))) half_t slab[4][32 * 72];
+    __shared__ __attribute__((aligned(16))) float sbias[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    int n, bx;
+    if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, n, bx)) return;
+    if (threadIdx.x < 64) sbias[threadIdx.x] = a.bias[threadIdx.x];
+    const int HW = a.h * a.w_;                 // stride 1, pad 1: output and input pixel indices coincide
+    float wa[14][2];
+    int toff4[14];              // byte offset of the tap relative to the pixel's own position in plane 0
+    unsigned need[14];          // borders this tap must not cross: 1 top, 2 bottom, 4 left, 8 right; 16: the zero pad of K = 27 -> 28; 32: a pixel of the image
+    float tmean[14], tinv[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const int t = 2 * i + hh;
+        const int tc = min(t, 26);
+        const int c = tc / 9, ky = (tc - c * 9) / 3, kx = tc - c * 9 - ky * 3;
+        wa[i][0] = t < 27 ? a.w[tc * 64 + r] : 0.f;
+        wa[i][1] = t < 27 ? a.w[tc * 64 + 32 + r] : 0.f;
+        toff4[i] = 4 * (c * HW + (ky - 1) * a.w_ + (kx - 1));
+        need[i] = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u) | (t < 27 ? 0u : 16u) | 32u;
+        tmean[i] = a.mean[c];
+        tinv[i] = a.inv_std[c];
+    }
+    const __amdgpu_buffer_rsrc_t irs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.img + (size_t)n * 3 * HW), 0, 3 * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * HW * 64, 0, HW * 128, 0x00020000);
+    half_t* sl = slab[wave];
+    const int tile0 = (bx * 4 + wave) * TPW;
+    __syncthreads();            // sbias
+
+    // the next tile to request: pixel index (x 4: the byte offset in plane 0), coordinates
+    int pu4 = (tile0 * 32 + r) * 4;
+    int oy = (tile0 * 32 + r) / a.wo, ox = tile0 * 32 + r - oy * a.wo;
+    float raw[2][14];           // taps in flight: tile t + 2 into raw[t & 1] while raw[(t + 1) & 1] waits to be normalised
+    unsigned viol[2];           // borders the lane's pixel touches, per requested tile
+    float v[2][14];             // normalised taps: tile t in v[t & 1]
+    auto request = [&](const int b) {
+        viol[b] = (oy == 0 ? 1u : 0u) | (oy == a.h - 1 ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox == a.w_ - 1 ? 8u : 0u) | 16u |
+                  (oy >= a.h ? 32u : 0u);       // pixels beyond the image (last tiles): every tap "outside", nothing stored
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int off = (need[i] & viol[b]) == 0u ? pu4 + toff4[i] : (int)0x80000000;      // out of range: no access
+            if (ABL & 4) raw[b][i] = __builtin_bit_cast(float, off);
+            else asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw[b][i]) : "v"(off), "s"(irs) : "memory");
+        }
+        pu4 += 128;
+        ox += 32;
+        const bool wrap = ox >= a.wo;           // wo >= 32 (launcher): at most one row per step
+        ox -= wrap ? a.wo : 0;
+        oy += wrap ? 1 : 0;
+    };
+    // `younger`: vector-memory operations issued behind the requests of this buffer (they may stay in flight)
+    auto normalise = [&](const int b, float (&vd)[14], const int younger) {
+        float(&q)[14] = raw[b];
+#define DN_STEM_TIE "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]), "+v"(q[9]), \
+                    "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13])
+        switch (younger) {
+        case 22: asm volatile("s_waitcnt vmcnt(22)" : DN_STEM_TIE : : "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" : DN_STEM_TIE : : "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" : DN_STEM_TIE : : "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" : DN_STEM_TIE : : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" : DN_STEM_TIE : : "memory"); break;
+        }
+#undef DN_STEM_TIE
+#pragma unroll
+        for (int i = 0; i < 14; ++i) vd[i] = (need[i] & viol[b]) == 0u ? (q[i] - tmean[i]) * tinv[i] : 0.f;      // zero padding is applied to the NORMALISED image
+    };
+    // one quarter of a finished tile's epilogue: lane = pixel r, registers 4g..4g+3 = channels 32 j + 8 g + 4 hh .. +3
+    auto epi_quarter = [&](const floatx16& acc0, const floatx16& acc1, const int g) {
+        half4 h0, h1;
+        const float4 b0 = *reinterpret_cast<const float4*>(sbias + 8 * g + 4 * hh), b1 = *reinterpret_cast<const float4*>(sbias + 32 + 8 * g + 4 * hh);
+        const float t8[8] = {acc0[4 * g + 0] + b0.x, acc0[4 * g + 1] + b0.y, acc0[4 * g + 2] + b0.z, acc0[4 * g + 3] + b0.w,
+                             acc1[4 * g + 0] + b1.x, acc1[4 * g + 1] + b1.y, acc1[4 * g + 2] + b1.z, acc1[4 * g + 3] + b1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h0[e] = (half_t)dn_relu(t8[e]); h1[e] = (half_t)dn_relu(t8[4 + e]); }
+        *reinterpret_cast<half4*>(sl + r * 72 + 8 * g + 4 * hh) = h0;
+        *reinterpret_cast<half4*>(sl + r * 72 + 32 + 8 * g + 4 * hh) = h1;
+    };
+    auto epi_store = [&](const int tile) {      // the slab is private to the wave: its own LDS operations are ordered, no barrier
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = lane + 64 * u;              // 16-B chunk of the 32 x 128-B tile
+            const int row = ch >> 3, q = ch & 7;
+            typedef unsigned __attribute__((ext_vector_type(4))) u4;
+            const u4 val = *reinterpret_cast<const u4*>(sl + row * 72 + q * 8);
+            const int off = (ABL & 1) ? ((val.x == 0x12345678u ? 0 : 0x80000000) + u * 16) : (tile * 32 + row) * 128 + q * 16;
+            // (s_nop: a store of more than 8 bytes reads its data registers a cycle after it issues; hipcc keeps writers of those registers
+            //  away from the stores it knows, an asm statement is opaque to it)
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(val), "v"(off), "s"(ors) : "memory");       // rows beyond the image: out of range, dropped
+        }
+    };
+    floatx16 acc[2][2];
+    auto step = [&](const int tt) {
+        const int p = tt & 1;
+        floatx16 &c0 = acc[p][0], &c1 = acc[p][1];
+        if (tt + 2 < TPW) request(p);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            if (ABL & 2) { c0[i] += wa[i][0] * v[p][i]; c1[i] += wa[i][1] * v[p][i]; } else {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][0], v[p][i], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][1], v[p][i], c1, 0, 0, 0); }
+            if (tt > 0 && i >= 1 && i <= 10 && (i % 3) == 1) epi_quarter(acc[p ^ 1][0], acc[p ^ 1][1], (i - 1) / 3);
+            if (tt > 0 && i == 11) epi_store(tile0 + tt - 1);
+            if (tt + 1 < TPW && i == 12) normalise(p ^ 1, v[p ^ 1], (tt >= 2 ? 4 : 0) + (tt + 2 < TPW ? 14 : 0) + (tt >= 1 ? 4 : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);          // one scheduling region per step
+    };
+    request(0);
+    if (TPW > 1) request(1);
+    normalise(0, v[0], TPW > 1 ? 14 : 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) step(tt);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) epi_quarter(acc[(TPW - 1) & 1][0], acc[(TPW - 1) & 1][1], g);
+    epi_store(tile0 + TPW - 1);
+}
+
+// ---- 3x3 stem on the fp16 matrix cores with fp32-grade products: every operand as the sum of two fp16 numbers --------------------------
+// Measured (tools/mfma_valu_lab.hip, profiles/r06_lab_mfma_valu.txt): v_mfma_f32_32x32x2_f32 and vector instructions do NOT overlap on
+// a SIMD -- not inside a wave, not between waves (one matrix-only + one vector-only wave per SIMD take the SUM of their times; the fp32
+// matrix rate equals the packed-fp32 vector rate: the same multipliers) -- while the fp16 matrix instructions run in the shadow of vector work.
+// So the fp32 stems pay 1 792 matrix cycles per 32 pixels x 64 channels ON TOP of their vector work (stem_mfma64*_kernel), or 27 x COUT vector
+// multiply-adds per pixel (stem3s2_kernel). Here x = xh + xl and w = wh + wl with xh = fp16(x), xl = fp16(x - xh) (x - xh is exact in fp32; the
+// pair carries 22+ bits of x, the error of the sum is below 2^-23 |x| until xl goes subnormal, then below 3e-8 absolute), and
+//     w x  ~  wl xh + wh xl + wh xh      (the dropped wl xl is below 2^-22 |w x|)
+// as three v_mfma_f32_32x32x16_f16 per 16 taps, exact fp16 products, fp32 accumulation: the sum differs from the fp32 kernels' by a few units of
+// fp32 rounding, i.e. the fp16 output differs in the last place in < 0.1 % of the values (tests/test_gpu_model.py measures it). 12 x 32 matrix
+// cycles per 32 x 64 tile instead of 28 x 64, and they overlap with the vector work. The bias rides in a spare K slot (x = 1).
+// K slots: lane (pixel r = lane & 31, kg = lane >> 5) holds 16 of the 32: element e of the lane is tap 15 kg + e -- rows (channel, ky) 0..4 for
+// kg = 0, rows 5..8 + the bias slot + zero pads for kg = 1 -- so that the three kx taps of a row are ONE 12-byte request per lane (5 requests per
+// tile and lane instead of 14 four-byte ones: the texture-address path was 1/6 of the fp32 kernel's time).
+// Pipeline per wave: straight-line over TPW tiles; tile t + 1 is requested (asm: hipcc would sink the loads to their use) before tile t's
+// matrix work; the hand-written wait leaves the tile's own stores in flight (loads and stores retire in order; tests/test_isa_lint.py).
+template <int COUT, int S, int ACT, int TPW, int ABL = 0>
+__global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks) {
+    constexpr int MT = (COUT + 31) / 32;         // 32-channel tiles (16 channels: the upper half of the one tile is zero weights)
+    constexpr int SW = COUT + 8;                 // slab row stride (halves)
+    constexpr int NS = COUT / 16;                // 1 KB store instructions per 32-pixel tile
+    if (a.zero_u32 && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.zero_count; i += 256) a.zero_u32[i] = 0u;
+    __shared__ __attribute__((aligned(16))) half_t slab[4][32 * SW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kg = lane >> 5;
+    int n, bx;
+    if (!xcd_image_of(blockIdx.x, nblocks, a.xq, a.n, n, bx)) return;
+    const int HW = a.h * a.w_, OHW = a.ho * a.wo;
+    // weights: A fragments (channel r of tile mt, this lane's 16 K slots), split
+    half8 ah[MT][2], al[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ch = 32 * mt + r;
+            const int tap = 15 * kg + e;
+            const bool is_tap = kg ? e < 12 : e < 15, is_bias = kg && e == 12;
+            float wv = 0.f;
+            if (ch < COUT) wv = is_tap ? a.w[min(tap, 26) * COUT + ch] : is_bias ? a.bias[ch] : 0.f;
+            const half_t h = (half_t)wv;
+            ah[mt][e >> 3][e & 7] = h;
+            al[mt][e >> 3][e & 7] = (half_t)(wv - (float)h);
+        }
+    // the lane's five rows q (row = 5 kg + q = channel * 3 + ky; row 9 does not exist): byte offset of the row's kx = 0 tap relative to the
+    // pixel's centre tap position in plane 0, ky, normalisation constants
+    int rowoff4[5], kyq[5];
+    float qmean[5], qinv[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int row = min(5 * kg + q, 8);
+        const int c = row / 3, ky = row - 3 * c;
+        rowoff4[q] = 4 * (c * HW + (ky - 1) * a.w_ - 1);
+        kyq[q] = 5 * kg + q < 9 ? ky - 1 : (1 << 20);          // the missing row is always "outside"
+        qmean[q] = a.mean[c];
+        qinv[q] = a.inv_std[c];
+    }
+    const __amdgpu_buffer_rsrc_t irs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.img + (size_t)n * 3 * HW), 0, 3 * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * OHW * COUT, 0, OHW * COUT * 2, 0x00020000);
+    half_t* sl = slab[wave];
+    const int tile0 = (bx * 4 + wave) * TPW;
+    typedef float f3 __attribute__((ext_vector_type(3)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+    // the next tile to request: this lane's output pixel
+    int oy = (tile0 * 32 + r) / a.wo, ox = tile0 * 32 + r - oy * a.wo;
+    f3 raw[5];
+    int noy, nox;               // the pixel of the tile in `raw`
+    auto request = [&]() {
+        noy = oy; nox = ox;
+        const int base4 = 4 * S * (oy * a.w_ + ox);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int iy = S * oy + kyq[q];
+            int off = ((unsigned)iy < (unsigned)a.h && oy < a.ho) ? base4 + rowoff4[q] : (int)0x80000000;      // out of range: no access, zeros
+            // image row 0 of plane 0 at ox = 0 (q = 0 with ky = 0, or q = 1 with ky = 1, of the kg = 0 lanes): the kx = 0 tap would sit 4 bytes in
+            // front of the buffer, and a negative offset takes the WHOLE request out of range (measured: columns 0 and 1 came back as zeros):
+            // lanes at ox = 0 ask for columns 0..2 instead and shift (normalise_split)
+            if (q <= 1) off += ox == 0 ? 4 : 0;
+            if (ABL & 4) { raw[q].x = __builtin_bit_cast(float, off); raw[q].y = raw[q].x; raw[q].z = raw[q].x; }
+            else asm volatile("buffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(raw[q]) : "v"(off), "s"(irs) : "memory");
+        }
+        ox += 32;
+        const bool wrap = ox >= a.wo;           // wo >= 32 (launcher): at most one row per step
+        ox -= wrap ? a.wo : 0;
+        oy += wrap ? 1 : 0;
+    };
+    half8 xh[2], xl[2];
+    auto normalise_split = [&](const bool stores_behind) {
+        if (stores_behind && NS == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
+        else if (stores_behind && NS == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
+        else if (stores_behind && NS == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
+        const bool left = nox > 0, right = S * nox + 1 < a.w_;
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const bool yok = (unsigned)(S * noy + kyq[q]) < (unsigned)a.h && noy < a.ho;
+            // zero padding is applied to the NORMALISED image (transform, then conv)
+            const float r1 = (q <= 1 && !left) ? raw[q].x : raw[q].y, r2 = (q <= 1 && !left) ? raw[q].y : raw[q].z;
+            const float n0 = (raw[q].x - qmean[q]) * qinv[q], n1 = (r1 - qmean[q]) * qinv[q], n2 = (r2 - qmean[q]) * qinv[q];
+            x[3 * q + 0] = (yok && left) ? n0 : 0.f;
+            x[3 * q + 1] = yok ? n1 : 0.f;
+            x[3 * q + 2] = (yok && right) ? n2 : 0.f;
+        }
+        x[15] = 0.f;
+        x[12] = kg ? 1.0f : x[12];              // the bias slot
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const half_t h = (half_t)x[e];
+            xh[e >> 3][e & 7] = h;
+            xl[e >> 3][e & 7] = (half_t)(x[e] - (float)h);
+        }
+    };
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        if (tt == 0) request();
+        normalise_split(tt > 0);
+        if (tt + 1 < TPW) request();
+        __builtin_amdgcn_sched_barrier(0);          // the requests stay in front of the work they overlap with
+        floatx16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+            if (!(ABL & 2)) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt][k], xh[k], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt][k], xl[k], acc[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt][k], xh[k], acc[mt], 0, 0, 0);
+            } else { acc[mt][0] = (float)xh[0][0] + (float)xl[1][3]; acc[mt][5] = (float)xh[1][2]; }
+        }
+        // lane = pixel r, registers 4g..4g+3 of tile mt = channels 32 mt + 8 g + 4 kg .. +3
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < (COUT >= 32 ? 4 : 2); ++g) {
+                float t4[4] = {acc[mt][4 * g + 0], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                dn_act_n<float[4], 4>(t4, ACT);
+                half4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)t4[e];
+                *reinterpret_cast<half4*>(sl + r * SW + 32 * mt + 8 * g + 4 * kg) = hv;
+            }
+        // the slab is private to the wave: its own LDS operations are ordered, no barrier
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int ch = lane + 64 * u;                   // 16-B chunk of the 32 x (2 COUT)-byte tile
+            const int row = ch / (COUT / 8), q = ch % (COUT / 8);
+            const u4 val = *reinterpret_cast<const u4*>(sl + row * SW + q * 8);
+            const int off = (ABL & 1) ? (int)0x80000000 : ((tile0 + tt) * 32 + row) * (COUT * 2) + q * 16;
+            // (s_nop: a store of more than 8 bytes reads its data registers a cycle after it issues; hipcc keeps writers of those registers
+            //  away from the stores it knows, an asm statement is opaque to it)
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(val), "v"(off), "s"(ors) : "memory");       // rows beyond the image: out of range, dropped
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int COUT, int K>
 int launch_stem_t(const StemArgs& a, hipStream_t s) {
     const int images = a.xq > 0 ? 8 * a.xq : a.n;      // image slots of the launch (XCD grouping: 8 groups of xq)
+    if (K == 3 && a.pad == 1 && a.split_ok && dn_knob("DN_STEM_SPLIT", 1) && a.wo >= 32 && (long)3 * a.h * a.w_ < (1L << 28) &&
+        (long)a.ho * a.wo * COUT < (1L << 29)) {
+        constexpr int TPW = 8;
+        const int tiles = dn_cdiv((long)a.ho * a.wo, 32);
+        const int nblocks = dn_cdiv(tiles, 4 * TPW);
+        const dim3 grid(nblocks * images);
+        const int abl = dn_knob("DN_STEM_ABL", 0);
+#define DN_STEM_SPLIT_CASE(C, S_, ACT_)                                                                                                    \
+        if (COUT == C && a.stride == S_ && a.act == ACT_ && (S_ == 1 ? (a.ho == a.h && a.wo == a.w_) : ((a.w_ & 1) == 0 && 2 * a.wo == a.w_ && a.ho == (a.h + 1) / 2))) { \
+            dn_note_kernel("stem_split_kernel<%d,%d>", C, S_);                                                                             \
+            if (abl == 1) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 1>), grid, dim3(256), 0, s, a, nblocks);                 \
+            else if (abl == 2) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 2>), grid, dim3(256), 0, s, a, nblocks);            \
+            else if (abl == 3) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 3>), grid, dim3(256), 0, s, a, nblocks);            \
+            else if (abl == 4) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 4>), grid, dim3(256), 0, s, a, nblocks);            \
+            else if (abl == 7) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 7>), grid, dim3(256), 0, s, a, nblocks);            \
+            else hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW>), grid, dim3(256), 0, s, a, nblocks);                             \
+            return DN_OK;                                                                                                                  \
+        }
+        DN_STEM_SPLIT_CASE(64, 1, DN_ACT_RELU)
+        DN_STEM_SPLIT_CASE(16, 2, DN_ACT_HSWISH)
+        DN_STEM_SPLIT_CASE(32, 2, DN_ACT_RELU6)
+#undef DN_STEM_SPLIT_CASE
+    }
     if (K == 3 && a.stride == 2 && a.pad == 1 && (a.w_ & 1) == 0 && 2 * a.wo == a.w_) {
         dn_note_kernel("stem3s2_kernel<%d>", COUT);
         const int nblocks = dn_cdiv((long)a.ho * a.wo, 256);
@@ -978,6 +1302,21 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
     const int mf = dn_knob("DN_STEM_MFMA", 1);
     if (mf && K == 3 && COUT == 64 && a.stride == 1 && (long)3 * a.h * a.w_ < (1L << 30)) {
         const int tiles = dn_cdiv((long)a.ho * a.wo, 32), per_wave = 8;
+        if (dn_knob("DN_STEM_PIPE", 1) && a.pad == 1 && a.act == DN_ACT_RELU && a.ho == a.h && a.wo == a.w_ && a.wo >= 32 && (long)a.h * a.w_ < (1L << 24)) {
+            dn_note_kernel("stem_mfma64p_kernel");
+            const int nblocks = dn_cdiv(tiles, 4 * per_wave);
+            switch (dn_knob("DN_STEM_ABL", 0)) {
+            case 1: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 1>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
+            case 2: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 2>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
+            case 3: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 3>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
+            case 4: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 4>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
+            case 5: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 5>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
+            case 6: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 6>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
+            case 7: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 7>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
+            default: hipLaunchKernelGGL((stem_mfma64p_kernel<8>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks);
+            }
+            return DN_OK;
+        }
         dn_note_kernel("stem_mfma64_kernel");
         const int nblocks = dn_cdiv(tiles, 4 * per_wave);
         hipLaunchKernelGGL(stem_mfma64_kernel, dim3(nblocks * images), dim3(256), 0, s, a, tiles, per_wave, nblocks);

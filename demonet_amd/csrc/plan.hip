@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -124,6 +125,7 @@ struct dn_plan {
     int n_se_in_dw = 0;                     // such pairs; slot q of the counter block belongs to the q-th
     std::vector<int> se_slot;               // per op (DW op of a pair): q
     int post_ticket_slot = -1;              // slot of the counter block lent to launch_postprocess (PostArgs::tickets); needs the stem launch that zeroes the block
+    std::vector<char> stem_split_ok;        // per op: STEM op whose weights and bias fit fp16's range (dn_create checks the host copy)
     std::vector<int> se_fold;               // per op: PW op -> index of the SE op whose FCs run in its prologue (pointwise.hip SEF), SE op -> -2, else -1
     std::vector<char> tail_materialise;     // per op of the run: its output is read outside the run (pyramid feature) -> also to HBM            // optional extra output of the merge kernel (dn_set_packed_output)
     // inverted-residual stages that run as one launch (expdw.hip): at the first op of a group, fused_len = number of ops and
@@ -399,6 +401,18 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     }
     // ---- small squeeze-excitations (c <= 128, squeeze <= 32: the 40 x 40 blocks of MobileNetV3) are computed in the prologue of the
     //      projection that consumes them: one dependent launch (~10 us of pure latency) less per block
+    // ---- stems: the split-fp16 matrix kernel (depthwise.hip stem_split_kernel) needs weights and bias that fp16 can hold (finite, |v| < 6e4)
+    p->stem_split_ok.assign(desc->n_ops, 0);
+    for (int i = 0; i < desc->n_ops; ++i) {
+        const dn_op_desc& so = p->ops[i];
+        if (so.type != DN_OP_STEM) continue;
+        const float* hw = reinterpret_cast<const float*>(static_cast<const unsigned char*>(weights) + so.w_off);
+        const float* hb = reinterpret_cast<const float*>(static_cast<const unsigned char*>(weights) + so.b_off);
+        bool ok = true;
+        for (int q = 0; q < so.k * so.k * 3 * so.cout; ++q) ok = ok && std::fabs(hw[q]) < 6.0e4f;      // (false for NaN too)
+        for (int q = 0; q < so.cout; ++q) ok = ok && std::fabs(hb[q]) < 6.0e4f;
+        p->stem_split_ok[i] = ok ? 1 : 0;
+    }
     p->se_fold.assign(desc->n_ops, -1);
     for (int i = 0; i + 1 < desc->n_ops; ++i) {
         const dn_op_desc& so = p->ops[i];
@@ -1104,6 +1118,7 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 a.ho = to.h; a.wo = to.w;
                 for (int c = 0; c < 3; ++c) { a.mean[c] = d.mean[c]; a.inv_std[c] = 1.0f / d.std[c]; }
                 a.xq = xq;
+                a.split_ok = p->stem_split_ok[i];
                 if (p->n_se_in_dw > 0) { a.zero_u32 = reinterpret_cast<unsigned*>(ws + L.secnt_off); a.zero_count = p->n_se_in_dw * n; }
                 rc = launch_stem(a, s);
                 break;

@@ -214,6 +214,68 @@ def test_weights_resident_patch_kernel_is_bit_identical_to_the_streamed_one(name
     assert torch.equal(res["0"][1], res["1"][1])
 
 
+@pytest.mark.parametrize("name,n,size", [("ssd300_vgg16", 5, 300), ("ssd512_vgg16", 3, 512), ("ssd300_vgg16", 33, 300)])
+def test_pipelined_stem_is_bit_identical_to_the_sequential_one(name, n, size, monkeypatch):
+    """Round 6 (DN_STEM_PIPE, default 1): conv1_1 of the VGG models (3 -> 64 on the full-size image, ssd_vgg16.py:33 via torchvision vgg16
+    features[0], behind the transform's normalisation) on stem_mfma64p_kernel -- the same 32-pixel tiles, fp32 products and accumulation order as
+    stem_mfma64_kernel with the next tile's taps requested ahead and the previous tile's epilogue in the shadow of the MFMA chain. Head outputs
+    equal bit for bit; 300 x 300 is ragged (2812.5 tiles per image: the last workgroup's tiles run off the image, rows wrap inside a tile)."""
+    imgs = torch.from_numpy(synth.images(61, n, size, size)).cuda()
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_STEM_PIPE", flag)
+        m = _model(name, num_classes=91)
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        again = m.forward_heads(imgs)
+        assert torch.equal(res[flag][0], again[0]) and torch.equal(res[flag][1], again[1])
+    assert torch.equal(res["0"][0], res["1"][0]), (res["0"][0] - res["1"][0]).abs().max().item()
+    assert torch.equal(res["0"][1], res["1"][1])
+
+
+@pytest.mark.parametrize("name,n,size", [("ssdlite320_mobilenet_v3_large", 3, 320), ("ssd_lite_mobilenet_v2", 3, 300), ("ssd300_vgg16", 3, 300),
+                                         ("ssd512_vgg16", 2, 512), ("ssdlite320_mobilenet_v3_large", 9, 320)])
+def test_split_fp16_stem_is_within_an_fp16_ulp_of_the_fp32_stem(name, n, size, monkeypatch):
+    """Round 6 (DN_STEM_SPLIT, default 1): the first conv (3 input channels on the full-size image behind the transform's normalisation:
+    mobilenetv3.py / mobilenetv2.py features[0], ssd_vgg16.py:33) on stem_split_kernel -- every operand as the sum of two fp16 numbers, three fp16
+    matrix products with fp32 accumulation -- instead of exact fp32 products (stem3s2_kernel / stem_mfma64p_kernel). The sums differ by fp32
+    rounding noise (~1e-7 relative; ~1e-7 absolute once an operand's low half is subnormal), so the fp16 OUTPUT may differ in the last place where
+    the sum sits on a rounding boundary: never by more than one unit in fp16's normal range (by < 5e-7 absolute below it), in well under 1 % of the values; the head outputs move by far less than the tolerance against the CPU path (1e-3 at
+    reference-scale logits). Image borders, the left-edge shift of row 0 and ragged tiles (300 x 300 -> 150 x 150, 22 500 / 32 tiles) included."""
+    kw = {"image_size": size} if name == "ssd_lite_mobilenet_v2" else {}
+    imgs = torch.from_numpy(synth.images(67, n, size, size)).cuda()
+    monkeypatch.setenv("DN_WS_REUSE", "0")
+    res, stem = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DN_STEM_SPLIT", flag)
+        m = _model(name, num_classes=91, **kw)
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+        tid = next(nd.out for nd in m.graph.nodes if nd.op == "stem")
+        stem[flag] = m.tensor(imgs.shape, tid)
+        again = m.forward_heads(imgs)
+        assert torch.equal(res[flag][0], again[0]) and torch.equal(res[flag][1], again[1])
+    a, b = stem["0"], stem["1"]
+    assert torch.isfinite(b.float()).all()
+    # distance in fp16 units in the last place: the bit patterns of same-sign fp16 numbers are ordered like the numbers
+    ia, ib = a.view(torch.int16).int(), b.view(torch.int16).int()
+    same_sign = (ia >= 0) == (ib >= 0)
+    d = (ia - ib).abs()
+    d = torch.where(same_sign, d, (ia & 0x7FFF) + (ib & 0x7FFF))        # (+0 / -0 or a sign change across zero)
+    frac = (d > 0).float().mean().item()
+    print("stem outputs differing in the last place: %.4f %%, max distance %d" % (100 * frac, int(d.max())))
+    # fp16's normal range: at most one unit; below it (|y| < 2^-14, units of 6e-8) the sums' absolute difference, ~1e-7, is several units
+    normal = a.float().abs() >= 2.0 ** -14
+    tiny_abs = (a.float() - b.float()).abs()[~normal]
+    assert int(d[normal].max()) <= 1 and frac < 0.01
+    assert tiny_abs.numel() == 0 or tiny_abs.max().item() <= 5e-7
+    # borders: first / last rows and columns are as close as the interior
+    for sl, nm in ((d[:, 0], normal[:, 0]), (d[:, -1], normal[:, -1]), (d[:, :, 0], normal[:, :, 0]), (d[:, :, -1], normal[:, :, -1])):
+        assert int(sl[nm].max()) <= 1
+    dl = (res["0"][0] - res["1"][0]).abs().max().item()
+    dr = (res["0"][1] - res["1"][1]).abs().max().item()
+    print("head outputs: max |d logits| %.3g  max |d regression| %.3g (logit scale %.3g)" % (dl, dr, res["0"][0].abs().max().item()))
+    assert dl <= 2e-3 * max(1.0, res["0"][0].abs().max().item()) and dr <= 2e-3 * max(1.0, res["0"][1].abs().max().item())
+
+
 def test_model_heads_match_golden(golden_dir):
     z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
     m = _model("ssdlite320_mobilenet_v3_large", z)

@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 _ASM_CACHE = {}
 # the flags demonet_amd/build.py compiles each file with (the hazard scan must see the code that ships)
 _BUILD_EXTRA = {"pwdirect.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"), "pointwise.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"),
-                "tail.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"), "postprocess.hip": ("-ffp-contract=off",)}
+                "tail.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"), "depthwise.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form=1"), "postprocess.hip": ("-ffp-contract=off",)}
 
 
 def _asm_cmd(src, out, extra=()):
@@ -42,7 +42,8 @@ def _asm(src, tmp_path, extra=()):
 def _kernels(text):
     """name -> (body lines, metadata dict) for every kernel of a device .s file"""
     res = {}
-    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+    # (up to the function-end label: a kernel with an early exit has an s_endpgm in the middle)
+    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n(.*?)\n\.Lfunc_end\d+:", text, re.S | re.M):
         res[m.group(1)] = m.group(2).split("\n")
     meta = {}
     for m in re.finditer(r"\.amdhsa_kernel (\w+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
@@ -103,6 +104,30 @@ def _lint_asm_loads(lines, name):
             pending.append([ln, _regs(ops[0]), False])
             checked += 1
             continue
+        if in_asm and op.startswith(("global_store_dword", "buffer_store_dword")):
+            # an asm-issued store counts in vmcnt like a load (stem_*_kernel: "the tile's own stores stay in flight"); it has no destination,
+            # but a store of more than 8 bytes reads its data registers a cycle after it issues: hipcc keeps writers of those registers two
+            # wait states away from the stores it knows -- for an asm statement the statement itself must (s_nop 1 behind the store)
+            pending.append([ln, set(), False])
+            if op.endswith(("x3", "x4")):
+                data = _regs(ops[0])
+                after, j = [], ln + 1
+                while len(after) < 2 and j < len(lines):
+                    o2, p2 = _operands(lines[j])
+                    if o2 is not None:
+                        after.append((o2, p2))
+                    j += 1
+                states = 0
+                for o2, p2 in after:
+                    if o2 == "s_nop":
+                        states += int(p2[0]) + 1
+                        continue
+                    if states >= 2:
+                        break
+                    written = _regs(p2[0]) if p2 and not o2.startswith(("s_", "buffer_store", "global_store", "ds_write")) else set()
+                    assert not (written & data), f"{name}: `{lines[j - 1].strip()}` writes the data registers of the asm-issued `{raw.strip()}` (line {ln}) inside its read window"
+                    states += 1
+            continue
         if in_asm and op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", raw)
             if m:
@@ -115,13 +140,28 @@ def _lint_asm_loads(lines, name):
             # a compiler-issued vector-memory operation inside a straight-line run of asm loads and their wait shifts the hand-made count
             if not in_asm and op.startswith(VMEM) and not all(q[2] for q in pending):
                 raise AssertionError(f"{name}: compiler-issued `{op}` (line {ln}) between asm-issued loads and their hand-counted wait")
-    left = [q for q in pending if not q[2]]
+    left = [q for q in pending if not q[2] and q[1]]          # (stores need no wait: the end of the kernel retires them)
     assert not left, f"{name}: {len(left)} asm-issued loads never waited for"
     return checked
 
 
+def test_hand_scheduled_requests_and_stores_of_the_stem_kernels(tmp_path):
+    """stem_split_kernel / stem_mfma64p_kernel (depthwise.hip): the taps of the next tile(s) are requested by asm statements ahead of the matrix
+    work, the tile's stores are asm statements too (a compiler-issued store between requests and wait would shift the count), and the wait is
+    `vmcnt(stores issued behind the requests)`. In the compiled code: nothing touches a requested register before the wait that retires it,
+    every request is waited for, no writer of a 16-byte store's data registers inside the store's read window, no scratch."""
+    text = _asm("depthwise.hip", tmp_path, _BUILD_EXTRA["depthwise.hip"])
+    kernels, meta = _kernels(text)
+    stems = {k: v for k, v in kernels.items() if ("stem_split_kernel" in k or "stem_mfma64p_kernel" in k) and k.endswith("Li0EEEv8StemArgsi")}
+    assert len(stems) >= 4, [k for k in kernels if "stem" in k]
+    for name, lines in stems.items():
+        n = _lint_asm_loads(lines, name)
+        assert n >= 40, (name, n)                  # 5 requests per tile x 8 tiles (14 x 8 for the fp32 kernel)
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta[name]), f"{name}: scratch in a kernel with hand-counted waits"
+
+
 def test_hand_scheduled_loads_of_se_fc8_are_not_touched_before_their_wait(tmp_path):
-    text = _asm("depthwise.hip", tmp_path)
+    text = _asm("depthwise.hip", tmp_path, _BUILD_EXTRA["depthwise.hip"])
     kernels, meta = _kernels(text)
     se = {k: v for k, v in kernels.items() if "se_fc8_kernel" in k}
     assert len(se) >= 2, list(kernels)[:5]
