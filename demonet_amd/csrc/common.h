@@ -285,7 +285,8 @@ struct StemArgs {
     float mean[3], inv_std[3];
     int xq = 0;             // XCD grouping: images per group (0: plain mapping)
     unsigned* zero_u32 = nullptr; int zero_count = 0;      // optional: words the first workgroup clears (the chain's SE counters)
-    int split_ok = 0;       // weights and bias finite and below the fp16 range: the split-fp16 matrix kernel may run (plan.hip checks the host copy)
+    int split_ok = 0;       // weights, bias and the normalised input range are finite and fit the split-fp16 matrix kernel (plan.hip checks the host copy)
+    float w_scale = 1.f, w_unscale = 1.f;      // 2^s and 2^-s: the split kernel's weights / bias are scaled so that the largest magnitude is in [2^13, 2^15)
 };
 int launch_stem(const StemArgs& a, hipStream_t s);
 

@@ -979,7 +979,7 @@ __global__ __launch_bounds__(256) void stem_mfma64_kernel(StemArgs a, int tiles_
 // asm statements keep their order -- requests(t + 2), stores(t - 1), wait(t + 1) -- so the wait's count is known: loads and stores retire in
 // order, and younger than the taps of tile t + 1 are the stores of t - 2, the requests of t + 2 and the stores of t - 1 (tests/test_isa_lint.py
 // checks the compiled code: nothing touches a requested register before the wait that retires it).
-template <int TPW, int ABL = 0>
+template <int TPW>
 __global__ __launch_bounds__(256) void stem_mfma64p_kernel(StemArgs a, int nblocks) {
     if (a.zero_u32 && blockIdx.x == 0)
         for (int i = threadIdx.x; i < a.zero_count; i += 256) a.zero_u32[i] = 0u;
@@ -1026,8 +1026,7 @@ __global__ __launch_bounds__(256) void stem_mfma64p_kernel(StemArgs a, int nbloc
 #pragma unroll
         for (int i = 0; i < 14; ++i) {
             const int off = (need[i] & viol[b]) == 0u ? pu4 + toff4[i] : (int)0x80000000;      // out of range: no access
-            if (ABL & 4) raw[b][i] = __builtin_bit_cast(float, off);
-            else asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw[b][i]) : "v"(off), "s"(irs) : "memory");
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw[b][i]) : "v"(off), "s"(irs) : "memory");
         }
         pu4 += 128;
         ox += 32;
@@ -1069,7 +1068,7 @@ __global__ __launch_bounds__(256) void stem_mfma64p_kernel(StemArgs a, int nbloc
             const int row = ch >> 3, q = ch & 7;
             typedef unsigned __attribute__((ext_vector_type(4))) u4;
             const u4 val = *reinterpret_cast<const u4*>(sl + row * 72 + q * 8);
-            const int off = (ABL & 1) ? ((val.x == 0x12345678u ? 0 : 0x80000000) + u * 16) : (tile * 32 + row) * 128 + q * 16;
+            const int off = (tile * 32 + row) * 128 + q * 16;
             // (s_nop: a store of more than 8 bytes reads its data registers a cycle after it issues; hipcc keeps writers of those registers
             //  away from the stores it knows, an asm statement is opaque to it)
             asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(val), "v"(off), "s"(ors) : "memory");       // rows beyond the image: out of range, dropped
@@ -1084,9 +1083,8 @@ __global__ __launch_bounds__(256) void stem_mfma64p_kernel(StemArgs a, int nbloc
         for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; }
 #pragma unroll
         for (int i = 0; i < 14; ++i) {
-            if (ABL & 2) { c0[i] += wa[i][0] * v[p][i]; c1[i] += wa[i][1] * v[p][i]; } else {
             c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][0], v[p][i], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][1], v[p][i], c1, 0, 0, 0); }
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][1], v[p][i], c1, 0, 0, 0);
             if (tt > 0 && i >= 1 && i <= 10 && (i % 3) == 1) epi_quarter(acc[p ^ 1][0], acc[p ^ 1][1], (i - 1) / 3);
             if (tt > 0 && i == 11) epi_store(tile0 + tt - 1);
             if (tt + 1 < TPW && i == 12) normalise(p ^ 1, v[p ^ 1], (tt >= 2 ? 4 : 0) + (tt + 2 < TPW ? 14 : 0) + (tt >= 1 ? 4 : 0));
@@ -1113,18 +1111,31 @@ __global__ __launch_bounds__(256) void stem_mfma64p_kernel(StemArgs a, int nbloc
 // pair carries 22+ bits of x, the error of the sum is below 2^-23 |x| until xl goes subnormal, then below 3e-8 absolute), and
 //     w x  ~  wl xh + wh xl + wh xh      (the dropped wl xl is below 2^-22 |w x|)
 // as three v_mfma_f32_32x32x16_f16 per 16 taps, exact fp16 products, fp32 accumulation: the sum differs from the fp32 kernels' by a few units of
-// fp32 rounding, i.e. the fp16 output differs in the last place in < 0.1 % of the values (tests/test_gpu_model.py measures it). 12 x 32 matrix
+// fp32 rounding, i.e. the fp16 output differs in the last place in ~0.1 % of the values (tests/test_gpu_model.py measures it). 12 x 32 matrix
 // cycles per 32 x 64 tile instead of 28 x 64, and they overlap with the vector work. The bias rides in a spare K slot (x = 1).
-// K slots: lane (pixel r = lane & 31, kg = lane >> 5) holds 16 of the 32: element e of the lane is tap 15 kg + e -- rows (channel, ky) 0..4 for
-// kg = 0, rows 5..8 + the bias slot + zero pads for kg = 1 -- so that the three kx taps of a row are ONE 12-byte request per lane (5 requests per
-// tile and lane instead of 14 four-byte ones: the texture-address path was 1/6 of the fp32 kernel's time).
-// Pipeline per wave: straight-line over TPW tiles; tile t + 1 is requested (asm: hipcc would sink the loads to their use) before tile t's
-// matrix work; the hand-written wait leaves the tile's own stores in flight (loads and stores retire in order; tests/test_isa_lint.py).
-template <int COUT, int S, int ACT, int TPW, int ABL = 0>
+// Weights and bias are scaled by a power of two (StemArgs::w_scale, chosen by the plan from their largest magnitude; the sums are scaled back
+// in the epilogue): small weights -- 0.003 on average in the VGG stem, against inputs up to 130 -- would otherwise have a SUBNORMAL low half
+// with a handful of bits (measured: differences of 3e-5 to the fp32 kernel instead of 1e-6).
+// K slots: lane (r = lane & 31, kg = lane >> 5) holds 16 of the 32: element e of the lane is tap 15 kg + e -- rows (channel, ky) 0..4 for
+// kg = 0, rows 5..8 + the bias slot + zero pads for kg = 1.
+// Taps: a lane requests ONE value per row -- its pixel's centre column (stride 2: the aligned pair of columns 2 ox, 2 ox + 1) -- whole 128-byte
+// lines per instruction, and takes the kx = 0 / kx = 2 taps from its neighbours' registers (DPP wave_shr:1 / wave_shl:1). The outer lanes of
+// the 32 have no neighbour: a tile is NV = 30 (stride 2: 31) output pixels, lanes 1..NV, the outer lanes only feed them. (First form: three
+// taps per lane and row as one 12-byte request -- 54 cycles of the texture-address path per instruction, as slow as the stores: 143 us per 16
+// images of 512 x 512, 85 without the requests OR without the stores.)
+// Pipeline per wave: straight-line over TPW tiles; tile t + 2 is requested (asm: hipcc would sink the loads to their use) when tile t starts;
+// the hand-written wait for tile t's taps leaves the stores of tiles t - 2 and t - 1 in flight (loads and stores retire in order, so a wait for
+// a request is also a wait for every older store: with the request only one tile ahead the launch ran at the pace of its store round trips --
+// 135 us per 16 images of 512 x 512, 84 without the requests OR without the stores; tests/test_isa_lint.py checks the counts).
+template <int S> struct StemTaps { typedef float type; };            // what a lane requests per row: the centre column,
+template <> struct StemTaps<2> { typedef float type __attribute__((ext_vector_type(2))); };     // stride 2: the pair (2 ox, 2 ox + 1)
+
+template <int COUT, int S, int ACT, int TPW>
 __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks) {
     constexpr int MT = (COUT + 31) / 32;         // 32-channel tiles (16 channels: the upper half of the one tile is zero weights)
     constexpr int SW = COUT + 8;                 // slab row stride (halves)
-    constexpr int NS = COUT / 16;                // 1 KB store instructions per 32-pixel tile
+    constexpr int NV = S == 1 ? 30 : 31;         // output pixels per tile: lanes 1..NV
+    constexpr int NS = (NV * COUT / 8 + 63) / 64;        // store instructions (16 bytes per lane) per tile
     if (a.zero_u32 && blockIdx.x == 0)
         for (int i = threadIdx.x; i < a.zero_count; i += 256) a.zero_u32[i] = 0u;
     __shared__ __attribute__((aligned(16))) half_t slab[4][32 * SW];
@@ -1144,19 +1155,20 @@ __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks
             const bool is_tap = kg ? e < 12 : e < 15, is_bias = kg && e == 12;
             float wv = 0.f;
             if (ch < COUT) wv = is_tap ? a.w[min(tap, 26) * COUT + ch] : is_bias ? a.bias[ch] : 0.f;
+            wv *= a.w_scale;            // (a power of two: exact) the low halves of all but negligible weights stay in fp16's normal range
             const half_t h = (half_t)wv;
             ah[mt][e >> 3][e & 7] = h;
             al[mt][e >> 3][e & 7] = (half_t)(wv - (float)h);
         }
-    // the lane's five rows q (row = 5 kg + q = channel * 3 + ky; row 9 does not exist): byte offset of the row's kx = 0 tap relative to the
-    // pixel's centre tap position in plane 0, ky, normalisation constants
+    // the lane's five rows q (row = 5 kg + q = channel * 3 + ky; row 9 does not exist): byte offset of the row's centre tap relative to the
+    // pixel's own centre tap in plane 0, ky - 1, normalisation constants
     int rowoff4[5], kyq[5];
     float qmean[5], qinv[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         const int row = min(5 * kg + q, 8);
         const int c = row / 3, ky = row - 3 * c;
-        rowoff4[q] = 4 * (c * HW + (ky - 1) * a.w_ - 1);
+        rowoff4[q] = 4 * (c * HW + (ky - 1) * a.w_);
         kyq[q] = 5 * kg + q < 9 ? ky - 1 : (1 << 20);          // the missing row is always "outside"
         qmean[q] = a.mean[c];
         qinv[q] = a.inv_std[c];
@@ -1166,46 +1178,58 @@ __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * OHW * COUT, 0, OHW * COUT * 2, 0x00020000);
     half_t* sl = slab[wave];
     const int tile0 = (bx * 4 + wave) * TPW;
-    typedef float f3 __attribute__((ext_vector_type(3)));
+    typedef typename StemTaps<S>::type fS;
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-    // the next tile to request: this lane's output pixel
-    int oy = (tile0 * 32 + r) / a.wo, ox = tile0 * 32 + r - oy * a.wo;
-    f3 raw[5];
-    int noy, nox;               // the pixel of the tile in `raw`
-    auto request = [&]() {
-        noy = oy; nox = ox;
+    // the next tile to request: this lane's pixel tile * NV + r - 1 (lane 0: the pixel in front of the tile; it may be pixel -1)
+    int oy, ox;
+    {
+        const int p0 = tile0 * NV + r - 1;
+        oy = p0 < 0 ? -1 : p0 / a.wo;
+        ox = p0 - oy * a.wo;            // (pixel -1 = row -1, last column)
+    }
+    fS raw[2][5];               // tile t's taps in raw[t & 1]: requested two tiles ahead, so that a tile's stores have two more tiles to retire in
+    int noy[2], nox[2];         // the lane's pixel of the tile in raw[b]
+    auto request = [&](const int b) {
+        noy[b] = oy; nox[b] = ox;
         const int base4 = 4 * S * (oy * a.w_ + ox);
+        const bool pix = (unsigned)oy < (unsigned)a.ho;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             const int iy = S * oy + kyq[q];
-            int off = ((unsigned)iy < (unsigned)a.h && oy < a.ho) ? base4 + rowoff4[q] : (int)0x80000000;      // out of range: no access, zeros
-            // image row 0 of plane 0 at ox = 0 (q = 0 with ky = 0, or q = 1 with ky = 1, of the kg = 0 lanes): the kx = 0 tap would sit 4 bytes in
-            // front of the buffer, and a negative offset takes the WHOLE request out of range (measured: columns 0 and 1 came back as zeros):
-            // lanes at ox = 0 ask for columns 0..2 instead and shift (normalise_split)
-            if (q <= 1) off += ox == 0 ? 4 : 0;
-            if (ABL & 4) { raw[q].x = __builtin_bit_cast(float, off); raw[q].y = raw[q].x; raw[q].z = raw[q].x; }
-            else asm volatile("buffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(raw[q]) : "v"(off), "s"(irs) : "memory");
+            const int off = ((unsigned)iy < (unsigned)a.h && pix) ? base4 + rowoff4[q] : (int)0x80000000;      // out of range: no access, zeros
+            if (S == 1) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(raw[b][q]) : "v"(off), "s"(irs) : "memory");
+            else asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(raw[b][q]) : "v"(off), "s"(irs) : "memory");
         }
-        ox += 32;
+        ox += NV;
         const bool wrap = ox >= a.wo;           // wo >= 32 (launcher): at most one row per step
         ox -= wrap ? a.wo : 0;
         oy += wrap ? 1 : 0;
     };
+    auto lane_below = [](const float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false)); };     // wave_shr:1
+    auto lane_above = [](const float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false)); };     // wave_shl:1
     half8 xh[2], xl[2];
-    auto normalise_split = [&](const bool stores_behind) {
-        if (stores_behind && NS == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
-        else if (stores_behind && NS == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
-        else if (stores_behind && NS == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]) : : "memory");
-        const bool left = nox > 0, right = S * nox + 1 < a.w_;
+    // `younger`: vector-memory operations issued behind this buffer's requests -- they may stay in flight (loads and stores retire in order)
+    auto normalise_split = [&](const int b, const int younger) {
+        fS(&w)[5] = raw[b];
+#define DN_STEM_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : : "memory"); break;
+        switch (younger) {
+            DN_STEM_WAIT(1) DN_STEM_WAIT(2) DN_STEM_WAIT(3) DN_STEM_WAIT(4) DN_STEM_WAIT(5) DN_STEM_WAIT(6) DN_STEM_WAIT(7) DN_STEM_WAIT(8)
+            DN_STEM_WAIT(9) DN_STEM_WAIT(10) DN_STEM_WAIT(11) DN_STEM_WAIT(12) DN_STEM_WAIT(13)
+            default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : : "memory"); break;
+        }
+#undef DN_STEM_WAIT
+        static_assert(NS == 1 || NS == 2 || NS == 4, "stem_split_kernel: store count");
+        const bool left = nox[b] > 0, right = S == 2 || nox[b] + 1 < a.w_;
         float x[16];
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            const bool yok = (unsigned)(S * noy + kyq[q]) < (unsigned)a.h && noy < a.ho;
+            const bool yok = (unsigned)(S * noy[b] + kyq[q]) < (unsigned)a.h && (unsigned)noy[b] < (unsigned)a.ho;
+            float t0, t1, t2;           // taps kx = 0, 1, 2: columns S ox - 1, S ox, S ox + 1
+            if constexpr (S == 1) { t0 = lane_below(w[q]); t1 = w[q]; t2 = lane_above(w[q]); }
+            else { t0 = lane_below(w[q].y); t1 = w[q].x; t2 = w[q].y; }
             // zero padding is applied to the NORMALISED image (transform, then conv)
-            const float r1 = (q <= 1 && !left) ? raw[q].x : raw[q].y, r2 = (q <= 1 && !left) ? raw[q].y : raw[q].z;
-            const float n0 = (raw[q].x - qmean[q]) * qinv[q], n1 = (r1 - qmean[q]) * qinv[q], n2 = (r2 - qmean[q]) * qinv[q];
+            const float n0 = (t0 - qmean[q]) * qinv[q], n1 = (t1 - qmean[q]) * qinv[q], n2 = (t2 - qmean[q]) * qinv[q];
             x[3 * q + 0] = (yok && left) ? n0 : 0.f;
             x[3 * q + 1] = yok ? n1 : 0.f;
             x[3 * q + 2] = (yok && right) ? n2 : 0.f;
@@ -1219,49 +1243,51 @@ __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks
             xl[e >> 3][e & 7] = (half_t)(x[e] - (float)h);
         }
     };
+    // order of the vector-memory operations: R(0) R(1) | tile 0: R(2) S(0) | tile 1: R(3) S(1) | ...  -- behind R(k) when tile k starts:
+    // S(k - 2) if k >= 2, R(k + 1) if it exists, S(k - 1) if k >= 1
+    request(0);
+    if (TPW > 1) request(1);
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-        if (tt == 0) request();
-        normalise_split(tt > 0);
-        if (tt + 1 < TPW) request();
+        normalise_split(tt & 1, (tt >= 2 ? NS : 0) + (tt + 1 < TPW ? 5 : 0) + (tt >= 1 ? NS : 0));
+        if (tt + 2 < TPW) request(tt & 1);
         __builtin_amdgcn_sched_barrier(0);          // the requests stay in front of the work they overlap with
         floatx16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
-            if (!(ABL & 2)) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 2; ++k) {              // the small terms first
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt][k], xh[k], acc[mt], 0, 0, 0);
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt][k], xl[k], acc[mt], 0, 0, 0);
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt][k], xh[k], acc[mt], 0, 0, 0);
-            } else { acc[mt][0] = (float)xh[0][0] + (float)xl[1][3]; acc[mt][5] = (float)xh[1][2]; }
         }
         // lane = pixel r, registers 4g..4g+3 of tile mt = channels 32 mt + 8 g + 4 kg .. +3
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int g = 0; g < (COUT >= 32 ? 4 : 2); ++g) {
-                float t4[4] = {acc[mt][4 * g + 0], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                float t4[4] = {acc[mt][4 * g + 0] * a.w_unscale, acc[mt][4 * g + 1] * a.w_unscale, acc[mt][4 * g + 2] * a.w_unscale,
+                               acc[mt][4 * g + 3] * a.w_unscale};
                 dn_act_n<float[4], 4>(t4, ACT);
                 half4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hv[e] = (half_t)t4[e];
                 *reinterpret_cast<half4*>(sl + r * SW + 32 * mt + 8 * g + 4 * kg) = hv;
             }
-        // the slab is private to the wave: its own LDS operations are ordered, no barrier
+        // the slab is private to the wave: its own LDS operations are ordered, no barrier. Slab rows 1..NV are the tile's pixels.
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-            const int ch = lane + 64 * u;                   // 16-B chunk of the 32 x (2 COUT)-byte tile
+            const int ch = lane + 64 * u;                   // 16-B chunk of the NV x (2 COUT)-byte tile
             const int row = ch / (COUT / 8), q = ch % (COUT / 8);
-            const u4 val = *reinterpret_cast<const u4*>(sl + row * SW + q * 8);
-            const int off = (ABL & 1) ? (int)0x80000000 : ((tile0 + tt) * 32 + row) * (COUT * 2) + q * 16;
+            const u4 val = *reinterpret_cast<const u4*>(sl + min(row + 1, 31) * SW + q * 8);
+            const int off = row >= NV ? (int)0x80000000 : ((tile0 + tt) * NV + row) * (COUT * 2) + q * 16;
             // (s_nop: a store of more than 8 bytes reads its data registers a cycle after it issues; hipcc keeps writers of those registers
             //  away from the stores it knows, an asm statement is opaque to it)
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(val), "v"(off), "s"(ors) : "memory");       // rows beyond the image: out of range, dropped
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(val), "v"(off), "s"(ors) : "memory");       // pixels beyond the image: out of range, dropped
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1272,20 +1298,18 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
     const int images = a.xq > 0 ? 8 * a.xq : a.n;      // image slots of the launch (XCD grouping: 8 groups of xq)
     if (K == 3 && a.pad == 1 && a.split_ok && dn_knob("DN_STEM_SPLIT", 1) && a.wo >= 32 && (long)3 * a.h * a.w_ < (1L << 28) &&
         (long)a.ho * a.wo * COUT < (1L << 29)) {
-        constexpr int TPW = 8;
-        const int tiles = dn_cdiv((long)a.ho * a.wo, 32);
-        const int nblocks = dn_cdiv(tiles, 4 * TPW);
+        // waves of 8 tiles (the weights' split once per 8 tiles); 4 where that leaves the chip under ~5 waves per SIMD (the 160 x 160 outputs of the
+        // MobileNet stems at 32 images per chain: a wave's tiles run one after the other, each with its own round trip)
+        const int nv = a.stride == 1 ? 30 : 31;
+        const int tiles = dn_cdiv((long)a.ho * a.wo, nv);
+        const int tpw = (long)tiles * images >= 8L * 5120 ? 8 : 4;
+        const int nblocks = dn_cdiv(tiles, 4 * tpw);
         const dim3 grid(nblocks * images);
-        const int abl = dn_knob("DN_STEM_ABL", 0);
 #define DN_STEM_SPLIT_CASE(C, S_, ACT_)                                                                                                    \
         if (COUT == C && a.stride == S_ && a.act == ACT_ && (S_ == 1 ? (a.ho == a.h && a.wo == a.w_) : ((a.w_ & 1) == 0 && 2 * a.wo == a.w_ && a.ho == (a.h + 1) / 2))) { \
             dn_note_kernel("stem_split_kernel<%d,%d>", C, S_);                                                                             \
-            if (abl == 1) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 1>), grid, dim3(256), 0, s, a, nblocks);                 \
-            else if (abl == 2) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 2>), grid, dim3(256), 0, s, a, nblocks);            \
-            else if (abl == 3) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 3>), grid, dim3(256), 0, s, a, nblocks);            \
-            else if (abl == 4) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 4>), grid, dim3(256), 0, s, a, nblocks);            \
-            else if (abl == 7) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW, 7>), grid, dim3(256), 0, s, a, nblocks);            \
-            else hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, TPW>), grid, dim3(256), 0, s, a, nblocks);                             \
+            if (tpw == 8) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, 8>), grid, dim3(256), 0, s, a, nblocks);                 \
+            else hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, 4>), grid, dim3(256), 0, s, a, nblocks);                               \
             return DN_OK;                                                                                                                  \
         }
         DN_STEM_SPLIT_CASE(64, 1, DN_ACT_RELU)
@@ -1305,16 +1329,7 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
         if (dn_knob("DN_STEM_PIPE", 1) && a.pad == 1 && a.act == DN_ACT_RELU && a.ho == a.h && a.wo == a.w_ && a.wo >= 32 && (long)a.h * a.w_ < (1L << 24)) {
             dn_note_kernel("stem_mfma64p_kernel");
             const int nblocks = dn_cdiv(tiles, 4 * per_wave);
-            switch (dn_knob("DN_STEM_ABL", 0)) {
-            case 1: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 1>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
-            case 2: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 2>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
-            case 3: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 3>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
-            case 4: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 4>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
-            case 5: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 5>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
-            case 6: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 6>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
-            case 7: hipLaunchKernelGGL((stem_mfma64p_kernel<8, 7>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks); break;
-            default: hipLaunchKernelGGL((stem_mfma64p_kernel<8>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks);
-            }
+            hipLaunchKernelGGL((stem_mfma64p_kernel<8>), dim3(nblocks * images), dim3(256), 0, s, a, nblocks);
             return DN_OK;
         }
         dn_note_kernel("stem_mfma64_kernel");

@@ -125,7 +125,8 @@ struct dn_plan {
     int n_se_in_dw = 0;                     // such pairs; slot q of the counter block belongs to the q-th
     std::vector<int> se_slot;               // per op (DW op of a pair): q
     int post_ticket_slot = -1;              // slot of the counter block lent to launch_postprocess (PostArgs::tickets); needs the stem launch that zeroes the block
-    std::vector<char> stem_split_ok;        // per op: STEM op whose weights and bias fit fp16's range (dn_create checks the host copy)
+    std::vector<char> stem_split_ok;        // per op: STEM op that may run on the split-fp16 matrix kernel (dn_create checks the host copy of the weights)
+    std::vector<int> stem_scale_log2;       // per op: its power-of-two weight scale
     std::vector<int> se_fold;               // per op: PW op -> index of the SE op whose FCs run in its prologue (pointwise.hip SEF), SE op -> -2, else -1
     std::vector<char> tail_materialise;     // per op of the run: its output is read outside the run (pyramid feature) -> also to HBM            // optional extra output of the merge kernel (dn_set_packed_output)
     // inverted-residual stages that run as one launch (expdw.hip): at the first op of a group, fused_len = number of ops and
@@ -401,17 +402,29 @@ extern "C" int dn_create(const dn_model_desc* desc, const void* weights, size_t 
     }
     // ---- small squeeze-excitations (c <= 128, squeeze <= 32: the 40 x 40 blocks of MobileNetV3) are computed in the prologue of the
     //      projection that consumes them: one dependent launch (~10 us of pure latency) less per block
-    // ---- stems: the split-fp16 matrix kernel (depthwise.hip stem_split_kernel) needs weights and bias that fp16 can hold (finite, |v| < 6e4)
+    // ---- stems: the split-fp16 matrix kernel (depthwise.hip stem_split_kernel) takes weights and bias scaled by a power of two such that the
+    //      largest magnitude lands in [2^13, 2^15) (the low halves of the split then stay normal fp16 numbers), and a normalised image that fp16 holds
+    //      (pixels in [0, 1]: |x| <= max(mean, 1 - mean) / std)
     p->stem_split_ok.assign(desc->n_ops, 0);
+    p->stem_scale_log2.assign(desc->n_ops, 0);
     for (int i = 0; i < desc->n_ops; ++i) {
         const dn_op_desc& so = p->ops[i];
         if (so.type != DN_OP_STEM) continue;
         const float* hw = reinterpret_cast<const float*>(static_cast<const unsigned char*>(weights) + so.w_off);
         const float* hb = reinterpret_cast<const float*>(static_cast<const unsigned char*>(weights) + so.b_off);
         bool ok = true;
-        for (int q = 0; q < so.k * so.k * 3 * so.cout; ++q) ok = ok && std::fabs(hw[q]) < 6.0e4f;      // (false for NaN too)
-        for (int q = 0; q < so.cout; ++q) ok = ok && std::fabs(hb[q]) < 6.0e4f;
+        float big = 0.f;
+        for (int q = 0; q < so.k * so.k * 3 * so.cout; ++q) { ok = ok && std::isfinite(hw[q]); big = std::max(big, std::fabs(hw[q])); }
+        for (int q = 0; q < so.cout; ++q) { ok = ok && std::isfinite(hb[q]); big = std::max(big, std::fabs(hb[q])); }
+        for (int c = 0; c < 3; ++c) ok = ok && desc->std[c] > 0.f && std::max(std::fabs(desc->mean[c]), std::fabs(1.f - desc->mean[c])) / desc->std[c] < 3.0e4f;
+        int e = 0;
+        if (ok && big > 0.f) {
+            (void)std::frexp(big, &e);           // big = m 2^e, m in [0.5, 1)
+            e = 15 - e;                          // big 2^e in [2^14, 2^15)
+            e = std::max(-100, std::min(100, e));
+        }
         p->stem_split_ok[i] = ok ? 1 : 0;
+        p->stem_scale_log2[i] = e;
     }
     p->se_fold.assign(desc->n_ops, -1);
     for (int i = 0; i + 1 < desc->n_ops; ++i) {
@@ -1119,6 +1132,8 @@ static int enqueue(dn_plan* p, const float* images, int n, int h, int w, float* 
                 for (int c = 0; c < 3; ++c) { a.mean[c] = d.mean[c]; a.inv_std[c] = 1.0f / d.std[c]; }
                 a.xq = xq;
                 a.split_ok = p->stem_split_ok[i];
+                a.w_scale = std::ldexp(1.0f, p->stem_scale_log2[i]);
+                a.w_unscale = std::ldexp(1.0f, -p->stem_scale_log2[i]);
                 if (p->n_se_in_dw > 0) { a.zero_u32 = reinterpret_cast<unsigned*>(ws + L.secnt_off); a.zero_count = p->n_se_in_dw * n; }
                 rc = launch_stem(a, s);
                 break;
