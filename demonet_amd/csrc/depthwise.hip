@@ -1298,18 +1298,18 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
     const int images = a.xq > 0 ? 8 * a.xq : a.n;      // image slots of the launch (XCD grouping: 8 groups of xq)
     if (K == 3 && a.pad == 1 && a.split_ok && dn_knob("DN_STEM_SPLIT", 1) && a.wo >= 32 && (long)3 * a.h * a.w_ < (1L << 28) &&
         (long)a.ho * a.wo * COUT < (1L << 29)) {
-        // waves of 8 tiles (the weights' split once per 8 tiles); 4 where that leaves the chip under ~5 waves per SIMD (the 160 x 160 outputs of the
-        // MobileNet stems at 32 images per chain: a wave's tiles run one after the other, each with its own round trip)
+        // tiles per wave: 8 for the 64-channel stem (the weights' split -- 64 values per lane -- once per 8 tiles), 4 for the narrow ones (their
+        // launches are small: more, shorter waves; measured 4 / 8 / 16: 17.5 / 19.3 / 19.0 us for 16 channels, 36.2 / 38.0 / 38.4 for 32,
+        // 147.5 / 144.8 / 144.6 for 64)
+        constexpr int TPW = COUT >= 64 ? 8 : 4;
         const int nv = a.stride == 1 ? 30 : 31;
         const int tiles = dn_cdiv((long)a.ho * a.wo, nv);
-        const int tpw = (long)tiles * images >= 8L * 5120 ? 8 : 4;
-        const int nblocks = dn_cdiv(tiles, 4 * tpw);
+        const int nblocks = dn_cdiv(tiles, 4 * TPW);
         const dim3 grid(nblocks * images);
 #define DN_STEM_SPLIT_CASE(C, S_, ACT_)                                                                                                    \
         if (COUT == C && a.stride == S_ && a.act == ACT_ && (S_ == 1 ? (a.ho == a.h && a.wo == a.w_) : ((a.w_ & 1) == 0 && 2 * a.wo == a.w_ && a.ho == (a.h + 1) / 2))) { \
             dn_note_kernel("stem_split_kernel<%d,%d>", C, S_);                                                                             \
-            if (tpw == 8) hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, 8>), grid, dim3(256), 0, s, a, nblocks);                 \
-            else hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, 4>), grid, dim3(256), 0, s, a, nblocks);                               \
+            hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, (C >= 64 ? 8 : 4)>), grid, dim3(256), 0, s, a, nblocks);                    \
             return DN_OK;                                                                                                                  \
         }
         DN_STEM_SPLIT_CASE(64, 1, DN_ACT_RELU)

@@ -216,11 +216,12 @@ def test_weights_resident_patch_kernel_is_bit_identical_to_the_streamed_one(name
 
 @pytest.mark.parametrize("name,n,size", [("ssd300_vgg16", 5, 300), ("ssd512_vgg16", 3, 512), ("ssd300_vgg16", 33, 300)])
 def test_pipelined_stem_is_bit_identical_to_the_sequential_one(name, n, size, monkeypatch):
-    """Round 6 (DN_STEM_PIPE, default 1): conv1_1 of the VGG models (3 -> 64 on the full-size image, ssd_vgg16.py:33 via torchvision vgg16
+    """Round 6 (DN_STEM_PIPE, default 1; the fallback behind DN_STEM_SPLIT): conv1_1 of the VGG models (3 -> 64 on the full-size image, ssd_vgg16.py:33 via torchvision vgg16
     features[0], behind the transform's normalisation) on stem_mfma64p_kernel -- the same 32-pixel tiles, fp32 products and accumulation order as
     stem_mfma64_kernel with the next tile's taps requested ahead and the previous tile's epilogue in the shadow of the MFMA chain. Head outputs
     equal bit for bit; 300 x 300 is ragged (2812.5 tiles per image: the last workgroup's tiles run off the image, rows wrap inside a tile)."""
     imgs = torch.from_numpy(synth.images(61, n, size, size)).cuda()
+    monkeypatch.setenv("DN_STEM_SPLIT", "0")            # the fp32 kernels: what runs when a model's weights do not fit the split-fp16 kernel
     res = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("DN_STEM_PIPE", flag)

@@ -153,7 +153,7 @@ def test_hand_scheduled_requests_and_stores_of_the_stem_kernels(tmp_path):
     text = _asm("depthwise.hip", tmp_path, _BUILD_EXTRA["depthwise.hip"])
     kernels, meta = _kernels(text)
     stems = {k: v for k, v in kernels.items() if "stem_split_kernel" in k or "stem_mfma64p_kernel" in k}
-    assert len(stems) >= 7, [k for k in kernels if "stem" in k]          # three split configurations x 4 / 8 tiles per wave + the fp32 pipeline
+    assert len(stems) >= 4, [k for k in kernels if "stem" in k]          # three split configurations + the fp32 pipeline
     for name, lines in stems.items():
         n = _lint_asm_loads(lines, name)
         assert n >= 20, (name, n)                  # 5 requests per tile x 4 or 8 tiles (14 x 8 for the fp32 kernel)
