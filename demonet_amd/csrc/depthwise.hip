@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(256) void stem_mfma64p_kernel(StemArgs a, int nbloc
 template <int S> struct StemTaps { typedef float type; };            // what a lane requests per row: the centre column,
 template <> struct StemTaps<2> { typedef float type __attribute__((ext_vector_type(2))); };     // stride 2: the pair (2 ox, 2 ox + 1)
 
-template <int COUT, int S, int ACT, int TPW>
+template <int COUT, int S, int ACT, int TPW, int D, bool TOUCH>
 __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks) {
     constexpr int MT = (COUT + 31) / 32;         // 32-channel tiles (16 channels: the upper half of the one tile is zero weights)
     constexpr int SW = COUT + 8;                 // slab row stride (halves)
@@ -1188,8 +1188,8 @@ __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks
         oy = p0 < 0 ? -1 : p0 / a.wo;
         ox = p0 - oy * a.wo;            // (pixel -1 = row -1, last column)
     }
-    fS raw[2][5];               // tile t's taps in raw[t & 1]: requested two tiles ahead, so that a tile's stores have two more tiles to retire in
-    int noy[2], nox[2];         // the lane's pixel of the tile in raw[b]
+    fS raw[D][5];               // tile t's taps in raw[t % D]: requested D tiles ahead, so that a tile's stores have D more tiles to retire in
+    int noy[D], nox[D];         // the lane's pixel of the tile in raw[b]
     auto request = [&](const int b) {
         noy[b] = oy; nox[b] = ox;
         const int base4 = 4 * S * (oy * a.w_ + ox);
@@ -1215,7 +1215,9 @@ __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks
 #define DN_STEM_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : : "memory"); break;
         switch (younger) {
             DN_STEM_WAIT(1) DN_STEM_WAIT(2) DN_STEM_WAIT(3) DN_STEM_WAIT(4) DN_STEM_WAIT(5) DN_STEM_WAIT(6) DN_STEM_WAIT(7) DN_STEM_WAIT(8)
-            DN_STEM_WAIT(9) DN_STEM_WAIT(10) DN_STEM_WAIT(11) DN_STEM_WAIT(12) DN_STEM_WAIT(13)
+            DN_STEM_WAIT(9) DN_STEM_WAIT(10) DN_STEM_WAIT(11) DN_STEM_WAIT(12) DN_STEM_WAIT(13) DN_STEM_WAIT(14) DN_STEM_WAIT(15) DN_STEM_WAIT(16)
+            DN_STEM_WAIT(17) DN_STEM_WAIT(18) DN_STEM_WAIT(19) DN_STEM_WAIT(20) DN_STEM_WAIT(21) DN_STEM_WAIT(22) DN_STEM_WAIT(23) DN_STEM_WAIT(24)
+            DN_STEM_WAIT(25) DN_STEM_WAIT(26) DN_STEM_WAIT(27) DN_STEM_WAIT(28) DN_STEM_WAIT(29) DN_STEM_WAIT(30) DN_STEM_WAIT(31)
             default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : : "memory"); break;
         }
 #undef DN_STEM_WAIT
@@ -1243,14 +1245,33 @@ __global__ __launch_bounds__(256) void stem_split_kernel(StemArgs a, int nblocks
             xl[e >> 3][e & 7] = (half_t)(x[e] - (float)h);
         }
     };
-    // order of the vector-memory operations: R(0) R(1) | tile 0: R(2) S(0) | tile 1: R(3) S(1) | ...  -- behind R(k) when tile k starts:
-    // S(k - 2) if k >= 2, R(k + 1) if it exists, S(k - 1) if k >= 1
-    request(0);
-    if (TPW > 1) request(1);
+    // Every line of the image the wave's tiles will ask for is touched once up front (two requests per lane into a register nobody reads: the
+    // oldest vector-memory operations of the wave, so no wait ever depends on them): behind a chip-wide stream of stores a first touch
+    // takes longer than the two tiles a request runs ahead.
+    float sink[2] = {0.f, 0.f};         // (kept allocated until the first wait has retired the two requests: tile loop)
+    if (TOUCH) {
+        const int p0 = tile0 * NV - 1;                                   // the wave's first pixel
+        const int y0 = p0 < 0 ? 0 : p0 / a.wo, x0 = p0 < 0 ? 0 : p0 - y0 * a.wo;
+        const int span = (TPW * NV + 2) * S * 4;                         // bytes of one input row the wave's pixels cover (rows wrap: the touch is approximate)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int l = lane + 64 * u, row = l >> 3, seg = l & 7;      // 9 (channel, ky) rows x 8 segments
+            const int c = row / 3, ky = row - 3 * c;
+            const int iy = S * y0 + ky - 1;
+            const int off = (row < 9 && (unsigned)iy < (unsigned)a.h && seg * ((span + 7) / 8) < span) ? 4 * (c * HW + iy * a.w_ + S * x0) + seg * ((span + 7) / 8) : (int)0x80000000;
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(sink[u]) : "v"(off), "s"(irs) : "memory");
+        }
+    }
+    // order of the vector-memory operations: R(0) .. R(D - 1) | tile 0: R(D) S(0) | tile 1: R(D + 1) S(1) | ...  -- behind R(k) when tile k starts:
+    // the requests k + 1 .. k + D - 1 that exist and the stores of the min(k, D) tiles before it
+    static_assert(D >= 1 && 5 * (D - 1) + NS * D <= 31, "stem_split_kernel: wait count");
+#pragma unroll
+    for (int k = 0; k < D && k < TPW; ++k) request(k);
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-        normalise_split(tt & 1, (tt >= 2 ? NS : 0) + (tt + 1 < TPW ? 5 : 0) + (tt >= 1 ? NS : 0));
-        if (tt + 2 < TPW) request(tt & 1);
+        normalise_split(tt % D, 5 * ((tt + D - 1 < TPW - 1 ? tt + D - 1 : TPW - 1) - tt) + NS * (tt < D ? tt : D));
+        if (tt == 0) asm volatile("" : "+v"(sink[0]), "+v"(sink[1]) : : "memory");      // the touch requests are older than tile 0's taps: retired by now
+        if (tt + D < TPW) request(tt % D);
         __builtin_amdgcn_sched_barrier(0);          // the requests stay in front of the work they overlap with
         floatx16 acc[MT];
 #pragma unroll
@@ -1298,6 +1319,9 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
     const int images = a.xq > 0 ? 8 * a.xq : a.n;      // image slots of the launch (XCD grouping: 8 groups of xq)
     if (K == 3 && a.pad == 1 && a.split_ok && dn_knob("DN_STEM_SPLIT", 1) && a.wo >= 32 && (long)3 * a.h * a.w_ < (1L << 28) &&
         (long)a.ho * a.wo * COUT < (1L << 29)) {
+        // requests run 3 tiles ahead and the wave touches its lines up front for the 64-channel stem (1 GB of stores per forward: a first touch of an
+        // image line behind that stream outlasts two tiles; 16 images of 512 x 512, same box: 145 us -> 126 with the touch, 128 with 3 tiles
+        // ahead, 121 - 126 with both, 123 with 4), 2 tiles ahead and no touch for the narrow ones (17.6 / 36.3 us; with the touch 19.1 / 37.2).
         // tiles per wave: 8 for the 64-channel stem (the weights' split -- 64 values per lane -- once per 8 tiles), 4 for the narrow ones (their
         // launches are small: more, shorter waves; measured 4 / 8 / 16: 17.5 / 19.3 / 19.0 us for 16 channels, 36.2 / 38.0 / 38.4 for 32,
         // 147.5 / 144.8 / 144.6 for 64)
@@ -1309,7 +1333,7 @@ int launch_stem_t(const StemArgs& a, hipStream_t s) {
 #define DN_STEM_SPLIT_CASE(C, S_, ACT_)                                                                                                    \
         if (COUT == C && a.stride == S_ && a.act == ACT_ && (S_ == 1 ? (a.ho == a.h && a.wo == a.w_) : ((a.w_ & 1) == 0 && 2 * a.wo == a.w_ && a.ho == (a.h + 1) / 2))) { \
             dn_note_kernel("stem_split_kernel<%d,%d>", C, S_);                                                                             \
-            hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, (C >= 64 ? 8 : 4)>), grid, dim3(256), 0, s, a, nblocks);                    \
+            hipLaunchKernelGGL((stem_split_kernel<C, S_, ACT_, (C >= 64 ? 8 : 4), (C >= 64 ? 3 : 2), (C >= 64)>), grid, dim3(256), 0, s, a, nblocks); \
             return DN_OK;                                                                                                                  \
         }
         DN_STEM_SPLIT_CASE(64, 1, DN_ACT_RELU)

@@ -2,7 +2,7 @@
 # dev tool: VGPRs / scratch / occupancy of every kernel of one csrc file (cross-compiles; no GPU needed).   usage: tools/kres.sh depthwise [filter]
 cd "$(dirname "$0")/.."
 b=$1; extra=""
-case $b in pwdirect|pointwise|tail) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; postprocess) extra="-ffp-contract=off";; esac
+case $b in pwdirect|pointwise|tail|depthwise) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; postprocess) extra="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-gpu-rdc $extra -c demonet_amd/csrc/$b.hip -o /tmp/kres_$b.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re,subprocess
 cur=None; rows={}
