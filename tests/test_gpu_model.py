@@ -285,6 +285,28 @@ def test_split_fp16_stem_is_within_an_fp16_ulp_of_the_fp32_stem(name, n, size, m
     assert (res["0"][0] - res["1"][0]).abs().mean().item() <= LOGIT_MEAN
 
 
+def test_stem_falls_back_to_fp32_when_the_input_range_does_not_fit_fp16(monkeypatch):
+    """dn_create checks what stem_split_kernel needs (plan.hip: finite weights, and a normalised input range below 3e4 for pixels in [0, 1]); a model
+    whose statistics break that -- image_std 1e-5: inputs up to 6e4, the first conv's weights scaled down to match -- runs the fp32 stem without being
+    told to: its head outputs equal the DN_STEM_SPLIT=0 run bit for bit (the split kernel's would differ in the last place of ~0.05 % of the stem's outputs,
+    test_split_fp16_stem...), and they are finite."""
+    name = "ssdlite320_mobilenet_v3_large"
+    std = [1e-5, 1e-5, 1e-5]
+    imgs = torch.stack(_images(models.ssdlite320_mobilenet_v3_large(num_classes=91).graph, [911, 912, 913]))
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DN_STEM_SPLIT", flag)
+        m = getattr(models, name)(num_classes=91, image_std=std)
+        sd = synth.state_dict(m.graph, 0)
+        k0 = next(k for k in sd if k.endswith("features.0.0.0.weight"))
+        sd[k0] = sd[k0] * np.float32(1e-5)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        m.cuda()
+        res[flag] = [t.clone() for t in m.forward_heads(imgs)]
+    assert torch.isfinite(res["1"][0]).all() and res["1"][0].abs().max().item() > 0.5
+    assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
 def test_model_heads_match_golden(golden_dir):
     z = _golden(golden_dir, "ssdlite320_mobilenet_v3_large")
     m = _model("ssdlite320_mobilenet_v3_large", z)
