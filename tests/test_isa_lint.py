@@ -268,3 +268,21 @@ def test_no_instruction_reads_a_matrix_result_before_it_is_written(tmp_path):
         assert "v_mfma" in text, src
         bad = asm_hazards(text)        # (consumers in `asm` statements: the ones hipcc's own hazard recognizer cannot see)
         assert not bad, f"{src}: {len(bad)} inline-asm reads of a matrix result inside its hazard window, first: {bad[0]}"
+
+
+def test_every_asm_issued_wide_store_carries_its_wait_state():
+    """A store of more than 8 bytes reads its data registers a cycle after it issues; hipcc keeps writers of those registers away from the stores IT
+    emits, an `asm` statement is opaque to it (round 6: 0.2 % of stem_split_kernel's first outputs were non-deterministic). Source-level rule for
+    every kernel file: an asm statement that issues a 12- or 16-byte store ends with `s_nop 1` (or more) inside the same statement."""
+    pat = re.compile(r'asm\s+volatile\s*\(\s*"((?:[^"\\]|\\.)*)"')
+    seen = 0
+    for fn in sorted(os.listdir(CSRC)):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        for m in pat.finditer(open(os.path.join(CSRC, fn)).read()):
+            text = m.group(1)
+            if re.search(r"(buffer|global|flat|scratch)_store_dwordx[34]", text):
+                seen += 1
+                assert re.search(r"store_dwordx[34][^\\]*\\n\\ts_nop [1-9]", text), f"{fn}: `{text}` has no wait state behind its store"
+    assert seen >= 2
+
