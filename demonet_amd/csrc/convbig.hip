@@ -1108,9 +1108,13 @@ __global__ __launch_bounds__(256) void conv_patch_resident_kernel(PwArgs a, int 
             __builtin_amdgcn_sched_barrier(0);
         });
         CP_STAMP_IF(k == 2, 4);
-        // the next block's patch and the stores issued above: landed; everyone is done reading this block's patch
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // the next block's patch has landed and everyone is done reading this block's patch. The wave's stores of the previous block's result
+        // (4 with the pool, 16 without: every unit issues its store, out of range or not) are all YOUNGER than its patch requests (steps 0 - 9
+        // against 10 - 29; loads and stores retire in order), so the count leaves them in flight: with vmcnt(0) -- or __syncthreads(), whose
+        // release fence waits for vmcnt(0) too -- every block ended with a wait for the acknowledgement of stores issued 0.3 - 2 us earlier
+        // (conv2_1, 16 stores per block: 164 -> 156 - 158 us per 16 images of 512 x 512; conv1_2 with its 4 pooled stores: level).
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(POOL ? 4 : 16) : "memory");
+        __builtin_amdgcn_s_barrier();
         CP_STAMP_IF(k == 2, 5);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
